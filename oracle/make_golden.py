@@ -1,0 +1,297 @@
+"""Golden-fixture generator: runs the REAL reference modules (imported from /root/reference with the two
+stubs of oracle/ref_import.py) on builder-PRNG weights/inputs and stores inputs + expected outputs under
+tests/golden/.  Runs only in the authoring container; the fixtures are data (no reference source).
+
+    python -m oracle.make_golden [--full]      # --full adds the IndexTTS-1.5-sized id/logit fixtures
+
+The weights are NOT stored: they regenerate bit-identically from itts_hip.synth (integer PRNG).
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "index-tts-ipex_amd"))
+
+from itts_hip import config as icfg  # noqa: E402
+from itts_hip import prng, synth  # noqa: E402
+from oracle import ref_import  # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+class H(dict):
+    __getattr__ = dict.__getitem__
+
+    def __setattr__(self, k, v):
+        self[k] = v
+
+
+def tt(sd):
+    return {k: torch.from_numpy(np.array(v)) for k, v in sd.items()}
+
+
+def build_ref_gpt(cfg, seed):
+    from indextts.gpt.model import UnifiedVoice
+
+    m = UnifiedVoice(**cfg.gpt)
+    sd = tt(synth.gpt_state_dict(cfg, seed))
+    ref_sd = m.state_dict()
+    assert set(sd) == set(ref_sd), (sorted(set(sd) ^ set(ref_sd))[:10])
+    for k in sd:
+        assert tuple(sd[k].shape) == tuple(ref_sd[k].shape), (k, sd[k].shape, ref_sd[k].shape)
+    m.load_state_dict(sd, strict=True)
+    m.eval()
+    m.post_init_gpt2_config(use_deepspeed=False, kv_cache=True, half=False)
+    return m
+
+
+def build_ref_bigvgan(cfg, seed):
+    from indextts.BigVGAN.models import BigVGAN
+
+    m = BigVGAN(H(cfg.bigvgan), use_cuda_kernel=False)
+    m.eval()
+    m.remove_weight_norm()
+    sd = tt(synth.bigvgan_state_dict(cfg, seed))
+    ref_sd = m.state_dict()
+    missing = [k for k in ref_sd if k not in sd]
+    assert all(k.endswith("filter") for k in missing), [k for k in missing if not k.endswith("filter")][:10]
+    assert not [k for k in sd if k not in ref_sd]
+    for k in sd:
+        assert tuple(sd[k].shape) == tuple(ref_sd[k].shape), (k, sd[k].shape, ref_sd[k].shape)
+    m.load_state_dict(sd, strict=False)
+    return m
+
+
+def build_ref_dvae(cfg, seed):
+    from indextts.vqvae.xtts_dvae import DiscreteVAE
+
+    m = DiscreteVAE(**{k: v for k, v in cfg.vqvae.items()})
+    m.eval()
+    sd = tt(synth.dvae_state_dict(cfg, seed))
+    ref_sd = m.state_dict()
+    assert not [k for k in sd if k not in ref_sd]
+    for k in sd:
+        assert tuple(sd[k].shape) == tuple(ref_sd[k].shape), (k, sd[k].shape, ref_sd[k].shape)
+    dec_keys = [k for k in ref_sd if k.startswith("decoder.") or k == "codebook.embed"]
+    assert set(dec_keys) == set(sd), sorted(set(dec_keys) ^ set(sd))[:10]
+    m.load_state_dict(sd, strict=False)
+    return m
+
+
+def ref_greedy(gpt, cond_mel, text, max_gen, rep=10.0, n_trace=None):
+    """Hand-rolled HF-4.36.2-style greedy_search over the reference's own GPT2InferenceModel.forward
+    (the installed transformers-5.x `generate` skips the prefill, so it is not used)."""
+    from transformers import RepetitionPenaltyLogitsProcessor
+
+    stop = gpt.stop_mel_token
+    lens = torch.tensor([cond_mel.shape[-1]])
+    conds = gpt.get_conditioning(cond_mel, lens)
+    ids, emb, mask = gpt.prepare_gpt_inputs(conds, text)
+    gpt.inference_model.store_mel_emb(emb)
+    s = emb.shape[1]
+    proc = RepetitionPenaltyLogitsProcessor(rep)
+    past = None
+    b = ids.shape[0]
+    unfinished = torch.ones(b, dtype=torch.long)
+    logits_trace = []
+    while True:
+        inp = ids if past is None else ids[:, -1:]
+        out = gpt.inference_model(input_ids=inp, past_key_values=past, attention_mask=mask, use_cache=True,
+                                  return_dict=True)
+        past = out.past_key_values
+        logits = out.logits[:, -1, :]
+        if n_trace is None or len(logits_trace) < n_trace:
+            logits_trace.append(logits.clone())
+        scores = proc(ids, logits.clone())
+        nxt = torch.argmax(scores, dim=-1)
+        nxt = nxt * unfinished + stop * (1 - unfinished)
+        ids = torch.cat([ids, nxt[:, None]], dim=-1)
+        mask = torch.cat([mask, torch.ones(b, 1, dtype=mask.dtype)], dim=-1)
+        unfinished = unfinished * (nxt != stop).long()
+        if unfinished.max() == 0 or ids.shape[-1] >= s + 1 + max_gen:
+            break
+    return ids[:, s + 1:], torch.stack(logits_trace, 1), conds, emb, mask[:, : s + 1]
+
+
+def save(name, **arrs):
+    os.makedirs(GOLD, exist_ok=True)
+    out = {}
+    for k, v in arrs.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        out[k] = np.asarray(v)
+    path = os.path.join(GOLD, name + ".npz")
+    np.savez_compressed(path, **out)
+    print(f"  wrote {path} ({os.path.getsize(path) / 1024:.1f} KiB)")
+
+
+def rnd(name, shape, seed=3, std=1.0, mean=0.0):
+    return torch.from_numpy(prng.tensor(name, seed, shape, std=std, mean=mean))
+
+
+@torch.no_grad()
+def micro_fixtures():
+    cfg = icfg.micro()
+    seed = 1234
+    g = cfg.gpt
+    print("[micro] activation1d / filter")
+    from indextts.BigVGAN import activations
+    from indextts.BigVGAN.alias_free_torch import Activation1d
+
+    for tag, (B, C, T) in {"a": (2, 8, 37), "b": (1, 24, 5), "c": (1, 3, 1)}.items():
+        act = Activation1d(activation=activations.SnakeBeta(C, alpha_logscale=True))
+        al, be = rnd(f"act.{tag}.alpha", (C,), std=0.4), rnd(f"act.{tag}.beta", (C,), std=0.4)
+        act.act.alpha.data.copy_(al)
+        act.act.beta.data.copy_(be)
+        x = rnd(f"act.{tag}.x", (B, C, T), std=1.5)
+        save(f"micro_act1d_{tag}", x=x, alpha=al, beta=be, y=act(x), filt=act.upsample.filter.view(-1),
+             filt_down=act.downsample.lowpass.filter.view(-1))
+
+    print("[micro] GPT conditioning / prefix / decode / latent")
+    gpt = build_ref_gpt(cfg, seed)
+    mel = torch.from_numpy(synth.prompt_mel(61, seed=7))
+    lens = torch.tensor([mel.shape[-1]])
+    enc, mask = gpt.conditioning_encoder(mel.transpose(1, 2), lens)
+    assert bool(mask.all())
+    cond = gpt.get_conditioning(mel, lens)
+    save("micro_conditioning", mel=mel, conformer_out=enc, cond=cond)
+
+    L = 11
+    text = torch.from_numpy(synth.text_ids(L, 11, g.number_text_tokens)).view(1, L).int()
+    codes, logits, conds, emb, mask0 = ref_greedy(gpt, mel, text, max_gen=24)
+    save("micro_decode_b1", text=text, codes=codes, logits=logits, prefix_emb=emb, prefix_mask=mask0)
+    # sensitivity self-check data: one changed text id
+    text2 = text.clone()
+    text2[0, 3] = (int(text2[0, 3]) + 7) % (g.number_text_tokens - 2) + 2
+    codes2, logits2, *_ = ref_greedy(gpt, mel, text2, max_gen=24)
+    save("micro_decode_b1_alt", text=text2, codes=codes2, logits0=logits2[:, 0])
+
+    # the padding/batch invariance of tests/padding_test.py:52-67 (five bos/eos padded variants as one batch)
+    F_ = torch.nn.functional
+    pads = [F_.pad(text, (8, 0), value=0), F_.pad(text, (0, 8), value=1),
+            F_.pad(F_.pad(text, (4, 0), value=0), (0, 4), value=1),
+            F_.pad(F_.pad(text, (6, 0), value=0), (0, 2), value=1),
+            F_.pad(F_.pad(text, (0, 4), value=0), (0, 4), value=1)]
+    btxt = torch.cat(pads, 0)
+    bcodes, blogits, _, bemb, bmask = ref_greedy(gpt, mel, btxt, max_gen=24, n_trace=4)
+    save("micro_decode_b5", text=btxt, codes=bcodes, logits=blogits, prefix_emb=bemb, prefix_mask=bmask)
+
+    # ragged real batch (different sentences, right-padded with stop like infer_fast's pad_tokens_cat)
+    t_a = torch.from_numpy(synth.text_ids(9, 21, g.number_text_tokens)).view(1, -1).int()
+    t_b = torch.from_numpy(synth.text_ids(14, 22, g.number_text_tokens)).view(1, -1).int()
+    rag = torch.nn.utils.rnn.pad_sequence([t_a[0], t_b[0]], batch_first=True, padding_value=1)
+    rcodes, rlogits, *_ = ref_greedy(gpt, mel, rag, max_gen=20, n_trace=4)
+    save("micro_decode_ragged", text=rag, codes=rcodes, logits=rlogits)
+
+    T = codes.shape[1]
+    lat_codes = codes.clone()
+    lat_codes[lat_codes == g.stop_mel_token] = 5  # latent pass sees cleaned codes (no stop inside)
+    latent = gpt(mel, text, torch.tensor([L]), lat_codes, torch.tensor([T * 1024]), cond_mel_lengths=lens,
+                 return_latent=True, clip_inputs=False)
+    save("micro_latent", text=text, codes=lat_codes, latent=latent)
+
+    print("[micro] ECAPA / BigVGAN")
+    bv = build_ref_bigvgan(cfg, seed)
+    spk = bv.speaker_encoder(mel.transpose(1, 2), None)
+    save("micro_ecapa", mel=mel, spk=spk)
+    lat_in = rnd("bigvgan.latent", (1, 7, cfg.bigvgan.gpt_dim), std=1.0)
+    wav, _ = bv(lat_in, mel.transpose(1, 2))
+    # stage taps through the reference's own submodules
+    x = bv.conv_pre(lat_in.transpose(1, 2)) + bv.cond_layer(spk.transpose(1, 2))
+    x_up0 = bv.ups[0][0](x) + bv.conds[0](spk.transpose(1, 2))
+    amp0 = bv.resblocks[0](x_up0)
+    save("micro_bigvgan", latent=lat_in, mel=mel, wav=wav, pre=x, up0=x_up0, amp0=amp0)
+    lat2 = rnd("bigvgan.latent2", (2, 5, cfg.bigvgan.gpt_dim), std=1.0)
+    mel2 = torch.cat([mel, torch.from_numpy(synth.prompt_mel(61, seed=8))], 0)
+    wav2, _ = bv(lat2, mel2.transpose(1, 2))
+    save("micro_bigvgan_b2", latent=lat2, mel=mel2, wav=wav2)
+
+    print("[micro] DVAE decode")
+    dv = build_ref_dvae(cfg, seed)
+    dcodes = torch.from_numpy(prng.randint("dvae.codes", 5, 2 * 9, 0, cfg.vqvae.num_tokens)).view(2, 9)
+    out, _ = dv.decode(dcodes)
+    save("micro_dvae", codes=dcodes, mel=out)
+
+    print("[int] remove_long_silence known answers")
+    ref_import._stub("omegaconf", OmegaConf=object)
+    from indextts.infer import IndexTTS
+
+    class Dummy:
+        stop_mel_token = g.stop_mel_token
+
+    cases = []
+    S = g.stop_mel_token
+    rows = [
+        [3, 4, 5, S, S, S],
+        [3] + [52] * 40 + [7, 8, S],
+        [52] * 12 + [9] + [52] * 25 + [4],
+        [1, 2, 3, 4, 5, 6],
+        [S, 1, 2],
+    ]
+    for i, r in enumerate(rows):
+        c = torch.tensor([r], dtype=torch.long)
+        oc, ol = IndexTTS.remove_long_silence(Dummy(), c.clone(), silent_token=52, max_consecutive=30)
+        cases.append((c, oc, ol))
+    # batched ragged case
+    c = torch.tensor([[3] + [52] * 40 + [7, 8, S, S], [5, 6, 7, S] + [S] * 41], dtype=torch.long)
+    oc, ol = IndexTTS.remove_long_silence(Dummy(), c.clone(), silent_token=52, max_consecutive=30)
+    cases.append((c, oc, ol))
+    save("silence_cases", **{f"in{i}": a for i, (a, _, _) in enumerate(cases)},
+         **{f"out{i}": b for i, (_, b, _) in enumerate(cases)}, **{f"len{i}": c_ for i, (_, _, c_) in enumerate(cases)},
+         n=len(cases), stop=S)
+
+
+@torch.no_grad()
+def full_fixtures():
+    """IndexTTS-1.5-sized: greedy ids + top-8 logits per step + margins (ints / small floats only)."""
+    cfg = icfg.indextts_1_5()
+    g = cfg.gpt
+    print("[full] building reference UnifiedVoice (583 M params) ...")
+    t0 = time.time()
+    gpt = build_ref_gpt(cfg, 1234)
+    print(f"  built in {time.time() - t0:.1f}s")
+    mel = torch.from_numpy(synth.prompt_mel(511, seed=7))
+    L = 52
+    text = torch.from_numpy(synth.text_ids(L, 11, g.number_text_tokens)).view(1, L).int()
+    t0 = time.time()
+    codes, logits, conds, emb, _ = ref_greedy(gpt, mel, text, max_gen=48)
+    print(f"  48-step greedy in {time.time() - t0:.1f}s")
+    top = torch.topk(logits[0], 8, dim=-1)
+    lat_codes = codes.clone()
+    lat_codes[lat_codes == g.stop_mel_token] = 5
+    latent = gpt(mel, text, torch.tensor([L]), lat_codes, torch.tensor([codes.shape[1] * 1024]),
+                 cond_mel_lengths=torch.tensor([511]), return_latent=True, clip_inputs=False)
+    save("full_decode_b1", text=text, codes=codes, top_idx=top.indices, top_val=top.values,
+         cond_sample=conds[0, :, :16], cond_rms=conds.pow(2).mean().sqrt(),
+         latent_sample=latent[0, :, :16], latent_rms=latent.pow(2).mean().sqrt(), lat_codes=lat_codes)
+    del gpt
+    print("[full] BigVGAN generator (134 M params) ...")
+    bv = build_ref_bigvgan(cfg, 1234)
+    lat_in = rnd("bigvgan.latent.full", (1, 12, cfg.bigvgan.gpt_dim), std=1.0)
+    t0 = time.time()
+    wav, _ = bv(lat_in, mel.transpose(1, 2))
+    spk = bv.speaker_encoder(mel.transpose(1, 2), None)
+    print(f"  vocoder in {time.time() - t0:.1f}s")
+    save("full_bigvgan", latent=lat_in, wav=wav, spk=spk)
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--full", action="store_true")
+    ap.add_argument("--skip-micro", action="store_true")
+    a = ap.parse_args()
+    ref_import.install()
+    torch.manual_seed(0)
+    if not a.skip_micro:
+        micro_fixtures()
+    if a.full:
+        full_fixtures()
