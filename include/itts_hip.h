@@ -1,0 +1,127 @@
+/* libitts_hip - C ABI of the MI355X-native IndexTTS hot path.
+ *
+ * Conventions: plain pointers and sizes, no torch types; every pointer is a DEVICE pointer
+ * unless the parameter name ends in `_host`; the caller allocates outputs; calls are asynchronous on the
+ * given HIP stream unless stated; the return value is 0 or a negative error code and
+ * `itts_last_error()` returns the message (thread-local).  One engine per host thread (the reference's
+ * web UI shares one engine between threads without a lock, webui.py:441-452: callers must serialise).
+ *
+ * dtype codes: 0 = f32, 1 = bf16.  Activations are channels-last ([B, T, C]) everywhere.
+ */
+#ifndef ITTS_HIP_H
+#define ITTS_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* itts_stream; /* hipStream_t */
+typedef struct itts_engine itts_engine;
+
+#define ITTS_F32 0
+#define ITTS_BF16 1
+
+const char* itts_last_error(void);
+int itts_abi_version(void);
+
+/* ---- operator level -------------------------------------------------------------------------------- */
+
+/* Fused anti-aliased SnakeBeta.  Replaces the reference's only native entry point
+ *   anti_alias_activation_cuda.forward(input, up_filter, down_filter, alpha, beta) -> Tensor
+ *   (indextts/BigVGAN/alias_free_activation/cuda/anti_alias_activation.cpp:19-23, fwd_cuda .cu:214-256)
+ * Same contract: alpha/beta are LOG-scale fp32 [C]; filters fp32 [12]; dst has the shape/dtype of src;
+ * src is not modified.  layout 0 = [B, C, T] (the reference's), 1 = [B, T, C] (engine-native). */
+int itts_snake_aa_fwd(void* dst, const void* src, const float* up12, const float* down12, const float* log_alpha,
+                      const float* log_beta, int B, int C, int T, int dtype, int layout, itts_stream stream);
+
+/* Generic linear / conv1d / transposed conv1d on channels-last activations (replaces nn.Linear, nn.Conv1d,
+ * nn.ConvTranspose1d calls of BigVGAN/models.py:149-161,184 and the conformer/GPT projections).
+ * W is [nphase][N][taps*Cin].  See csrc/itts_common.h GemmArgs for the epilogue definition. */
+typedef struct {
+  const void* A; const void* W; void* C;
+  int M, N, Cin, taps, lda, ldc, T, dil, pad_left, pad_mode, in_up, nphase;
+  int phase_shift[8];
+  const float* bias; int bias_bstride; int act;
+  const float* scale; const float* shift; int act2;
+  const void* R; int ldr; float alpha;
+  const void* ADD; int ldadd; float beta;
+  int dtype_a, dtype_w, dtype_c;
+  int force_simple; /* 1 = vector-ALU kernel even when the MFMA kernel supports the shape */
+} itts_gemm_args;
+int itts_gemm(const itts_gemm_args* args, itts_stream stream);
+
+int itts_layernorm(void* y, int dtype_y, const void* x, int dtype_x, const float* gamma, const float* beta, int rows,
+                   int D, float eps, itts_stream stream);
+
+/* attention over strided q/k/v (see csrc/itts_kernels.h AttnArgs) */
+int itts_attention(void* o, const void* q, const void* k, const void* v, int B, int H, int Sq, int Sk, int dqk, int dv,
+                   int ldq, int ldk, int ldv, int ldo, float scale, int causal, const int* kv_start, int dtype,
+                   itts_stream stream);
+
+int itts_transpose(void* y, const void* x, int B, int R, int C, int dtype, itts_stream stream);
+
+/* ---- engine level ----------------------------------------------------------------------------------- */
+
+typedef struct {
+  int dtype; /* weight + activation dtype of the engine (ITTS_F32 parity path / ITTS_BF16 throughput path) */
+  /* gpt (UnifiedVoice ctor, gpt/model.py:301-379) */
+  int model_dim, layers, heads, max_mel_tokens, max_text_tokens, number_text_tokens, number_mel_codes;
+  int start_mel_token, stop_mel_token, start_text_token, stop_text_token, cond_latents;
+  /* conformer + perceiver (condition_module) */
+  int cond_dim, cond_ff, cond_heads, cond_blocks, cond_idim, perc_inner, perc_layers;
+  /* bigvgan (BigVGAN.__init__, BigVGAN/models.py:132-197) */
+  int bv_gpt_dim, bv_init_ch, bv_num_up, bv_up_rates[8], bv_up_kernels[8];
+  int bv_num_res, bv_res_kernels[4], bv_res_dils[4][4], bv_num_dil, bv_spk_dim, bv_num_mels;
+  /* ECAPA-TDNN (ECAPA_TDNN.py:429-449 defaults) */
+  int ec_channels[5], ec_kernels[5], ec_dils[5], ec_att, ec_scale, ec_se;
+  /* DVAE decoder (vqvae/xtts_dvae.py:202-291) */
+  int dv_channels, dv_tokens, dv_hidden, dv_resblocks, dv_codebook, dv_layers, dv_kernel;
+  /* limits */
+  int max_batch;
+} itts_config;
+
+int itts_engine_create(const itts_config* cfg, itts_engine** out);
+void itts_engine_destroy(itts_engine* e);
+/* Register a packed tensor that lives in caller-owned device memory (the weight arena). */
+int itts_engine_bind_tensor(itts_engine* e, const char* name, const void* ptr, int dtype, int ndim, const int64_t* dims);
+/* Validate that every tensor the configured model needs is bound with the right shape/dtype. */
+int itts_engine_finalize(itts_engine* e);
+
+/* G2/C1/P1  UnifiedVoice.get_conditioning (gpt/model.py:490-502): mel [1, F, idim] -> cond fp32 [latents, D] */
+int itts_conditioning(itts_engine* e, const void* mel_bfc, int F, float* cond_out, itts_stream stream);
+/* V6  ECAPA_TDNN.forward (BigVGAN/ECAPA_TDNN.py:545-581): mel [B, F, num_mels] -> spk fp32 [B, spk_dim] */
+int itts_ecapa(itts_engine* e, const void* mel_bfc, int B, int F, float* spk_out, itts_stream stream);
+
+/* G1/G3/G4 step 0: prepare_gpt_inputs (model.py:591-654) + prefill + first greedy token.
+ * cond fp32 [latents, D]; text ids host int32 [B, L] (may hold start/stop padding ids, stripped per row).
+ * Synchronises the stream once (uploads the row descriptors). */
+int itts_gpt_prefill(itts_engine* e, const float* cond, const int32_t* text_ids_host, int B, int L, int max_gen,
+                     float repetition_penalty, int suppress_stop, itts_stream stream);
+/* G4/G5/G6: run up to nsteps further greedy steps (hipGraph replay of one captured step). */
+int itts_gpt_decode(itts_engine* e, int nsteps, itts_stream stream);
+/* Host-visible progress (synchronises): tokens generated per row so far, rows still unfinished. */
+int itts_gpt_status(itts_engine* e, int* steps_done_host, int* n_unfinished_host, itts_stream stream);
+/* Copy generated codes (int32 [B, max_gen], pad = stop token) and optionally the last logits fp32 [B, V]. */
+int itts_gpt_fetch(itts_engine* e, int32_t* codes_host, float* logits_host, itts_stream stream);
+
+/* G8  UnifiedVoice.forward(return_latent=True) for one sentence (model.py:521-589):
+ * text ids host [L], codes host [T] -> latent [T, D] in the engine dtype. */
+int itts_gpt_latent(itts_engine* e, const float* cond, const int32_t* text_ids_host, int L, const int32_t* codes_host,
+                    int T, void* latent_out, itts_stream stream);
+
+/* V1-V5  BigVGAN.forward given the speaker embedding (BigVGAN/models.py:201-250):
+ * latent [B, T, gpt_dim] (engine dtype), spk fp32 [B, spk_dim] -> wav fp32 [B, T * prod(up_rates)] */
+int itts_bigvgan(itts_engine* e, const void* latent, const float* spk, int B, int T, float* wav_out, itts_stream stream);
+
+/* Q1  DiscreteVAE.decode (vqvae/xtts_dvae.py:332-351): codes host int32 [B, T] -> mel [B, 4T, channels] engine dtype */
+int itts_dvae_decode(itts_engine* e, const int32_t* codes_host, int B, int T, void* mel_out, itts_stream stream);
+
+/* Debug/testing: copy a named intermediate of the LAST call into host memory (fp32), returns element count. */
+int64_t itts_debug_fetch(itts_engine* e, const char* name, float* out_host, int64_t max_elems);
+int itts_debug_enable(itts_engine* e, int on);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

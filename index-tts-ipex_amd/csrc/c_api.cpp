@@ -1,0 +1,187 @@
+// extern "C" boundary of libitts_hip (declared in include/itts_hip.h).
+#include <cstring>
+#include <new>
+
+#include "engine.h"
+
+using namespace itts;
+
+struct itts_engine {
+  Engine e;
+};
+
+namespace itts {
+int gemm(const GemmArgs& g, int ta, int tw, int tc, hipStream_t s) {
+  if (gemm_mfma_supported(g, ta, tw, tc)) return gemm_mfma(g, ta, tw, tc, s);
+  return gemm_simple(g, ta, tw, tc, s);
+}
+}  // namespace itts
+
+extern "C" {
+
+const char* itts_last_error(void) { return last_error(); }
+int itts_abi_version(void) { return 1; }
+
+int itts_snake_aa_fwd(void* dst, const void* src, const float* up12, const float* down12, const float* log_alpha,
+                      const float* log_beta, int B, int C, int T, int dtype, int layout, itts_stream stream) {
+  (void)hipGetLastError();  // drop stale errors left by other HIP users (torch)
+  if (layout == 1) return snake_aa(dst, src, log_alpha, log_beta, up12, down12, B, T, C, dtype, (hipStream_t)stream);
+  if (layout == 0) return snake_aa_bct(dst, src, log_alpha, log_beta, up12, down12, B, C, T, dtype, (hipStream_t)stream);
+  set_error("itts_snake_aa_fwd: layout must be 0 ([B,C,T]) or 1 ([B,T,C])");
+  return E_INVALID;
+}
+
+int itts_gemm(const itts_gemm_args* a, itts_stream stream) {
+  (void)hipGetLastError();  // drop stale errors left by other HIP users (torch)
+  if (!a) {
+    set_error("itts_gemm: null args");
+    return E_INVALID;
+  }
+  GemmArgs g;
+  g.A = a->A; g.W = a->W; g.C = a->C;
+  g.M = a->M; g.N = a->N; g.Cin = a->Cin; g.taps = a->taps; g.lda = a->lda; g.ldc = a->ldc; g.T = a->T;
+  g.dil = a->dil; g.pad_left = a->pad_left; g.pad_mode = a->pad_mode; g.in_up = a->in_up < 1 ? 1 : a->in_up;
+  g.nphase = a->nphase < 1 ? 1 : a->nphase;
+  for (int i = 0; i < 8; ++i) g.phase_shift[i] = a->phase_shift[i];
+  g.bias = a->bias; g.bias_bstride = a->bias_bstride; g.act = a->act; g.scale = a->scale; g.shift = a->shift;
+  g.act2 = a->act2; g.R = a->R; g.ldr = a->ldr; g.alpha = a->alpha; g.ADD = a->ADD; g.ldadd = a->ldadd; g.beta = a->beta;
+  if (a->force_simple) return gemm_simple(g, a->dtype_a, a->dtype_w, a->dtype_c, (hipStream_t)stream);
+  return gemm(g, a->dtype_a, a->dtype_w, a->dtype_c, (hipStream_t)stream);
+}
+
+int itts_layernorm(void* y, int dtype_y, const void* x, int dtype_x, const float* gamma, const float* beta, int rows,
+                   int D, float eps, itts_stream stream) {
+  (void)hipGetLastError();  // drop stale errors left by other HIP users (torch)
+  return layernorm(y, dtype_y, x, dtype_x, gamma, beta, rows, D, D, D, eps, ACT_NONE, (hipStream_t)stream);
+}
+
+int itts_attention(void* o, const void* q, const void* k, const void* v, int B, int H, int Sq, int Sk, int dqk, int dv,
+                   int ldq, int ldk, int ldv, int ldo, float scale, int causal, const int* kv_start, int dtype,
+                   itts_stream stream) {
+  (void)hipGetLastError();  // drop stale errors left by other HIP users (torch)
+  AttnArgs a;
+  a.q = q; a.k = k; a.v = v; a.o = o; a.B = B; a.H = H; a.Sq = Sq; a.Sk = Sk; a.dqk = dqk; a.dv = dv;
+  a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.scale = scale; a.causal = causal; a.kv_start = kv_start;
+  return attention_simple(a, dtype, (hipStream_t)stream);
+}
+
+int itts_transpose(void* y, const void* x, int B, int R, int C, int dtype, itts_stream stream) {
+  (void)hipGetLastError();  // drop stale errors left by other HIP users (torch)
+  return transpose_brc(y, x, B, R, C, dtype, (hipStream_t)stream);
+}
+
+int itts_engine_create(const itts_config* cfg, itts_engine** out) {
+  if (!cfg || !out) {
+    set_error("itts_engine_create: null argument");
+    return E_INVALID;
+  }
+  if (cfg->dtype != F32 && cfg->dtype != BF16) {
+    set_error("itts_engine_create: dtype must be ITTS_F32 or ITTS_BF16");
+    return E_INVALID;
+  }
+  if (cfg->model_dim <= 0 || cfg->heads <= 0 || cfg->model_dim % cfg->heads != 0 || cfg->model_dim / cfg->heads != 64) {
+    set_error("itts_engine_create: model_dim/heads must give head_dim 64");
+    return E_INVALID;
+  }
+  if (cfg->bv_num_up > 8 || cfg->bv_num_res > 4 || cfg->bv_num_dil > 4) {
+    set_error("itts_engine_create: vocoder topology out of range");
+    return E_INVALID;
+  }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+    (void)hipGetLastError();
+    set_error("itts_engine_create: no HIP device (this library has no CPU fallback)");
+    return E_HIP;
+  }
+  itts_engine* e = new (std::nothrow) itts_engine();
+  if (!e) return E_NOMEM;
+  e->e.cfg = *cfg;
+  e->e.adt = cfg->dtype;
+  e->e.es = dtype_size(cfg->dtype);
+  *out = e;
+  return OK;
+}
+
+void itts_engine_destroy(itts_engine* e) { delete e; }
+
+int itts_engine_bind_tensor(itts_engine* e, const char* name, const void* ptr, int dtype, int ndim, const int64_t* dims) {
+  if (!e || !name || !ptr || ndim < 1 || ndim > 4 || !dims) {
+    set_error("itts_engine_bind_tensor: bad argument");
+    return E_INVALID;
+  }
+  Tensor t;
+  t.p = ptr;
+  t.dt = dtype;
+  t.nd = ndim;
+  for (int i = 0; i < ndim; ++i) t.d[i] = dims[i];
+  e->e.tensors[name] = t;
+  e->e.finalized = false;
+  return OK;
+}
+
+int itts_engine_finalize(itts_engine* e) { return e ? e->e.finalize() : E_INVALID; }
+
+#define ENG(e)                           \
+  (void)hipGetLastError();               \
+  if (!(e)) {                            \
+    set_error("null engine");            \
+    return E_INVALID;                    \
+  }
+
+int itts_conditioning(itts_engine* e, const void* mel, int F, float* cond_out, itts_stream s) {
+  ENG(e);
+  return e->e.conditioning(mel, F, cond_out, (hipStream_t)s);
+}
+int itts_ecapa(itts_engine* e, const void* mel, int B, int F, float* spk_out, itts_stream s) {
+  ENG(e);
+  return e->e.ecapa(mel, B, F, spk_out, (hipStream_t)s);
+}
+int itts_gpt_prefill(itts_engine* e, const float* cond, const int32_t* text_ids_host, int B, int L, int max_gen,
+                     float repetition_penalty, int suppress_stop, itts_stream s) {
+  ENG(e);
+  return e->e.gpt_prefill(cond, text_ids_host, B, L, max_gen, repetition_penalty, suppress_stop, (hipStream_t)s);
+}
+int itts_gpt_decode(itts_engine* e, int nsteps, itts_stream s) {
+  ENG(e);
+  return e->e.gpt_decode(nsteps, (hipStream_t)s);
+}
+int itts_gpt_status(itts_engine* e, int* steps, int* n_unf, itts_stream s) {
+  ENG(e);
+  return e->e.gpt_status(steps, n_unf, (hipStream_t)s);
+}
+int itts_gpt_fetch(itts_engine* e, int32_t* codes, float* logits, itts_stream s) {
+  ENG(e);
+  return e->e.gpt_fetch(codes, logits, (hipStream_t)s);
+}
+int itts_gpt_latent(itts_engine* e, const float* cond, const int32_t* text_ids_host, int L, const int32_t* codes_host,
+                    int T, void* latent_out, itts_stream s) {
+  ENG(e);
+  return e->e.gpt_latent(cond, text_ids_host, L, codes_host, T, latent_out, (hipStream_t)s);
+}
+int itts_bigvgan(itts_engine* e, const void* latent, const float* spk, int B, int T, float* wav_out, itts_stream s) {
+  ENG(e);
+  return e->e.bigvgan(latent, spk, B, T, wav_out, (hipStream_t)s);
+}
+int itts_dvae_decode(itts_engine* e, const int32_t* codes_host, int B, int T, void* mel_out, itts_stream s) {
+  ENG(e);
+  return e->e.dvae_decode(codes_host, B, T, mel_out, (hipStream_t)s);
+}
+
+int itts_debug_enable(itts_engine* e, int on) {
+  ENG(e);
+  e->e.debug = on & 1;
+  e->e.force_simple = (on & 2) != 0;
+  e->e.use_graph = (on & 4) == 0;
+  return OK;
+}
+
+int64_t itts_debug_fetch(itts_engine* e, const char* name, float* out_host, int64_t max_elems) {
+  if (!e || !name) return -1;
+  auto it = e->e.taps.find(name);
+  if (it == e->e.taps.end()) return -1;
+  const int64_t n = (int64_t)it->second.size();
+  if (out_host) std::memcpy(out_host, it->second.data(), (size_t)std::min(n, max_elems) * 4);
+  return n;
+}
+
+}  // extern "C"

@@ -1,0 +1,195 @@
+// The inference engine behind the C ABI: owns nothing but scratch/state memory; weights stay in the
+// caller's arena and are bound by name (itts_engine_bind_tensor).
+#pragma once
+#include <map>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/itts_hip.h"
+#include "itts_decode.h"
+#include "itts_kernels.h"
+
+namespace itts {
+
+struct Tensor {
+  const void* p = nullptr;
+  int dt = 0, nd = 0;
+  int64_t d[4] = {0, 0, 0, 0};
+  int64_t numel() const {
+    int64_t n = 1;
+    for (int i = 0; i < nd; ++i) n *= d[i];
+    return n;
+  }
+};
+
+// a linear / conv layer: W [nphase][N][taps*Cin] in `dt`, bias fp32 [N] (optional), BN-eval affine (optional)
+struct Lin {
+  const void* w = nullptr;
+  const float* b = nullptr;
+  const float* bn_scale = nullptr;
+  const float* bn_shift = nullptr;
+  int N = 0, Cin = 0, taps = 1, nphase = 1, dt = 0;
+};
+struct Norm {
+  const float* g = nullptr;
+  const float* b = nullptr;
+};
+
+struct ConformerLayerW {
+  Norm norm_mha, norm_conv, norm_ff, norm_final, conv_norm;
+  Lin qkv, pos, out, pw1, pw2, w1, w2;
+  const float *bu = nullptr, *bv = nullptr, *dw_w = nullptr, *dw_b = nullptr;
+};
+struct CondW {
+  bool ok = false;
+  const float *conv_w = nullptr, *conv_b = nullptr;
+  Lin embed_out;
+  const void* pe = nullptr;  // [max_len, od] activation dtype
+  int pe_len = 0;
+  std::vector<ConformerLayerW> layers;
+  Norm after_norm;
+  // perceiver
+  const float* latents = nullptr;
+  Lin proj;
+  struct PL {
+    Lin to_q, to_kv, to_out, ff1, ff2;
+  };
+  std::vector<PL> pl;
+  const float* gamma = nullptr;
+  int ffi = 0, ffi_pad = 0, inner = 0;
+};
+struct GptLayerW {
+  Norm ln1, ln2;
+  Lin attn, proj, fc, proj2;
+};
+struct GptW {
+  bool ok = false;
+  std::vector<GptLayerW> layers;
+  Norm ln_f, final_norm;
+  Lin head;
+  const void *text_emb = nullptr, *mel_emb = nullptr, *mel_pos = nullptr, *text_pos = nullptr;
+};
+struct AmpW {
+  Lin c1[4], c2[4];
+  const float *a1[4], *b1[4], *a2[4], *b2[4];
+};
+struct BigvganW {
+  bool ok = false;
+  Lin conv_pre, cond_layer, conv_post;
+  std::vector<Lin> ups, conds;
+  std::vector<AmpW> res;
+  const float *post_alpha = nullptr, *post_beta = nullptr, *filter = nullptr;
+};
+struct EcapaW {
+  bool ok = false;
+  Lin b0;
+  struct Blk {
+    Lin tdnn1, tdnn2, se1, se2;
+    std::vector<Lin> res;
+  };
+  std::vector<Blk> blks;
+  Lin mfa, asp_x, asp_ms, asp_conv, fc;
+  const float *aspbn_scale = nullptr, *aspbn_shift = nullptr;
+};
+struct DvaeW {
+  bool ok = false;
+  const void* codebook = nullptr;
+  Lin in_conv, out_conv;
+  struct RB {
+    Lin c0, c2, c4;
+  };
+  std::vector<RB> rbs;
+  std::vector<Lin> ups;
+};
+
+struct DecodeState {
+  int B = 0, Smax = 0, prefix = 0, max_gen = 0;
+  size_t cache_bytes = 0;
+  void *kc = nullptr, *vc = nullptr;  // [layers][B][H][Smax][dh]
+  float *h = nullptr, *qkv = nullptr, *ctx = nullptr, *act = nullptr, *hn = nullptr, *logits = nullptr;
+  int *step = nullptr, *n_unf = nullptr, *n_unf_next = nullptr, *prefix_dev = nullptr;
+  int *kv_start = nullptr, *cur_tok = nullptr, *ids = nullptr, *unfinished = nullptr;
+  uint8_t* seen = nullptr;
+  int cap_B = 0, cap_gen = 0;
+  float penalty = 1.f;
+  int suppress_stop = 0;
+  hipGraphExec_t graph = nullptr;
+  int graph_B = 0, graph_Smax = 0, graph_suppress = 0;
+  float graph_penalty = 0.f;
+  bool active = false;
+};
+
+struct Engine {
+  itts_config cfg;
+  int adt = 0;  // activation / weight dtype
+  size_t es = 4;
+  std::unordered_map<std::string, Tensor> tensors;
+  bool finalized = false;
+  CondW cond;
+  GptW gpt;
+  BigvganW bv;
+  EcapaW ec;
+  DvaeW dv;
+  DecodeState ds;
+  bool use_graph = true;
+  bool force_simple = false;
+
+  // scratch workspace (bump allocator, two-pass: dry run sizes it, real run uses it)
+  char* ws = nullptr;
+  size_t ws_cap = 0, ws_off = 0;
+  bool dry = false;
+  void ws_reset() { ws_off = 0; }
+  void* alloc(size_t bytes) {
+    const size_t a = (ws_off + 255) & ~size_t(255);
+    ws_off = a + bytes;
+    return dry ? (void*)(uintptr_t)(0x1000 + a) : (void*)(ws + a);
+  }
+  int ws_reserve(size_t bytes, hipStream_t s);
+
+  // debug taps
+  bool debug = false;
+  std::map<std::string, std::vector<float>> taps;
+  int tap(const char* name, const void* p, int dt, int64_t n, hipStream_t s);
+
+  ~Engine();
+
+  // op wrappers (skip launches in dry mode)
+  int lin(void* C, int tc, const void* A, int ta, int lda, const Lin& w, int M, int ldc, hipStream_t s, int act = ACT_NONE,
+          const void* R = nullptr, int ldr = 0, float alpha = 1.f);
+  int conv(GemmArgs& g, int ta, int tw, int tc, hipStream_t s);
+  int ln(void* y, int ty, const void* x, int tx, const Norm& n, int rows, int D, hipStream_t s, int act = ACT_NONE,
+         float eps = 1e-5f);
+
+  // model entry points
+  int finalize();
+  int conditioning(const void* mel, int F, float* cond_out, hipStream_t s);
+  int ecapa(const void* mel, int B, int F, float* spk_out, hipStream_t s);
+  int gpt_prefill(const float* cond, const int32_t* text_ids, int B, int L, int max_gen, float penalty, int suppress,
+                  hipStream_t s);
+  int gpt_decode(int nsteps, hipStream_t s);
+  int gpt_status(int* steps, int* n_unf, hipStream_t s);
+  int gpt_fetch(int32_t* codes, float* logits, hipStream_t s);
+  int gpt_latent(const float* cond, const int32_t* text_ids, int L, const int32_t* codes, int T, void* latent_out,
+                 hipStream_t s);
+  int bigvgan(const void* latent, const float* spk, int B, int T, float* wav, hipStream_t s);
+  int dvae_decode(const int32_t* codes, int B, int T, void* mel_out, hipStream_t s);
+
+  // internals
+  int gpt_layers_full(float* h, int B, int S, const int* kv_start_dev, bool write_cache, hipStream_t s);
+  int decode_step_launch(hipStream_t s);
+  int ensure_decode_state(int B, int Smax, int max_gen, hipStream_t s);
+  template <typename F>
+  int two_pass(F&& body, hipStream_t s) {
+    dry = true;
+    ws_reset();
+    int st = body();
+    dry = false;
+    if (st != OK) return st;
+    ITTS_TRY(ws_reserve(ws_off + 4096, s));
+    ws_reset();
+    return body();
+  }
+};
+
+}  // namespace itts

@@ -1,0 +1,111 @@
+// Common definitions for libitts_hip (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+
+namespace itts {
+
+typedef __bf16 bf16_t;
+
+enum DType : int { F32 = 0, BF16 = 1, I32 = 2, I64 = 3 };
+enum Act : int { ACT_NONE = 0, ACT_RELU = 1, ACT_SILU = 2, ACT_GELU_NEW = 3, ACT_GELU_ERF = 4, ACT_TANH = 5, ACT_SIGMOID = 6 };
+enum PadMode : int { PAD_ZERO = 0, PAD_REFLECT = 1 };
+
+inline size_t dtype_size(int dt) { return dt == F32 ? 4 : dt == BF16 ? 2 : dt == I32 ? 4 : 8; }
+
+// status codes of the C ABI (0 ok, negative = error; message via itts_last_error())
+enum Status : int { OK = 0, E_INVALID = -1, E_HIP = -2, E_NOMEM = -3, E_STATE = -4, E_MISSING = -5 };
+
+void set_error(const std::string& msg);
+const char* last_error();
+
+#define ITTS_HIP_CHECK(expr)                                                                         \
+  do {                                                                                               \
+    hipError_t _e = (expr);                                                                          \
+    if (_e != hipSuccess) {                                                                          \
+      ::itts::set_error(std::string(#expr) + " failed: " + hipGetErrorString(_e) + " at " + __FILE__ + ":" + \
+                        std::to_string(__LINE__));                                                   \
+      return ::itts::E_HIP;                                                                          \
+    }                                                                                                \
+  } while (0)
+
+#define ITTS_REQUIRE(cond, msg)                                                         \
+  do {                                                                                  \
+    if (!(cond)) {                                                                      \
+      ::itts::set_error(std::string("invalid argument: ") + msg + " (" #cond ") at " + __FILE__ + ":" + \
+                        std::to_string(__LINE__));                                      \
+      return ::itts::E_INVALID;                                                         \
+    }                                                                                   \
+  } while (0)
+
+#define ITTS_TRY(expr)              \
+  do {                              \
+    int _s = (expr);                \
+    if (_s != ::itts::OK) return _s; \
+  } while (0)
+
+// ---- device helpers ----
+__device__ __forceinline__ float ldf(const float* p) { return *p; }
+__device__ __forceinline__ float ldf(const bf16_t* p) { return (float)(*p); }
+__device__ __forceinline__ void stf(float* p, float v) { *p = v; }
+__device__ __forceinline__ void stf(bf16_t* p, float v) { *p = (bf16_t)v; }
+
+__device__ __forceinline__ float act_apply(int act, float x) {
+  switch (act) {
+    case ACT_RELU: return x > 0.f ? x : 0.f;
+    case ACT_SILU: return x / (1.f + __expf(-x));
+    case ACT_GELU_NEW: {
+      const float k = 0.7978845608028654f;  // sqrt(2/pi)
+      return 0.5f * x * (1.f + tanhf(k * (x + 0.044715f * x * x * x)));
+    }
+    case ACT_GELU_ERF: return 0.5f * x * (1.f + erff(x * 0.7071067811865476f));
+    case ACT_TANH: return tanhf(x);
+    case ACT_SIGMOID: return 1.f / (1.f + __expf(-x));
+    default: return x;
+  }
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// Arguments of the generic "shift-GEMM" (linear / conv1d / transposed conv1d / upsampled conv) on
+// channels-last activations:   C[m, n] = epilogue( sum_{tap, c} A[row(m, tap), c] * W[n, tap*Cin + c] )
+struct GemmArgs {
+  const void* A = nullptr;  // [M rows][lda], element type TA
+  const void* W = nullptr;  // [nphase][N][taps*Cin], element type TW
+  void* C = nullptr;        // [M rows][ldc] (row m, col phase*N + n), element type TC
+  int M = 0, N = 0, Cin = 0, taps = 1;
+  int lda = 0, ldc = 0;
+  int T = 0;         // rows per batch item in OUTPUT-row space (M = B*T); shifts never cross an item
+  int dil = 1;       // row offset of tap j = phase_shift + j*dil - pad_left
+  int pad_left = 0;
+  int pad_mode = PAD_ZERO;
+  int in_up = 1;     // input is nearest-upsampled by in_up: source row = (t + off) / in_up
+  int nphase = 1;    // transposed conv: output columns [phase*N, (phase+1)*N), W slab per phase
+  int phase_shift[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  // epilogue: v = acc + bias[b*bias_bstride + col]; v = act(v); v = v*scale[col] + shift[col]; v = act2(v);
+  //           v += R[m, col]; v *= alpha; v += beta * ADD[m, col]
+  const float* bias = nullptr;
+  int bias_bstride = 0;
+  int act = ACT_NONE;
+  const float* scale = nullptr;
+  const float* shift = nullptr;
+  int act2 = ACT_NONE;
+  const void* R = nullptr;  // residual, element type TC
+  int ldr = 0;
+  float alpha = 1.f;
+  const void* ADD = nullptr;  // element type TC
+  int ldadd = 0;
+  float beta = 0.f;
+};
+
+}  // namespace itts

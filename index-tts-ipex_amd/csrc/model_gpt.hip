@@ -1,0 +1,474 @@
+// GPT-2 acoustic LM: prefix assembly + prefill (step 0), per-token decode (hipGraph-captured), latent pass.
+// Reference: UnifiedVoice.inference_speech / prepare_gpt_inputs / forward(return_latent) and
+// GPT2InferenceModel.forward (indextts/gpt/model.py:115-192,521-708); HF transformers 4.36.2 GPT2Model /
+// greedy_search semantics (not vendored; restated in oracle/gpt.py and pinned by tests/golden).
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+#include "engine.h"
+
+namespace itts {
+
+namespace {
+
+// row descriptor for the embedding assembly: kind 0 zero, 1 cond row, 2 text (emb+pos), 3 mel (emb+pos)
+struct RowDesc {
+  int kind, a, b, pad;
+};
+
+template <typename TW>
+__global__ void gpt_embed_rows_kernel(float* __restrict__ h, const RowDesc* __restrict__ rd, const float* __restrict__ cond,
+                                      const TW* __restrict__ text_emb, const TW* __restrict__ text_pos,
+                                      const TW* __restrict__ mel_emb, const TW* __restrict__ mel_pos, int D) {
+  const int r = blockIdx.x;
+  const RowDesc d = rd[r];
+  for (int i = threadIdx.x; i < D; i += blockDim.x) {
+    float v = 0.f;
+    if (d.kind == 1) v = cond[(size_t)d.a * D + i];
+    else if (d.kind == 2) v = ldf(text_emb + (size_t)d.a * D + i) + ldf(text_pos + (size_t)d.b * D + i);
+    else if (d.kind == 3) v = ldf(mel_emb + (size_t)d.a * D + i) + ldf(mel_pos + (size_t)d.b * D + i);
+    h[(size_t)r * D + i] = v;
+  }
+}
+
+__global__ void init_decode_state_kernel(uint8_t* seen, int* unfinished, int* cur_tok, int* step, int* n_unf,
+                                         int* n_unf_next, int* prefix_dev, int B, int V, int fake_id, int start_tok,
+                                         int prefix) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < (long)B * V) {
+    const int v = (int)(i % V);
+    seen[i] = (v == fake_id || v == start_tok) ? 1 : 0;
+  }
+  if (i < B) {
+    unfinished[i] = 1;
+    cur_tok[i] = start_tok;
+  }
+  if (i == 0) {
+    step[0] = 0;
+    n_unf[0] = B;
+    n_unf_next[0] = 0;
+    prefix_dev[0] = prefix;
+  }
+}
+
+}  // namespace
+
+#define K(call)               \
+  do {                        \
+    if (!dry) ITTS_TRY(call); \
+  } while (0)
+
+// full-sequence pass of the 24 blocks over h fp32 [B*S, D] (in place); optional KV-cache fill
+int Engine::gpt_layers_full(float* h, int B, int S, const int* kv_start_dev, bool write_cache, hipStream_t s) {
+  const itts_config& c = cfg;
+  const int D = c.model_dim, H = c.heads, dh = D / H, M = B * S;
+  void* xn = alloc((size_t)M * D * es);
+  void* qkv = alloc((size_t)M * 3 * D * es);
+  void* ctx = alloc((size_t)M * D * es);
+  void* act = alloc((size_t)M * 4 * D * es);
+  for (int l = 0; l < c.layers; ++l) {
+    const GptLayerW& L = gpt.layers[l];
+    ITTS_TRY(ln(xn, adt, h, F32, L.ln1, M, D, s));
+    ITTS_TRY(lin(qkv, adt, xn, adt, D, L.attn, M, 3 * D, s));
+    if (write_cache) {
+      const size_t lo = (size_t)l * ds.B * H * ds.Smax * dh * es;
+      K(kv_scatter((char*)ds.kc + lo, (char*)ds.vc + lo, qkv, B, S, H, dh, ds.Smax, adt, adt, s));
+    }
+    AttnArgs a;
+    a.q = qkv;
+    a.k = (const char*)qkv + (size_t)D * es;
+    a.v = (const char*)qkv + (size_t)2 * D * es;
+    a.o = ctx;
+    a.B = B;
+    a.H = H;
+    a.Sq = a.Sk = S;
+    a.dqk = a.dv = dh;
+    a.ldq = a.ldk = a.ldv = 3 * D;
+    a.ldo = D;
+    a.scale = 1.f / std::sqrt((float)dh);
+    a.causal = 1;
+    a.kv_start = kv_start_dev;
+    K(attention_simple(a, adt, s));
+    ITTS_TRY(lin(h, F32, ctx, adt, D, L.proj, M, D, s, ACT_NONE, h, D));
+    ITTS_TRY(ln(xn, adt, h, F32, L.ln2, M, D, s));
+    ITTS_TRY(lin(act, adt, xn, adt, D, L.fc, M, 4 * D, s, ACT_GELU_NEW));
+    ITTS_TRY(lin(h, F32, act, adt, 4 * D, L.proj2, M, D, s, ACT_NONE, h, D));
+  }
+  return OK;
+}
+
+static int dev_alloc(void** p, size_t bytes) {
+  if (*p) (void)hipFree(*p);
+  *p = nullptr;
+  if (hipMalloc(p, bytes) != hipSuccess) {
+    (void)hipGetLastError();
+    set_error("device allocation of " + std::to_string(bytes) + " bytes failed");
+    return E_NOMEM;
+  }
+  return OK;
+}
+
+int Engine::ensure_decode_state(int B, int Smax, int max_gen, hipStream_t s) {
+  const itts_config& c = cfg;
+  const int D = c.model_dim, H = c.heads, dh = D / H, V = c.number_mel_codes;
+  DecodeState& d = ds;
+  const size_t need = (size_t)c.layers * B * H * Smax * dh * es;
+  const bool regrow = B > d.cap_B || max_gen > d.cap_gen;
+  if (need > d.cache_bytes || regrow || B != d.B || Smax != d.Smax) {
+    ITTS_HIP_CHECK(hipStreamSynchronize(s));
+    if (d.graph) {
+      (void)hipGraphExecDestroy(d.graph);
+      d.graph = nullptr;
+    }
+  }
+  if (need > d.cache_bytes) {
+    ITTS_TRY(dev_alloc(&d.kc, need));
+    ITTS_TRY(dev_alloc(&d.vc, need));
+    d.cache_bytes = need;
+  }
+  if (regrow) {
+    const int cb = std::max(B, d.cap_B), cg = std::max(max_gen, d.cap_gen);
+    ITTS_TRY(dev_alloc((void**)&d.h, (size_t)cb * D * 4));
+    ITTS_TRY(dev_alloc((void**)&d.qkv, (size_t)cb * 3 * D * 4));
+    ITTS_TRY(dev_alloc((void**)&d.ctx, (size_t)cb * D * 4));
+    ITTS_TRY(dev_alloc((void**)&d.act, (size_t)cb * 4 * D * 4));
+    ITTS_TRY(dev_alloc((void**)&d.hn, (size_t)cb * D * 4));
+    ITTS_TRY(dev_alloc((void**)&d.logits, (size_t)cb * V * 4));
+    ITTS_TRY(dev_alloc((void**)&d.kv_start, (size_t)cb * 4));
+    ITTS_TRY(dev_alloc((void**)&d.cur_tok, (size_t)cb * 4));
+    ITTS_TRY(dev_alloc((void**)&d.unfinished, (size_t)cb * 4));
+    ITTS_TRY(dev_alloc((void**)&d.ids, (size_t)cb * cg * 4));
+    ITTS_TRY(dev_alloc((void**)&d.seen, (size_t)cb * V));
+    if (!d.step) {
+      ITTS_TRY(dev_alloc((void**)&d.step, 64));
+      d.n_unf = d.step + 4;
+      d.n_unf_next = d.step + 8;
+      d.prefix_dev = d.step + 12;
+    }
+    d.cap_B = cb;
+    d.cap_gen = cg;
+  }
+  d.B = B;
+  d.Smax = Smax;
+  d.max_gen = max_gen;
+  return OK;
+}
+
+int Engine::gpt_prefill(const float* cond_dev, const int32_t* text_ids, int B, int L, int max_gen, float penalty,
+                        int suppress, hipStream_t s) {
+  if (!finalized || !gpt.ok) {
+    set_error("gpt_prefill: GPT weights not bound");
+    return E_STATE;
+  }
+  const itts_config& c = cfg;
+  ITTS_REQUIRE(cond_dev && text_ids && B > 0 && L > 0 && max_gen > 0, "gpt_prefill: bad arguments");
+  ITTS_REQUIRE(B <= c.max_batch, "gpt_prefill: batch larger than max_batch");
+  ITTS_REQUIRE(L + 2 <= c.max_text_tokens + 2, "gpt_prefill: text longer than max_text_tokens");
+  ITTS_REQUIRE(max_gen + 2 <= c.max_mel_tokens + 3, "gpt_prefill: max_gen exceeds the mel position table");
+  const int D = c.model_dim, nl = c.cond_latents, V = c.number_mel_codes;
+  const int sp = nl + L + 2;  // prefix length s (model.py:614)
+  const int S0 = sp + 1;      // + start_mel_token
+  const int Smax = (S0 + max_gen + 255) / 256 * 256;  // coarse, so one captured graph serves many L
+  ITTS_REQUIRE(Smax <= 2048, "gpt_prefill: sequence too long for the decode attention kernel");
+  ITTS_TRY(ensure_decode_state(B, Smax, max_gen, s));
+  ds.prefix = sp;
+  ds.penalty = penalty;
+  ds.suppress_stop = suppress;
+  // host: row descriptors (prepare_gpt_inputs, model.py:615-639)
+  std::vector<RowDesc> rd((size_t)B * S0);
+  std::vector<int> kvs(B);
+  for (int b = 0; b < B; ++b) {
+    std::vector<int> ids;
+    for (int i = 0; i < L; ++i) {
+      const int t = text_ids[(size_t)b * L + i];
+      if (t != c.start_text_token && t != c.stop_text_token) {
+        ITTS_REQUIRE(t >= 0 && t <= c.number_text_tokens, "gpt_prefill: text id out of range");
+        ids.push_back(t);
+      }
+    }
+    const int n = (int)ids.size();
+    const int pad = L - n;
+    kvs[b] = pad;
+    RowDesc* r = rd.data() + (size_t)b * S0;
+    int k = 0;
+    for (int i = 0; i < pad; ++i) r[k++] = {0, 0, 0, 0};
+    for (int i = 0; i < nl; ++i) r[k++] = {1, i, 0, 0};
+    r[k++] = {2, c.start_text_token, 0, 0};
+    for (int i = 0; i < n; ++i) r[k++] = {2, ids[i], i + 1, 0};
+    r[k++] = {2, c.stop_text_token, n + 1, 0};
+    r[k++] = {3, c.start_mel_token, 0, 0};
+  }
+  auto body = [&]() -> int {
+    RowDesc* rd_dev = (RowDesc*)alloc(rd.size() * sizeof(RowDesc));
+    float* h = (float*)alloc((size_t)B * S0 * D * 4);
+    if (!dry) {
+      ITTS_HIP_CHECK(hipMemcpyAsync(rd_dev, rd.data(), rd.size() * sizeof(RowDesc), hipMemcpyHostToDevice, s));
+      ITTS_HIP_CHECK(hipMemcpyAsync(ds.kv_start, kvs.data(), B * 4, hipMemcpyHostToDevice, s));
+      const long n = (long)B * V;
+      hipLaunchKernelGGL(init_decode_state_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, ds.seen,
+                         ds.unfinished, ds.cur_tok, ds.step, ds.n_unf, ds.n_unf_next, ds.prefix_dev, B, V, 1,
+                         c.start_mel_token, sp);
+      if (adt == F32)
+        hipLaunchKernelGGL(gpt_embed_rows_kernel<float>, dim3(B * S0), dim3(256), 0, s, h, rd_dev, cond_dev,
+                           (const float*)gpt.text_emb, (const float*)gpt.text_pos, (const float*)gpt.mel_emb,
+                           (const float*)gpt.mel_pos, D);
+      else
+        hipLaunchKernelGGL(gpt_embed_rows_kernel<bf16_t>, dim3(B * S0), dim3(256), 0, s, h, rd_dev, cond_dev,
+                           (const bf16_t*)gpt.text_emb, (const bf16_t*)gpt.text_pos, (const bf16_t*)gpt.mel_emb,
+                           (const bf16_t*)gpt.mel_pos, D);
+      ITTS_HIP_CHECK(hipGetLastError());
+    }
+    ITTS_TRY(tap("prefix_emb", h, F32, (int64_t)B * S0 * D, s));
+    ITTS_TRY(gpt_layers_full(h, B, S0, ds.kv_start, true, s));
+    // logits of the last position only (generate takes logits[:, -1, :])
+    K(copy_rows(ds.h, D, h + (size_t)(S0 - 1) * D, S0 * D, B, D, F32, s));
+    K(double_ln(ds.hn, ds.h, gpt.ln_f.g, gpt.ln_f.b, gpt.final_norm.g, gpt.final_norm.b, B, D, 1e-5f, s));
+    if (!dry) {
+      GemvArgs g;
+      g.X = ds.hn;
+      g.W = gpt.head.w;
+      g.Y = ds.logits;
+      g.bias = gpt.head.b;
+      g.B = B;
+      g.N = V;
+      g.K = D;
+      g.ldy = V;
+      ITTS_TRY(gemv(g, gpt.head.dt, s));
+      SamplerArgs sa;
+      sa.logits = ds.logits;
+      sa.seen = ds.seen;
+      sa.ids = ds.ids;
+      sa.cur_tok = ds.cur_tok;
+      sa.unfinished = ds.unfinished;
+      sa.step = ds.step;
+      sa.n_unfinished = ds.n_unf;
+      sa.n_unfinished_next = ds.n_unf_next;
+      sa.V = V;
+      sa.max_gen = ds.max_gen;
+      sa.stop = c.stop_mel_token;
+      sa.suppress_stop = suppress;
+      sa.penalty = penalty;
+      ITTS_TRY(tap("logits0", ds.logits, F32, (int64_t)B * V, s));
+      ITTS_TRY(sampler_step(sa, B, s));
+    }
+    return OK;
+  };
+  ITTS_TRY(two_pass(body, s));
+  // rd/kvs are host stack buffers read by async copies
+  ITTS_HIP_CHECK(hipStreamSynchronize(s));
+  ds.active = true;
+  return OK;
+}
+
+// one decode step: embed -> 24 x {LN+QKV gemv, cache attention, proj gemv (+res), LN+FC gemv (gelu), proj2 gemv (+res)}
+// -> ln_f/final_norm -> mel_head gemv -> sampler.  Every length/position is read from device memory.
+int Engine::decode_step_launch(hipStream_t s) {
+  const itts_config& c = cfg;
+  const int D = c.model_dim, H = c.heads, dh = D / H, V = c.number_mel_codes, B = ds.B;
+  ITTS_TRY(decode_embed(ds.h, gpt.mel_emb, gpt.mel_pos, ds.cur_tok, ds.step, B, D, adt, s));
+  for (int l = 0; l < c.layers; ++l) {
+    const GptLayerW& L = gpt.layers[l];
+    GemvArgs g;
+    g.B = B;
+    // qkv = LN1(h) Wqkv + b
+    g.X = ds.h;
+    g.W = L.attn.w;
+    g.Y = ds.qkv;
+    g.bias = L.attn.b;
+    g.N = 3 * D;
+    g.K = D;
+    g.ldy = 3 * D;
+    g.ln_gamma = L.ln1.g;
+    g.ln_beta = L.ln1.b;
+    ITTS_TRY(gemv(g, L.attn.dt, s));
+    const size_t lo = (size_t)l * B * H * ds.Smax * dh * es;
+    ITTS_TRY(decode_attn(ds.ctx, ds.qkv, (char*)ds.kc + lo, (char*)ds.vc + lo, ds.step, ds.kv_start, ds.prefix_dev, B, H, dh,
+                         ds.Smax, adt, s));
+    // h += ctx Wproj + b
+    GemvArgs p;
+    p.B = B;
+    p.X = ds.ctx;
+    p.W = L.proj.w;
+    p.Y = ds.h;
+    p.bias = L.proj.b;
+    p.N = D;
+    p.K = D;
+    p.ldy = D;
+    p.accumulate = 1;
+    ITTS_TRY(gemv(p, L.proj.dt, s));
+    // act = gelu_new(LN2(h) Wfc + b)
+    GemvArgs f;
+    f.B = B;
+    f.X = ds.h;
+    f.W = L.fc.w;
+    f.Y = ds.act;
+    f.bias = L.fc.b;
+    f.N = 4 * D;
+    f.K = D;
+    f.ldy = 4 * D;
+    f.act = ACT_GELU_NEW;
+    f.ln_gamma = L.ln2.g;
+    f.ln_beta = L.ln2.b;
+    ITTS_TRY(gemv(f, L.fc.dt, s));
+    // h += act Wproj2 + b
+    GemvArgs q;
+    q.B = B;
+    q.X = ds.act;
+    q.W = L.proj2.w;
+    q.Y = ds.h;
+    q.bias = L.proj2.b;
+    q.N = D;
+    q.K = 4 * D;
+    q.ldy = D;
+    q.accumulate = 1;
+    ITTS_TRY(gemv(q, L.proj2.dt, s));
+  }
+  ITTS_TRY(double_ln(ds.hn, ds.h, gpt.ln_f.g, gpt.ln_f.b, gpt.final_norm.g, gpt.final_norm.b, B, D, 1e-5f, s));
+  GemvArgs g;
+  g.X = ds.hn;
+  g.W = gpt.head.w;
+  g.Y = ds.logits;
+  g.bias = gpt.head.b;
+  g.B = B;
+  g.N = V;
+  g.K = D;
+  g.ldy = V;
+  ITTS_TRY(gemv(g, gpt.head.dt, s));
+  SamplerArgs sa;
+  sa.logits = ds.logits;
+  sa.seen = ds.seen;
+  sa.ids = ds.ids;
+  sa.cur_tok = ds.cur_tok;
+  sa.unfinished = ds.unfinished;
+  sa.step = ds.step;
+  sa.n_unfinished = ds.n_unf;
+  sa.n_unfinished_next = ds.n_unf_next;
+  sa.V = V;
+  sa.max_gen = ds.max_gen;
+  sa.stop = c.stop_mel_token;
+  sa.suppress_stop = ds.suppress_stop;
+  sa.penalty = ds.penalty;
+  return sampler_step(sa, B, s);
+}
+
+int Engine::gpt_decode(int nsteps, hipStream_t s) {
+  if (!ds.active) {
+    set_error("gpt_decode: call itts_gpt_prefill first");
+    return E_STATE;
+  }
+  ITTS_REQUIRE(nsteps >= 0, "gpt_decode: nsteps < 0");
+  if (use_graph && s != nullptr) {
+    DecodeState& d = ds;
+    const bool stale = !d.graph || d.graph_B != d.B || d.graph_Smax != d.Smax || d.graph_penalty != d.penalty ||
+                       d.graph_suppress != d.suppress_stop;
+    if (stale && nsteps > 0) {
+      if (d.graph) {
+        (void)hipGraphExecDestroy(d.graph);
+        d.graph = nullptr;
+      }
+      hipGraph_t g = nullptr;
+      ITTS_HIP_CHECK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+      const int st = decode_step_launch(s);
+      const hipError_t ee = hipStreamEndCapture(s, &g);
+      if (st != OK) {
+        if (g) (void)hipGraphDestroy(g);
+        return st;
+      }
+      ITTS_HIP_CHECK(ee);
+      ITTS_HIP_CHECK(hipGraphInstantiate(&d.graph, g, nullptr, nullptr, 0));
+      (void)hipGraphDestroy(g);
+      d.graph_B = d.B;
+      d.graph_Smax = d.Smax;
+      d.graph_penalty = d.penalty;
+      d.graph_suppress = d.suppress_stop;
+    }
+    for (int i = 0; i < nsteps; ++i) ITTS_HIP_CHECK(hipGraphLaunch(d.graph, s));
+    return OK;
+  }
+  for (int i = 0; i < nsteps; ++i) ITTS_TRY(decode_step_launch(s));
+  return OK;
+}
+
+int Engine::gpt_status(int* steps, int* n_unf, hipStream_t s) {
+  if (!ds.active) {
+    set_error("gpt_status: no active generation");
+    return E_STATE;
+  }
+  int host[16];
+  ITTS_HIP_CHECK(hipMemcpyAsync(host, ds.step, 64, hipMemcpyDeviceToHost, s));
+  ITTS_HIP_CHECK(hipStreamSynchronize(s));
+  if (steps) *steps = host[0];
+  if (n_unf) *n_unf = host[4];
+  return OK;
+}
+
+int Engine::gpt_fetch(int32_t* codes, float* logits, hipStream_t s) {
+  if (!ds.active) {
+    set_error("gpt_fetch: no active generation");
+    return E_STATE;
+  }
+  if (codes) ITTS_HIP_CHECK(hipMemcpyAsync(codes, ds.ids, (size_t)ds.B * ds.max_gen * 4, hipMemcpyDeviceToHost, s));
+  if (logits)
+    ITTS_HIP_CHECK(hipMemcpyAsync(logits, ds.logits, (size_t)ds.B * cfg.number_mel_codes * 4, hipMemcpyDeviceToHost, s));
+  ITTS_HIP_CHECK(hipStreamSynchronize(s));
+  return OK;
+}
+
+int Engine::gpt_latent(const float* cond_dev, const int32_t* text_ids, int L, const int32_t* codes, int T,
+                       void* latent_out, hipStream_t s) {
+  if (!finalized || !gpt.ok) {
+    set_error("gpt_latent: GPT weights not bound");
+    return E_STATE;
+  }
+  const itts_config& c = cfg;
+  ITTS_REQUIRE(cond_dev && text_ids && codes && latent_out && L > 0 && T > 0, "gpt_latent: bad arguments");
+  ITTS_REQUIRE(L + 2 <= c.max_text_tokens + 2 && T + 2 <= c.max_mel_tokens + 3, "gpt_latent: sequence too long");
+  const int D = c.model_dim, nl = c.cond_latents;
+  const int S = nl + (L + 2) + (T + 2);
+  std::vector<RowDesc> rd(S);
+  int k = 0;
+  for (int i = 0; i < nl; ++i) rd[k++] = {1, i, 0, 0};
+  rd[k++] = {2, c.start_text_token, 0, 0};
+  for (int i = 0; i < L; ++i) {
+    ITTS_REQUIRE(text_ids[i] >= 0 && text_ids[i] <= c.number_text_tokens, "gpt_latent: text id out of range");
+    rd[k++] = {2, text_ids[i], i + 1, 0};
+  }
+  rd[k++] = {2, c.stop_text_token, L + 1, 0};
+  rd[k++] = {3, c.start_mel_token, 0, 0};
+  for (int i = 0; i < T; ++i) {
+    ITTS_REQUIRE(codes[i] >= 0 && codes[i] < c.number_mel_codes, "gpt_latent: mel code out of range");
+    rd[k++] = {3, codes[i], i + 1, 0};
+  }
+  rd[k++] = {3, c.stop_mel_token, T + 1, 0};
+  auto body = [&]() -> int {
+    RowDesc* rd_dev = (RowDesc*)alloc(rd.size() * sizeof(RowDesc));
+    float* h = (float*)alloc((size_t)S * D * 4);
+    float* hn = (float*)alloc((size_t)T * D * 4);
+    if (!dry) {
+      ITTS_HIP_CHECK(hipMemcpyAsync(rd_dev, rd.data(), rd.size() * sizeof(RowDesc), hipMemcpyHostToDevice, s));
+      if (adt == F32)
+        hipLaunchKernelGGL(gpt_embed_rows_kernel<float>, dim3(S), dim3(256), 0, s, h, rd_dev, cond_dev,
+                           (const float*)gpt.text_emb, (const float*)gpt.text_pos, (const float*)gpt.mel_emb,
+                           (const float*)gpt.mel_pos, D);
+      else
+        hipLaunchKernelGGL(gpt_embed_rows_kernel<bf16_t>, dim3(S), dim3(256), 0, s, h, rd_dev, cond_dev,
+                           (const bf16_t*)gpt.text_emb, (const bf16_t*)gpt.text_pos, (const bf16_t*)gpt.mel_emb,
+                           (const bf16_t*)gpt.mel_pos, D);
+      ITTS_HIP_CHECK(hipGetLastError());
+    }
+    const bool saved = ds.active;
+    (void)saved;
+    ITTS_TRY(gpt_layers_full(h, 1, S, nullptr, false, s));
+    // mel part = rows [nl + L + 2, +T+2); strip the two tokens added by the forward pass (model.py:578)
+    const float* mel_rows = h + (size_t)(nl + L + 2) * D;
+    K(double_ln(hn, mel_rows, gpt.ln_f.g, gpt.ln_f.b, gpt.final_norm.g, gpt.final_norm.b, T, D, 1e-5f, s));
+    K(cast_copy(latent_out, adt, hn, F32, (long)T * D, s));
+    return OK;
+  };
+  ITTS_TRY(two_pass(body, s));
+  ITTS_HIP_CHECK(hipStreamSynchronize(s));  // rd is a host buffer
+  return OK;
+}
+
+}  // namespace itts

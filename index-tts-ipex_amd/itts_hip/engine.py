@@ -1,0 +1,277 @@
+"""Python face of the HIP engine: owns the weight arena (one contiguous device buffer, so a single RCCL
+broadcast replicates a model across ranks), binds it into libitts_hip and exposes the hot-path stages
+as tensor-in / tensor-out calls.  torch is used for device memory and streams only."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import lib as L
+from .config import ecapa_dims, perceiver_inner
+
+_TORCH_DT = {L.F32: torch.float32, L.BF16: torch.bfloat16}
+
+
+def make_config(cfg, dtype: int, max_batch: int = 64) -> L.Config:
+    g, h, v = cfg["gpt"], cfg["bigvgan"], cfg["vqvae"]
+    cm = g["condition_module"]
+    c = L.Config()
+    c.dtype = dtype
+    c.model_dim, c.layers, c.heads = g["model_dim"], g["layers"], g["heads"]
+    c.max_mel_tokens, c.max_text_tokens = g["max_mel_tokens"], g["max_text_tokens"]
+    c.number_text_tokens, c.number_mel_codes = g["number_text_tokens"], g["number_mel_codes"]
+    c.start_mel_token, c.stop_mel_token = g["start_mel_token"], g["stop_mel_token"]
+    c.start_text_token, c.stop_text_token = g["start_text_token"], g["stop_text_token"]
+    c.cond_latents = g.get("condition_num_latent", 32)
+    c.cond_dim, c.cond_ff, c.cond_heads = cm["output_size"], cm["linear_units"], cm["attention_heads"]
+    c.cond_blocks, c.cond_idim = cm["num_blocks"], 100
+    c.perc_inner, c.perc_layers = perceiver_inner(g), 2
+    c.bv_gpt_dim, c.bv_init_ch = h["gpt_dim"], h["upsample_initial_channel"]
+    c.bv_num_up = len(h["upsample_rates"])
+    for i, (u, k) in enumerate(zip(h["upsample_rates"], h["upsample_kernel_sizes"])):
+        c.bv_up_rates[i], c.bv_up_kernels[i] = u, k
+    c.bv_num_res = len(h["resblock_kernel_sizes"])
+    c.bv_num_dil = len(h["resblock_dilation_sizes"][0])
+    for j, (k, ds) in enumerate(zip(h["resblock_kernel_sizes"], h["resblock_dilation_sizes"])):
+        c.bv_res_kernels[j] = k
+        for l, d in enumerate(ds):
+            c.bv_res_dils[j][l] = d
+    c.bv_spk_dim, c.bv_num_mels = h["speaker_embedding_dim"], h["num_mels"]
+    e = ecapa_dims(h)
+    for i in range(5):
+        c.ec_channels[i], c.ec_kernels[i], c.ec_dils[i] = e["channels"][i], e["kernel_sizes"][i], e["dilations"][i]
+    c.ec_att, c.ec_scale, c.ec_se = e["attention_channels"], e["res2net_scale"], e["se_channels"]
+    c.dv_channels, c.dv_tokens, c.dv_hidden = v["channels"], v["num_tokens"], v["hidden_dim"]
+    c.dv_resblocks, c.dv_codebook, c.dv_layers, c.dv_kernel = v["num_resnet_blocks"], v["codebook_dim"], v["num_layers"], v["kernel_size"]
+    c.max_batch = max_batch
+    return c
+
+
+class WeightArena:
+    """All packed tensors in ONE device buffer (256-byte aligned slots) + a manifest."""
+
+    def __init__(self, packed: Dict[str, Tuple[str, np.ndarray]], dtype: int, device):
+        self.dtype = dtype
+        self.manifest: List[Tuple[str, int, int, Tuple[int, ...]]] = []  # name, offset, dt, shape
+        off = 0
+        for name, (tag, arr) in packed.items():
+            dt = dtype if tag == "w" else L.F32
+            nbytes = int(np.prod(arr.shape)) * (2 if dt == L.BF16 else 4)
+            self.manifest.append((name, off, dt, tuple(int(x) for x in arr.shape)))
+            off = (off + nbytes + 255) // 256 * 256
+        self.nbytes = off
+        self.buf = torch.empty(off, dtype=torch.uint8, device=device)
+        # stage through pinned-free host tensors in chunks (bf16 rounding = torch RNE, same as the device cast)
+        for (name, o, dt, shape), (tag, arr) in zip(self.manifest, packed.values()):
+            t = torch.from_numpy(np.ascontiguousarray(arr, dtype=np.float32))
+            if dt == L.BF16:
+                t = t.to(torch.bfloat16)
+            n = t.numel() * t.element_size()
+            self.buf[o:o + n].copy_(t.reshape(-1).view(torch.uint8), non_blocking=False)
+
+    def view(self, name: str) -> torch.Tensor:
+        for n, o, dt, shape in self.manifest:
+            if n == name:
+                nb = int(np.prod(shape)) * (2 if dt == L.BF16 else 4)
+                return self.buf[o:o + nb].view(_TORCH_DT[dt]).view(*shape)
+        raise KeyError(name)
+
+
+class Engine:
+    def __init__(self, cfg, dtype: str = "bf16", device: str = "cuda:0", max_batch: int = 64):
+        if not torch.cuda.is_available():
+            raise RuntimeError("itts_hip.Engine needs an MI355X (no CPU fallback in the product path)")
+        self.lib = L.load()
+        self.cfg = cfg
+        self.dt = {"fp32": L.F32, "f32": L.F32, "bf16": L.BF16}[dtype]
+        self.tdt = _TORCH_DT[self.dt]
+        self.device = torch.device(device)
+        torch.cuda.set_device(self.device)
+        self.stream = torch.cuda.Stream(device=self.device)
+        self.ccfg = make_config(cfg, self.dt, max_batch)
+        h = C.c_void_p()
+        L.check(self.lib.itts_engine_create(C.byref(self.ccfg), C.byref(h)), "engine_create")
+        self.h = h
+        self.arenas: List[WeightArena] = []
+        self.up_total = int(np.prod(cfg["bigvgan"]["upsample_rates"]))
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                torch.cuda.synchronize(self.device)
+                self.lib.itts_engine_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    # ---- weights ----
+    def load_packed(self, packed: Dict[str, Tuple[str, np.ndarray]], arena: Optional[WeightArena] = None):
+        a = arena or WeightArena(packed, self.dt, self.device)
+        self.arenas.append(a)
+        base = a.buf.data_ptr()
+        for name, off, dt, shape in a.manifest:
+            dims = (C.c_int64 * len(shape))(*shape)
+            L.check(self.lib.itts_engine_bind_tensor(self.h, name.encode(), C.c_void_p(base + off), dt, len(shape), dims),
+                    f"bind {name}")
+        return a
+
+    def finalize(self):
+        L.check(self.lib.itts_engine_finalize(self.h), "finalize")
+
+    def debug(self, taps: bool = False, force_simple: bool = False, no_graph: bool = False):
+        L.check(self.lib.itts_debug_enable(self.h, int(taps) | (int(force_simple) << 1) | (int(no_graph) << 2)))
+
+    def fetch_tap(self, name: str) -> np.ndarray:
+        n = self.lib.itts_debug_fetch(self.h, name.encode(), None, 0)
+        if n < 0:
+            raise KeyError(name)
+        out = np.empty(n, dtype=np.float32)
+        self.lib.itts_debug_fetch(self.h, name.encode(), out.ctypes.data_as(C.c_void_p), n)
+        return out
+
+    # ---- helpers ----
+    def _s(self):
+        return C.c_void_p(self.stream.cuda_stream)
+
+    def _enter(self):
+        self.stream.wait_stream(torch.cuda.current_stream(self.device))
+
+    def _exit(self):
+        torch.cuda.current_stream(self.device).wait_stream(self.stream)
+
+    def to_act(self, x: torch.Tensor) -> torch.Tensor:
+        return x.to(device=self.device, dtype=self.tdt).contiguous()
+
+    # ---- stages ----
+    def conditioning(self, mel_bcf: torch.Tensor) -> torch.Tensor:
+        """mel [1, n_mels, F] (the reference's layout) -> cond fp32 [1, latents, D]."""
+        assert mel_bcf.ndim == 3 and mel_bcf.shape[0] == 1
+        mel = self.to_act(mel_bcf.transpose(1, 2))
+        F = mel.shape[1]
+        out = torch.empty(1, self.ccfg.cond_latents, self.ccfg.model_dim, dtype=torch.float32, device=self.device)
+        self._enter()
+        L.check(self.lib.itts_conditioning(self.h, mel.data_ptr(), F, out.data_ptr(), self._s()), "conditioning")
+        self._exit()
+        mel.record_stream(self.stream)
+        return out
+
+    def ecapa(self, mel_bfc: torch.Tensor) -> torch.Tensor:
+        """mel_ref [B, F, n_mels] -> spk fp32 [B, E]."""
+        mel = self.to_act(mel_bfc)
+        B, F, _ = mel.shape
+        out = torch.empty(B, self.ccfg.bv_spk_dim, dtype=torch.float32, device=self.device)
+        self._enter()
+        L.check(self.lib.itts_ecapa(self.h, mel.data_ptr(), B, F, out.data_ptr(), self._s()), "ecapa")
+        self._exit()
+        mel.record_stream(self.stream)
+        return out
+
+    def prefill(self, cond: torch.Tensor, text_ids: np.ndarray, max_gen: int, repetition_penalty: float = 10.0,
+                suppress_stop: bool = False):
+        ids = np.ascontiguousarray(text_ids, dtype=np.int32)
+        assert ids.ndim == 2
+        B, Lt = ids.shape
+        cond = cond.to(device=self.device, dtype=torch.float32).contiguous().view(-1, self.ccfg.model_dim)
+        self._enter()
+        L.check(self.lib.itts_gpt_prefill(self.h, cond.data_ptr(), ids.ctypes.data_as(C.c_void_p), B, Lt, max_gen,
+                                          float(repetition_penalty), int(suppress_stop), self._s()), "gpt_prefill")
+        self._gen = (B, max_gen)
+
+    def decode(self, nsteps: int):
+        L.check(self.lib.itts_gpt_decode(self.h, nsteps, self._s()), "gpt_decode")
+
+    def status(self) -> Tuple[int, int]:
+        a, b = C.c_int(), C.c_int()
+        L.check(self.lib.itts_gpt_status(self.h, C.byref(a), C.byref(b), self._s()), "gpt_status")
+        return a.value, b.value
+
+    def fetch(self, logits: bool = False):
+        B, mg = self._gen
+        codes = np.empty((B, mg), dtype=np.int32)
+        lg = np.empty((B, self.ccfg.number_mel_codes), dtype=np.float32) if logits else None
+        L.check(self.lib.itts_gpt_fetch(self.h, codes.ctypes.data_as(C.c_void_p),
+                                        lg.ctypes.data_as(C.c_void_p) if logits else None, self._s()), "gpt_fetch")
+        return (codes, lg) if logits else codes
+
+    def generate(self, cond: torch.Tensor, text_ids: np.ndarray, max_gen: int, repetition_penalty: float = 10.0,
+                 suppress_stop: bool = False, check_every: int = 16) -> np.ndarray:
+        """Greedy decode (do_sample=False, num_beams=1 of tests/padding_test.py:35-46).  Returns int64 codes
+        [B, n] with n <= max_gen: HF stops when every row has emitted stop or at max length."""
+        self.prefill(cond, text_ids, max_gen, repetition_penalty, suppress_stop)
+        done = 1
+        while done < max_gen:
+            if not suppress_stop:
+                step, unf = self.status()
+                done = step
+                if unf == 0:
+                    break
+            n = min(check_every, max_gen - done)
+            self.decode(n)
+            done += n
+        step, unf = self.status()
+        codes = self.fetch()[:, :step].astype(np.int64)
+        self._exit()
+        # HF stops right after the step in which the last running row emitted stop: trim the look-ahead steps
+        stop = self.ccfg.stop_mel_token
+        n = 0
+        for row in codes:
+            hit = np.nonzero(row == stop)[0]
+            n = max(n, int(hit[0]) + 1 if len(hit) else step)
+        return codes[:, :n]
+
+    def latent(self, cond: torch.Tensor, text_ids: np.ndarray, codes: np.ndarray) -> torch.Tensor:
+        """-> latent [1, T, D] engine dtype."""
+        t = np.ascontiguousarray(text_ids, dtype=np.int32).reshape(-1)
+        c = np.ascontiguousarray(codes, dtype=np.int32).reshape(-1)
+        cond = cond.to(device=self.device, dtype=torch.float32).contiguous().view(-1, self.ccfg.model_dim)
+        out = torch.empty(1, c.shape[0], self.ccfg.model_dim, dtype=self.tdt, device=self.device)
+        self._enter()
+        L.check(self.lib.itts_gpt_latent(self.h, cond.data_ptr(), t.ctypes.data_as(C.c_void_p), t.shape[0],
+                                         c.ctypes.data_as(C.c_void_p), c.shape[0], out.data_ptr(), self._s()), "gpt_latent")
+        self._exit()
+        return out
+
+    def bigvgan(self, latent: torch.Tensor, spk: torch.Tensor) -> torch.Tensor:
+        """latent [B, T, D], spk [B, E] -> wav fp32 [B, 1, T*up]."""
+        lat = self.to_act(latent)
+        B, T, _ = lat.shape
+        spk = spk.to(device=self.device, dtype=torch.float32).contiguous().view(B, -1)
+        out = torch.empty(B, 1, T * self.up_total, dtype=torch.float32, device=self.device)
+        self._enter()
+        L.check(self.lib.itts_bigvgan(self.h, lat.data_ptr(), spk.data_ptr(), B, T, out.data_ptr(), self._s()), "bigvgan")
+        self._exit()
+        lat.record_stream(self.stream)
+        spk.record_stream(self.stream)
+        return out
+
+    def dvae_decode(self, codes: np.ndarray) -> torch.Tensor:
+        """codes [B, T] -> mel [B, channels, 4T] (reference layout), engine dtype."""
+        c = np.ascontiguousarray(codes, dtype=np.int32)
+        B, T = c.shape
+        ch = self.ccfg.dv_channels
+        up = 2 ** self.ccfg.dv_layers
+        out = torch.empty(B, T * up, ch, dtype=self.tdt, device=self.device)
+        self._enter()
+        L.check(self.lib.itts_dvae_decode(self.h, c.ctypes.data_as(C.c_void_p), B, T, out.data_ptr(), self._s()), "dvae_decode")
+        self._exit()
+        return out.transpose(1, 2)
+
+
+def build_engine(cfg, dtype: str = "bf16", device: str = "cuda:0", seed: int = 1234, parts=("gpt", "bigvgan", "dvae"),
+                 state_dicts: Optional[dict] = None, max_batch: int = 64) -> Engine:
+    """Engine with synthetic (PRNG) or supplied reference-layout state dicts."""
+    from . import pack, synth
+
+    eng = Engine(cfg, dtype, device, max_batch)
+    sds = state_dicts or {}
+    if "gpt" in parts:
+        eng.load_packed(pack.pack_gpt(sds.get("gpt") or synth.gpt_state_dict(cfg, seed), cfg))
+    if "bigvgan" in parts:
+        eng.load_packed(pack.pack_bigvgan(sds.get("bigvgan") or synth.bigvgan_state_dict(cfg, seed), cfg))
+    if "dvae" in parts:
+        eng.load_packed(pack.pack_dvae(sds.get("dvae") or synth.dvae_state_dict(cfg, seed), cfg))
+    eng.finalize()
+    return eng

@@ -1,0 +1,107 @@
+"""ctypes binding of libitts_hip.so (C ABI declared in include/itts_hip.h).
+
+The product path has NO CPU fallback: if the shared library is missing or a call fails, this module
+raises RuntimeError (the reference's loader does the same when its CUDA extension cannot be built,
+indextts/BigVGAN/alias_free_activation/cuda/load.py:51-52,82-87).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.normpath(os.path.join(_HERE, "..", "csrc"))
+LIB_PATH = os.environ.get("ITTS_HIP_LIB", os.path.join(CSRC, "libitts_hip.so"))
+
+F32, BF16 = 0, 1
+ACT = {"none": 0, "relu": 1, "silu": 2, "gelu_new": 3, "gelu_erf": 4, "tanh": 5, "sigmoid": 6}
+
+vp, i32, f32, i64 = C.c_void_p, C.c_int, C.c_float, C.c_int64
+
+
+class GemmArgs(C.Structure):
+    _fields_ = [("A", vp), ("W", vp), ("C", vp),
+                ("M", i32), ("N", i32), ("Cin", i32), ("taps", i32), ("lda", i32), ("ldc", i32), ("T", i32),
+                ("dil", i32), ("pad_left", i32), ("pad_mode", i32), ("in_up", i32), ("nphase", i32),
+                ("phase_shift", i32 * 8),
+                ("bias", vp), ("bias_bstride", i32), ("act", i32),
+                ("scale", vp), ("shift", vp), ("act2", i32),
+                ("R", vp), ("ldr", i32), ("alpha", f32),
+                ("ADD", vp), ("ldadd", i32), ("beta", f32),
+                ("dtype_a", i32), ("dtype_w", i32), ("dtype_c", i32), ("force_simple", i32)]
+
+
+class Config(C.Structure):
+    _fields_ = [("dtype", i32),
+                ("model_dim", i32), ("layers", i32), ("heads", i32), ("max_mel_tokens", i32), ("max_text_tokens", i32),
+                ("number_text_tokens", i32), ("number_mel_codes", i32),
+                ("start_mel_token", i32), ("stop_mel_token", i32), ("start_text_token", i32), ("stop_text_token", i32),
+                ("cond_latents", i32),
+                ("cond_dim", i32), ("cond_ff", i32), ("cond_heads", i32), ("cond_blocks", i32), ("cond_idim", i32),
+                ("perc_inner", i32), ("perc_layers", i32),
+                ("bv_gpt_dim", i32), ("bv_init_ch", i32), ("bv_num_up", i32), ("bv_up_rates", i32 * 8),
+                ("bv_up_kernels", i32 * 8),
+                ("bv_num_res", i32), ("bv_res_kernels", i32 * 4), ("bv_res_dils", (i32 * 4) * 4), ("bv_num_dil", i32),
+                ("bv_spk_dim", i32), ("bv_num_mels", i32),
+                ("ec_channels", i32 * 5), ("ec_kernels", i32 * 5), ("ec_dils", i32 * 5), ("ec_att", i32),
+                ("ec_scale", i32), ("ec_se", i32),
+                ("dv_channels", i32), ("dv_tokens", i32), ("dv_hidden", i32), ("dv_resblocks", i32),
+                ("dv_codebook", i32), ("dv_layers", i32), ("dv_kernel", i32),
+                ("max_batch", i32)]
+
+
+_lib = None
+
+_PROTOS = {
+    "itts_last_error": (C.c_char_p, []),
+    "itts_abi_version": (i32, []),
+    "itts_snake_aa_fwd": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
+    "itts_gemm": (i32, [C.POINTER(GemmArgs), vp]),
+    "itts_layernorm": (i32, [vp, i32, vp, i32, vp, vp, i32, i32, f32, vp]),
+    "itts_attention": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, f32, i32, vp, i32, vp]),
+    "itts_transpose": (i32, [vp, vp, i32, i32, i32, i32, vp]),
+    "itts_engine_create": (i32, [C.POINTER(Config), C.POINTER(vp)]),
+    "itts_engine_destroy": (None, [vp]),
+    "itts_engine_bind_tensor": (i32, [vp, C.c_char_p, vp, i32, i32, C.POINTER(i64)]),
+    "itts_engine_finalize": (i32, [vp]),
+    "itts_conditioning": (i32, [vp, vp, i32, vp, vp]),
+    "itts_ecapa": (i32, [vp, vp, i32, i32, vp, vp]),
+    "itts_gpt_prefill": (i32, [vp, vp, vp, i32, i32, i32, f32, i32, vp]),
+    "itts_gpt_decode": (i32, [vp, i32, vp]),
+    "itts_gpt_status": (i32, [vp, C.POINTER(i32), C.POINTER(i32), vp]),
+    "itts_gpt_fetch": (i32, [vp, vp, vp, vp]),
+    "itts_gpt_latent": (i32, [vp, vp, vp, i32, vp, i32, vp, vp]),
+    "itts_bigvgan": (i32, [vp, vp, vp, i32, i32, vp, vp]),
+    "itts_dvae_decode": (i32, [vp, vp, i32, i32, vp, vp]),
+    "itts_debug_fetch": (i64, [vp, C.c_char_p, vp, i64]),
+    "itts_debug_enable": (i32, [vp, i32]),
+}
+
+
+def exported_symbols():
+    """Every entry point include/itts_hip.h declares (used by the CPU load/export test)."""
+    return sorted(_PROTOS)
+
+
+def load():
+    """dlopen the library and attach prototypes.  No GPU work happens here."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"libitts_hip.so not found at {LIB_PATH}: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            f"or `make -C {CSRC}` (there is no CPU fallback)")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in _PROTOS.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(status: int, what: str = ""):
+    if status != 0:
+        msg = load().itts_last_error().decode("utf-8", "replace")
+        raise RuntimeError(f"libitts_hip {what} failed ({status}): {msg}")

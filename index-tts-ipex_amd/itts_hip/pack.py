@@ -1,0 +1,249 @@
+"""Weight packer: reference-layout state dicts -> the engine's tensor set.
+
+Ingests what `load_checkpoint(gpt, gpt.pth)` / `bigvgan_generator.pth["generator"]` / `dvae.pth` hold
+(SURVEY.md section 5 key layout; infer.py:47-66) and produces the layouts the HIP kernels stream:
+
+* every linear / conv weight as [N][taps][Cin] (k-contiguous rows; HF Conv1D [in,out] is transposed,
+  torch Conv1d [Cout,Cin,k] is tap-major re-ordered, ConvTranspose1d [Cin,Cout,k] becomes `u` polyphase
+  slabs [u][Cout][k/u][Cin]),
+* weight-norm pairs (weight_g / weight_v) folded (what `remove_weight_norm` does, models.py:252-260),
+* eval-mode BatchNorm folded to a per-channel (scale, shift) applied after the ReLU (ECAPA_TDNN.py:128),
+* conformer q/k/v projections fused, the ASP context conv split into its x / (mean,std) column blocks,
+* the perceiver FFN's odd inner width zero-padded to a multiple of 32,
+* SnakeBeta alpha/beta kept LOG-scale fp32 (the native-op contract, cuda/activation1d.py:60-71).
+
+Values tagged "w" are stored in the engine dtype (fp32 parity path or bf16), "f" always fp32.
+"""
+from __future__ import annotations
+
+from typing import Dict, Tuple
+
+import numpy as np
+
+from .config import ecapa_dims, perceiver_inner
+
+Packed = Dict[str, Tuple[str, np.ndarray]]
+
+
+def _fold_weight_norm(sd: Dict[str, np.ndarray]) -> Dict[str, np.ndarray]:
+    """weight = g * v / ||v|| with the norm over all dims but 0 (torch weight_norm dim=0)."""
+    out = dict(sd)
+    for k in list(sd):
+        if k.endswith(".weight_g"):
+            base = k[: -len(".weight_g")]
+            g, v = sd[k], sd[base + ".weight_v"]
+            nrm = np.sqrt((v.astype(np.float64) ** 2).sum(axis=tuple(range(1, v.ndim)), keepdims=True))
+            out[base + ".weight"] = (v * (g / nrm)).astype(np.float32)
+            del out[k], out[base + ".weight_v"]
+    return out
+
+
+def conv_w(w: np.ndarray) -> np.ndarray:
+    """torch Conv1d [Cout, Cin, k] -> [Cout, k*Cin] (tap-major)."""
+    co, ci, k = w.shape
+    return np.ascontiguousarray(w.transpose(0, 2, 1)).reshape(co, k * ci)
+
+
+def convT_w(w: np.ndarray, u: int, p: int) -> np.ndarray:
+    """torch ConvTranspose1d [Cin, Cout, k] -> [u, Cout, (k/u)*Cin]; phase ph tap m uses kernel index
+    ((ph+p) % u) + u*m and input offset floor((ph+p)/u) - m."""
+    ci, co, k = w.shape
+    nt = k // u
+    out = np.zeros((u, co, nt * ci), dtype=np.float32)
+    for ph in range(u):
+        for m in range(nt):
+            kk = (ph + p) % u + u * m
+            out[ph, :, m * ci:(m + 1) * ci] = w[:, :, kk].T
+    return out
+
+
+def bn_fold(sd, name: str, eps: float = 1e-5):
+    sc = sd[name + ".weight"] / np.sqrt(sd[name + ".running_var"] + eps)
+    sh = sd[name + ".bias"] - sd[name + ".running_mean"] * sc
+    return sc.astype(np.float32), sh.astype(np.float32)
+
+
+def pack_gpt(sd: Dict[str, np.ndarray], cfg) -> Packed:
+    g = cfg["gpt"]
+    cm = g["condition_module"]
+    P: Packed = {}
+    ce = "conditioning_encoder."
+    od = cm["output_size"]
+    P["cond.embed.conv.weight"] = ("f", sd[ce + "embed.conv.0.weight"].reshape(od, 9))
+    P["cond.embed.conv.bias"] = ("f", sd[ce + "embed.conv.0.bias"])
+    P["cond.embed.out.weight"] = ("w", sd[ce + "embed.out.0.weight"])
+    P["cond.embed.out.bias"] = ("f", sd[ce + "embed.out.0.bias"])
+    P["cond.pe"] = ("w", sd[ce + "embed.pos_enc.pe"][0])
+    for n in ("weight", "bias"):
+        P[f"cond.after_norm.{n}"] = ("f", sd[f"{ce}after_norm.{n}"])
+    for i in range(cm["num_blocks"]):
+        s, d = f"{ce}encoders.{i}.", f"cond.{i}."
+        a = s + "self_attn."
+        P[d + "qkv.weight"] = ("w", np.concatenate([sd[a + f"linear_{x}.weight"] for x in "qkv"], 0))
+        P[d + "qkv.bias"] = ("f", np.concatenate([sd[a + f"linear_{x}.bias"] for x in "qkv"], 0))
+        P[d + "pos.weight"] = ("w", sd[a + "linear_pos.weight"])
+        P[d + "pos_bias_u"] = ("f", sd[a + "pos_bias_u"].reshape(-1))
+        P[d + "pos_bias_v"] = ("f", sd[a + "pos_bias_v"].reshape(-1))
+        P[d + "out.weight"] = ("w", sd[a + "linear_out.weight"])
+        P[d + "out.bias"] = ("f", sd[a + "linear_out.bias"])
+        P[d + "ff.w1.weight"] = ("w", sd[s + "feed_forward.w_1.weight"])
+        P[d + "ff.w1.bias"] = ("f", sd[s + "feed_forward.w_1.bias"])
+        P[d + "ff.w2.weight"] = ("w", sd[s + "feed_forward.w_2.weight"])
+        P[d + "ff.w2.bias"] = ("f", sd[s + "feed_forward.w_2.bias"])
+        c = s + "conv_module."
+        P[d + "conv.pw1.weight"] = ("w", sd[c + "pointwise_conv1.weight"][:, :, 0])
+        P[d + "conv.pw1.bias"] = ("f", sd[c + "pointwise_conv1.bias"])
+        P[d + "conv.dw.weight"] = ("f", sd[c + "depthwise_conv.weight"][:, 0, :])
+        P[d + "conv.dw.bias"] = ("f", sd[c + "depthwise_conv.bias"])
+        P[d + "conv.norm.weight"] = ("f", sd[c + "norm.weight"])
+        P[d + "conv.norm.bias"] = ("f", sd[c + "norm.bias"])
+        P[d + "conv.pw2.weight"] = ("w", sd[c + "pointwise_conv2.weight"][:, :, 0])
+        P[d + "conv.pw2.bias"] = ("f", sd[c + "pointwise_conv2.bias"])
+        for nn in ("norm_ff", "norm_mha", "norm_conv", "norm_final"):
+            P[d + nn + ".weight"] = ("f", sd[s + nn + ".weight"])
+            P[d + nn + ".bias"] = ("f", sd[s + nn + ".bias"])
+    pe = "perceiver_encoder."
+    P["perc.latents"] = ("f", sd[pe + "latents"])
+    P["perc.proj.weight"] = ("w", sd[pe + "proj_context.weight"])
+    P["perc.proj.bias"] = ("f", sd[pe + "proj_context.bias"])
+    ffi = perceiver_inner(g)
+    ffp = (ffi + 31) // 32 * 32
+    for j in range(2):
+        s, d = f"{pe}layers.{j}.", f"perc.{j}."
+        P[d + "to_q.weight"] = ("w", sd[s + "0.to_q.weight"])
+        P[d + "to_kv.weight"] = ("w", sd[s + "0.to_kv.weight"])
+        P[d + "to_out.weight"] = ("w", sd[s + "0.to_out.weight"])
+        P[d + "ff1.weight"] = ("w", sd[s + "1.0.weight"])
+        P[d + "ff1.bias"] = ("f", sd[s + "1.0.bias"])
+        w2 = np.zeros((sd[s + "1.2.weight"].shape[0], ffp), dtype=np.float32)
+        w2[:, :ffi] = sd[s + "1.2.weight"]
+        P[d + "ff2.weight"] = ("w", w2)
+        P[d + "ff2.bias"] = ("f", sd[s + "1.2.bias"])
+    P["perc.norm.gamma"] = ("f", sd[pe + "norm.gamma"])
+    # GPT-2 stack (inference_model.* aliases of a post-init state dict are ignored: SURVEY 3.1 step 3)
+    for i in range(g["layers"]):
+        s = f"gpt.h.{i}."
+        for nn in ("ln_1", "ln_2"):
+            P[s + nn + ".weight"] = ("f", sd[s + nn + ".weight"])
+            P[s + nn + ".bias"] = ("f", sd[s + nn + ".bias"])
+        for nn in ("attn.c_attn", "attn.c_proj", "mlp.c_fc", "mlp.c_proj"):
+            P[s + nn + ".weight"] = ("w", np.ascontiguousarray(sd[s + nn + ".weight"].T))
+            P[s + nn + ".bias"] = ("f", sd[s + nn + ".bias"])
+    for nn in ("weight", "bias"):
+        P["gpt.ln_f." + nn] = ("f", sd["gpt.ln_f." + nn])
+        P["gpt.final_norm." + nn] = ("f", sd["final_norm." + nn])
+    P["gpt.mel_head.weight"] = ("w", sd["mel_head.weight"])
+    P["gpt.mel_head.bias"] = ("f", sd["mel_head.bias"])
+    P["gpt.text_embedding"] = ("w", sd["text_embedding.weight"])
+    P["gpt.mel_embedding"] = ("w", sd["mel_embedding.weight"])
+    P["gpt.mel_pos"] = ("w", sd["mel_pos_embedding.emb.weight"])
+    P["gpt.text_pos"] = ("w", sd["text_pos_embedding.emb.weight"])
+    return P
+
+
+def _filter12() -> np.ndarray:
+    """kaiser_sinc_filter1d(cutoff 0.25, half_width 0.3, 12 taps) (alias_free_torch/filter.py:29-58), computed
+    in float64 numpy (np.i0 Kaiser window) and rounded once to fp32."""
+    ks, half = 12, 6
+    A = 2.285 * (half - 1) * np.pi * (4 * 0.3) + 7.95
+    beta = 0.1102 * (A - 8.7) if A > 50.0 else (0.5842 * (A - 21) ** 0.4 + 0.07886 * (A - 21.0) if A >= 21.0 else 0.0)
+    n = np.arange(ks, dtype=np.float64)
+    window = np.i0(beta * np.sqrt(1 - ((n - (ks - 1) / 2) / ((ks - 1) / 2)) ** 2)) / np.i0(beta)
+    time = np.arange(-half, half, dtype=np.float64) + 0.5
+    f = 2 * 0.25 * window * np.sinc(2 * 0.25 * time)
+    return (f / f.sum()).astype(np.float32)
+
+
+def pack_bigvgan(sd: Dict[str, np.ndarray], cfg) -> Packed:
+    h = cfg["bigvgan"]
+    sd = _fold_weight_norm(sd)
+    P: Packed = {}
+    C0 = h["upsample_initial_channel"]
+    P["bv.conv_pre.weight"] = ("w", conv_w(sd["conv_pre.weight"]))
+    P["bv.conv_pre.bias"] = ("f", sd["conv_pre.bias"])
+    P["bv.cond_layer.weight"] = ("f", sd["cond_layer.weight"][:, :, 0])
+    P["bv.cond_layer.bias"] = ("f", sd["cond_layer.bias"])
+    nk = len(h["resblock_kernel_sizes"])
+    ch = C0
+    for i, (u, k) in enumerate(zip(h["upsample_rates"], h["upsample_kernel_sizes"])):
+        P[f"bv.ups.{i}.weight"] = ("w", convT_w(sd[f"ups.{i}.0.weight"], u, (k - u) // 2))
+        P[f"bv.ups.{i}.bias"] = ("f", sd[f"ups.{i}.0.bias"])
+        P[f"bv.conds.{i}.weight"] = ("f", sd[f"conds.{i}.weight"][:, :, 0])
+        P[f"bv.conds.{i}.bias"] = ("f", sd[f"conds.{i}.bias"])
+        ch = C0 // (2 ** (i + 1))
+        for j in range(nk):
+            n = i * nk + j
+            nd = len(h["resblock_dilation_sizes"][j])
+            for l in range(nd):
+                P[f"bv.res.{n}.c1.{l}.weight"] = ("w", conv_w(sd[f"resblocks.{n}.convs1.{l}.weight"]))
+                P[f"bv.res.{n}.c1.{l}.bias"] = ("f", sd[f"resblocks.{n}.convs1.{l}.bias"])
+                P[f"bv.res.{n}.c2.{l}.weight"] = ("w", conv_w(sd[f"resblocks.{n}.convs2.{l}.weight"]))
+                P[f"bv.res.{n}.c2.{l}.bias"] = ("f", sd[f"resblocks.{n}.convs2.{l}.bias"])
+            for m in range(2 * nd):
+                P[f"bv.res.{n}.act.{m}.alpha"] = ("f", sd[f"resblocks.{n}.activations.{m}.act.alpha"])
+                P[f"bv.res.{n}.act.{m}.beta"] = ("f", sd[f"resblocks.{n}.activations.{m}.act.beta"])
+    P["bv.act_post.alpha"] = ("f", sd["activation_post.act.alpha"])
+    P["bv.act_post.beta"] = ("f", sd["activation_post.act.beta"])
+    P["bv.conv_post.weight"] = ("w", conv_w(sd["conv_post.weight"]))
+    P["bv.conv_post.bias"] = ("f", sd["conv_post.bias"])
+    fk = "activation_post.upsample.filter"
+    P["bv.filter"] = ("f", sd[fk].reshape(-1).astype(np.float32) if fk in sd else _filter12())
+    # ---- ECAPA-TDNN ----
+    e = ecapa_dims(h)
+    chs = e["channels"]
+    s = "speaker_encoder."
+
+    def tdnn(dst, src):
+        P[dst + ".weight"] = ("w", conv_w(sd[src + ".conv.conv.weight"]))
+        P[dst + ".bias"] = ("f", sd[src + ".conv.conv.bias"])
+        sc, sh = bn_fold(sd, src + ".norm.norm")
+        P[dst + ".bn_scale"], P[dst + ".bn_shift"] = ("f", sc), ("f", sh)
+
+    tdnn("spk.b0", s + "blocks.0")
+    for i in range(1, len(chs) - 1):
+        p = f"{s}blocks.{i}."
+        tdnn(f"spk.b{i}.tdnn1", p + "tdnn1")
+        for q in range(e["res2net_scale"] - 1):
+            tdnn(f"spk.b{i}.res.{q}", f"{p}res2net_block.blocks.{q}")
+        tdnn(f"spk.b{i}.tdnn2", p + "tdnn2")
+        P[f"spk.b{i}.se1.weight"] = ("f", sd[p + "se_block.conv1.conv.weight"][:, :, 0])
+        P[f"spk.b{i}.se1.bias"] = ("f", sd[p + "se_block.conv1.conv.bias"])
+        P[f"spk.b{i}.se2.weight"] = ("f", sd[p + "se_block.conv2.conv.weight"][:, :, 0])
+        P[f"spk.b{i}.se2.bias"] = ("f", sd[p + "se_block.conv2.conv.bias"])
+    tdnn("spk.mfa", s + "mfa")
+    wa = sd[s + "asp.tdnn.conv.conv.weight"][:, :, 0]
+    C4 = chs[-1]
+    P["spk.asp.tdnn_x.weight"] = ("w", np.ascontiguousarray(wa[:, :C4]))
+    P["spk.asp.tdnn_ms.weight"] = ("f", np.ascontiguousarray(wa[:, C4:]))
+    P["spk.asp.tdnn_ms.bias"] = ("f", sd[s + "asp.tdnn.conv.conv.bias"])
+    sc, sh = bn_fold(sd, s + "asp.tdnn.norm.norm")
+    P["spk.asp.tdnn.bn_scale"], P["spk.asp.tdnn.bn_shift"] = ("f", sc), ("f", sh)
+    P["spk.asp.conv.weight"] = ("w", sd[s + "asp.conv.conv.weight"][:, :, 0])
+    P["spk.asp.conv.bias"] = ("f", sd[s + "asp.conv.conv.bias"])
+    sc, sh = bn_fold(sd, s + "asp_bn.norm")
+    P["spk.asp_bn.scale"], P["spk.asp_bn.shift"] = ("f", sc), ("f", sh)
+    P["spk.fc.weight"] = ("f", sd[s + "fc.conv.weight"][:, :, 0])
+    P["spk.fc.bias"] = ("f", sd[s + "fc.conv.bias"])
+    return P
+
+
+def pack_dvae(sd: Dict[str, np.ndarray], cfg) -> Packed:
+    v = cfg["vqvae"]
+    P: Packed = {}
+    P["dvae.codebook"] = ("w", np.ascontiguousarray(sd["codebook.embed"].T))
+    idx = 0
+    P["dvae.in.weight"] = ("w", conv_w(sd[f"decoder.{idx}.weight"]))
+    P["dvae.in.bias"] = ("f", sd[f"decoder.{idx}.bias"])
+    idx += 1
+    for i in range(v["num_resnet_blocks"]):
+        for a, b in (("c0", 0), ("c2", 2), ("c4", 4)):
+            P[f"dvae.rb{i}.{a}.weight"] = ("w", conv_w(sd[f"decoder.{idx}.net.{b}.weight"]))
+            P[f"dvae.rb{i}.{a}.bias"] = ("f", sd[f"decoder.{idx}.net.{b}.bias"])
+        idx += 1
+    for i in range(v["num_layers"]):
+        P[f"dvae.up{i}.weight"] = ("w", conv_w(sd[f"decoder.{idx}.0.conv.weight"]))
+        P[f"dvae.up{i}.bias"] = ("f", sd[f"decoder.{idx}.0.conv.bias"])
+        idx += 1
+    P["dvae.out.weight"] = ("w", conv_w(sd[f"decoder.{idx}.weight"]))
+    P["dvae.out.bias"] = ("f", sd[f"decoder.{idx}.bias"])
+    return P

@@ -1,0 +1,196 @@
+"""GPU: operator-level parity of the HIP kernels (through the C ABI) against the oracle / torch-fp32 CPU."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from itts_hip import lib as L  # noqa: E402
+from itts_hip import pack, prng  # noqa: E402
+from oracle import vocoder as ovoc  # noqa: E402
+
+DEV = "cuda:0"
+
+
+def rnd(name, shape, std=1.0):
+    return torch.from_numpy(prng.tensor(name, 5, shape, std=std))
+
+
+def relerr(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-12))
+
+
+def stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+@pytest.fixture(scope="module")
+def lib():
+    return L.load()
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+@pytest.mark.parametrize("layout", [0, 1])
+def test_snake_golden(lib, gold, tag, layout):
+    g = gold(f"micro_act1d_{tag}")
+    x = torch.from_numpy(g["x"]).to(DEV)
+    B, Cc, T = x.shape
+    xin = x.contiguous() if layout == 0 else x.transpose(1, 2).contiguous()
+    y = torch.empty_like(xin)
+    filt = torch.from_numpy(g["filt"]).to(DEV)
+    al, be = torch.from_numpy(g["alpha"]).to(DEV), torch.from_numpy(g["beta"]).to(DEV)
+    L.check(lib.itts_snake_aa_fwd(y.data_ptr(), xin.data_ptr(), filt.data_ptr(), filt.data_ptr(), al.data_ptr(),
+                                  be.data_ptr(), B, Cc, T, L.F32, layout, stream()))
+    out = y if layout == 0 else y.transpose(1, 2)
+    assert relerr(out, torch.from_numpy(g["y"])) < 2e-5
+
+
+@pytest.mark.parametrize("shape", [(2, 768, 100), (1, 24, 4099), (3, 5, 33)])
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+def test_snake_vs_oracle(lib, shape, dt):
+    B, Cc, T = shape
+    x = rnd(f"snk{shape}", shape, 1.5)
+    al, be = rnd("snk.a", (Cc,), 0.4), rnd("snk.b", (Cc,), 0.4)
+    tdt = torch.float32 if dt == "f32" else torch.bfloat16
+    xq = x.to(tdt)
+    ref = ovoc.activation1d(xq.float(), al, be)
+    filt = ovoc.kaiser_sinc_filter12().to(DEV)
+    ald, bed = al.to(DEV), be.to(DEV)  # keep alive: data_ptr() of a temporary dangles
+    for layout in (0, 1):
+        xin = (xq if layout == 0 else xq.transpose(1, 2)).contiguous().to(DEV)
+        y = torch.empty_like(xin)
+        L.check(lib.itts_snake_aa_fwd(y.data_ptr(), xin.data_ptr(), filt.data_ptr(), filt.data_ptr(),
+                                      ald.data_ptr(), bed.data_ptr(), B, Cc, T,
+                                      L.F32 if dt == "f32" else L.BF16, layout, stream()))
+        out = (y if layout == 0 else y.transpose(1, 2)).float()
+        assert relerr(out, ref) < (2e-5 if dt == "f32" else 1e-2)
+
+
+def run_gemm(lib, A, W, Cshape, dt_a, dt_w, dt_c, force_simple=0, **kw):
+    g = L.GemmArgs()
+    for k in ("dil", "in_up", "nphase", "taps"):
+        setattr(g, k, 1)
+    g.alpha = 1.0
+    g.A, g.W = A.data_ptr(), W.data_ptr()
+    Cout = torch.empty(Cshape, dtype=torch.float32 if dt_c == L.F32 else torch.bfloat16, device=DEV)
+    g.C = Cout.data_ptr()
+    keep = []
+    for k, v in kw.items():
+        if isinstance(v, torch.Tensor):
+            keep.append(v)
+            v = v.data_ptr()
+        if k == "phase_shift":
+            for i, s in enumerate(v):
+                g.phase_shift[i] = s
+            continue
+        setattr(g, k, v)
+    g.dtype_a, g.dtype_w, g.dtype_c, g.force_simple = dt_a, dt_w, dt_c, force_simple
+    L.check(lib.itts_gemm(C.byref(g), stream()))
+    torch.cuda.synchronize()
+    return Cout
+
+
+CONV_CASES = [
+    # B, T, Cin, Cout, k, dil, mode
+    (2, 37, 32, 48, 3, 1, "zeros"), (1, 50, 64, 64, 7, 3, "zeros"), (2, 41, 24, 24, 11, 5, "zeros"),
+    (1, 33, 100, 64, 5, 1, "reflect"), (2, 29, 64, 64, 3, 4, "reflect"), (1, 64, 128, 1, 7, 1, "zeros"),
+    (1, 130, 256, 192, 3, 1, "zeros"),
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("simple", [1, 0])
+def test_conv1d(lib, case, dt, simple):
+    B, T, Cin, Cout, k, dil, mode = case
+    tdt = torch.float32 if dt == "f32" else torch.bfloat16
+    ldt = L.F32 if dt == "f32" else L.BF16
+    x = rnd(f"cv.x{case}", (B, Cin, T)).to(tdt)
+    w = rnd(f"cv.w{case}", (Cout, Cin, k), 1.0 / np.sqrt(Cin * k)).to(tdt)
+    bias = rnd(f"cv.b{case}", (Cout,), 0.1)
+    pad = dil * (k - 1) // 2
+    xp = F.pad(x.float(), (pad, pad), mode="reflect") if mode == "reflect" else F.pad(x.float(), (pad, pad))
+    ref = F.conv1d(xp, w.float(), bias, dilation=dil)
+    res = rnd(f"cv.r{case}", (B, Cout, T)).to(tdt)
+    ref = F.relu(ref) + res.float()
+    A = x.transpose(1, 2).contiguous().to(DEV)
+    W = torch.from_numpy(pack.conv_w(w.float().numpy())).to(tdt).to(DEV)
+    R = res.transpose(1, 2).contiguous().to(DEV)
+    out = run_gemm(lib, A, W, (B, T, Cout), ldt, ldt, ldt, simple, M=B * T, N=Cout, Cin=Cin, taps=k, lda=Cin, ldc=Cout,
+                   T=T, dil=dil, pad_left=pad, pad_mode=1 if mode == "reflect" else 0, bias=bias.to(DEV), act=1, R=R,
+                   ldr=Cout)
+    assert relerr(out.float().transpose(1, 2), ref) < (2e-5 if dt == "f32" else 2e-2)
+
+
+@pytest.mark.parametrize("case", [(2, 19, 64, 32, 8, 4), (1, 23, 32, 16, 4, 4), (2, 17, 48, 24, 4, 2), (1, 9, 128, 64, 8, 4)])
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("simple", [1, 0])
+def test_conv_transpose1d(lib, case, dt, simple):
+    B, T, Cin, Cout, k, u = case
+    p = (k - u) // 2
+    tdt = torch.float32 if dt == "f32" else torch.bfloat16
+    ldt = L.F32 if dt == "f32" else L.BF16
+    x = rnd(f"ct.x{case}", (B, Cin, T)).to(tdt)
+    w = rnd(f"ct.w{case}", (Cin, Cout, k), 1.0 / np.sqrt(Cin * k / u)).to(tdt)
+    bias = rnd(f"ct.b{case}", (B, Cout), 0.1)  # per-batch bias (speaker conditioning folded in)
+    ref = F.conv_transpose1d(x.float(), w.float(), None, stride=u, padding=p) + bias[:, :, None]
+    A = x.transpose(1, 2).contiguous().to(DEV)
+    W = torch.from_numpy(pack.convT_w(w.float().numpy(), u, p)).to(tdt).to(DEV)
+    out = run_gemm(lib, A, W, (B, T * u, Cout), ldt, ldt, ldt, simple, M=B * T, N=Cout, Cin=Cin, taps=k // u, lda=Cin,
+                   ldc=u * Cout, T=T, dil=-1, pad_left=0, nphase=u, phase_shift=[(ph + p) // u for ph in range(u)],
+                   bias=bias.to(DEV), bias_bstride=Cout)
+    assert relerr(out.float().transpose(1, 2), ref) < (2e-5 if dt == "f32" else 2e-2)
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+def test_upsampled_conv_and_linear(lib, dt):
+    tdt = torch.float32 if dt == "f32" else torch.bfloat16
+    ldt = L.F32 if dt == "f32" else L.BF16
+    B, T, Cin, Cout = 2, 11, 64, 32
+    x = rnd("uc.x", (B, Cin, T)).to(tdt)
+    w = rnd("uc.w", (Cout, Cin, 3), 0.1).to(tdt)
+    ref = F.conv1d(F.interpolate(x.float(), scale_factor=2, mode="nearest"), w.float(), None, padding=1)
+    A = x.transpose(1, 2).contiguous().to(DEV)
+    W = torch.from_numpy(pack.conv_w(w.float().numpy())).to(tdt).to(DEV)
+    out = run_gemm(lib, A, W, (B, 2 * T, Cout), ldt, ldt, ldt, 0, M=B * 2 * T, N=Cout, Cin=Cin, taps=3, lda=Cin, ldc=Cout,
+                   T=2 * T, pad_left=1, in_up=2)
+    assert relerr(out.float().transpose(1, 2), ref) < (2e-5 if dt == "f32" else 2e-2)
+    # linear with odd K and alpha/affine epilogue, fp32 output
+    M, K, N = 37, 3413, 130
+    a = rnd("ln.a", (M, K)).to(tdt)
+    wl = rnd("ln.w", (N, K), 0.02).to(tdt)
+    sc, sh = rnd("ln.sc", (N,), 0.2) + 1, rnd("ln.sh", (N,), 0.2)
+    ref = torch.tanh(F.silu(a.float() @ wl.float().T) * sc + sh) * 0.5
+    out = run_gemm(lib, a.to(DEV), wl.to(DEV), (M, N), ldt, ldt, L.F32, 0, M=M, N=N, Cin=K, lda=K, ldc=N, act=2,
+                   scale=sc.to(DEV), shift=sh.to(DEV), act2=5, alpha=0.5)
+    assert relerr(out, ref) < (5e-5 if dt == "f32" else 2e-2)
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+def test_attention(lib, dt):
+    tdt = torch.float32 if dt == "f32" else torch.bfloat16
+    ldt = L.F32 if dt == "f32" else L.BF16
+    B, H, S, dh = 2, 3, 150, 64
+    D = H * dh
+    qkv = rnd("at.qkv", (B, S, 3 * D)).to(tdt)
+    kvs = torch.tensor([0, 7], dtype=torch.int32)
+    q, k, v = [t.float().view(B, S, H, dh).transpose(1, 2) for t in qkv.split(D, dim=2)]
+    att = (q @ k.transpose(-1, -2)) / 8.0
+    mask = torch.tril(torch.ones(S, S, dtype=torch.bool))[None, None].expand(B, 1, S, S).clone()
+    mask[1, :, :, :7] = False
+    att = att.masked_fill(~mask, float("-inf"))
+    ref = (torch.softmax(att, -1).nan_to_num(0.0) @ v).transpose(1, 2).reshape(B, S, D)
+    x = qkv.to(DEV)
+    kvd = kvs.to(DEV)
+    o = torch.empty(B, S, D, dtype=tdt, device=DEV)
+    es = x.element_size()
+    L.check(lib.itts_attention(o.data_ptr(), x.data_ptr(), x.data_ptr() + D * es, x.data_ptr() + 2 * D * es, B, H, S, S,
+                               dh, dh, 3 * D, 3 * D, 3 * D, D, 0.125, 1, kvd.data_ptr(), ldt, stream()))
+    torch.cuda.synchronize()
+    # rows that are themselves padding (query < kv_start) are don't-care
+    assert relerr(o.float()[0], ref[0]) < (2e-5 if dt == "f32" else 2e-2)
+    assert relerr(o.float()[1, 7:], ref[1, 7:]) < (2e-5 if dt == "f32" else 2e-2)
