@@ -1,0 +1,250 @@
+#!/usr/bin/env python3
+"""Headline benchmark: audio-seconds per second of the IndexTTS-1.5 hot path on MI355X.
+
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 it is launched under
+torch.distributed.run with one rank per GPU.  One "step" = one pass of the whole hot path over one batch
+of synthetic utterances per GPU: conditioning (conformer+perceiver) + ECAPA once per
+utterance, greedy AR decode with KV cache (all sentences of the utterance as one batch, fixed length,
+eos suppressed), latent pass per sentence, BigVGAN, int16 waveform copied to the host (infer.py:208-212).
+Inputs (prompt mel, weights) are resident in HBM before the timed region.  Utterances shard over ranks with
+no collective on the data path (weights are replicated once by an RCCL broadcast before timing).
+
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "index-tts-ipex_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable copy)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=1, help="utterances per GPU per step (config 2: 1, config 3: 32)")
+    ap.add_argument("--sentences", type=int, default=2, help="sentences per utterance (200-char zh = 2 x L105)")
+    ap.add_argument("--text-tokens", type=int, default=105)
+    ap.add_argument("--mel-tokens", type=int, default=480)
+    ap.add_argument("--prompt-frames", type=int, default=511)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--micro", action="store_true", help="tiny config (plumbing check)")
+    return ap.parse_args()
+
+
+def build_engine_dp(cfg, dtype, device, rank, world):
+    """Rank 0 materialises + packs the synthetic checkpoint; other ranks receive the packed arena by an RCCL
+    broadcast over xGMI (one-off, outside the timed region)."""
+    from itts_hip import engine as ieng
+    from itts_hip import pack, synth
+
+    eng = ieng.Engine(cfg, dtype, device, max_batch=128)
+    if world == 1:
+        eng.load_packed(pack.pack_gpt(synth.gpt_state_dict(cfg, 1234), cfg))
+        eng.load_packed(pack.pack_bigvgan(synth.bigvgan_state_dict(cfg, 1234), cfg))
+        eng.finalize()
+        return eng
+    import torch.distributed as dist
+
+    for part in ("gpt", "bigvgan"):
+        if rank == 0:
+            packed = (pack.pack_gpt(synth.gpt_state_dict(cfg, 1234), cfg) if part == "gpt"
+                      else pack.pack_bigvgan(synth.bigvgan_state_dict(cfg, 1234), cfg))
+            arena = ieng.WeightArena(packed, eng.dt, eng.device)
+            meta = [arena.manifest, arena.nbytes]
+        else:
+            arena, meta = None, [None, None]
+        dist.broadcast_object_list(meta, src=0)
+        if rank != 0:
+            arena = ieng.WeightArena.__new__(ieng.WeightArena)
+            arena.dtype, arena.manifest, arena.nbytes = eng.dt, meta[0], meta[1]
+            arena.buf = torch.empty(meta[1], dtype=torch.uint8, device=eng.device)
+        dist.broadcast(arena.buf, src=0)
+        eng.load_packed(None, arena=arena)
+    eng.finalize()
+    return eng
+
+
+def cpu_baseline(cfg, a):
+    """Oracle (CPU port of the reference path, torch fp32, all host cores) on a bounded sample of the same
+    workload; extrapolated per phase to one L/T sentence.  Reported next to the GPU number, never the target."""
+    from itts_hip import synth
+    from oracle import gpt as ogpt
+    from oracle import vocoder as ovoc
+    from itts_hip.config import ecapa_dims
+
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    g = cfg["gpt"]
+    wg = ogpt.to_torch(synth.gpt_state_dict(cfg, 1234))
+    wb = ogpt.to_torch(synth.bigvgan_state_dict(cfg, 1234))
+    mel = torch.from_numpy(synth.prompt_mel(a.prompt_frames, seed=7))
+    L, T = a.text_tokens, a.mel_tokens
+    text = torch.from_numpy(synth.text_ids(L, 11, g["number_text_tokens"])).view(1, L)
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        cond = ogpt.get_conditioning(mel, wg, g)
+        t_cond = time.perf_counter() - t0
+        nsamp = 24
+        t0 = time.perf_counter()
+        codes = ogpt.greedy_generate(cond, text, wg, g, nsamp, suppress_eos=True)
+        t_gen = time.perf_counter() - t0
+        # prefill alone, to separate it from the per-token cost
+        t0 = time.perf_counter()
+        ogpt.greedy_generate(cond, text, wg, g, 1, suppress_eos=True)
+        t_prefill = time.perf_counter() - t0
+        t_tok = (t_gen - t_prefill) / (nsamp - 1)
+        full_codes = torch.from_numpy(synth.text_ids(T, 5, g["stop_mel_token"] - 1)).view(1, T)
+        t0 = time.perf_counter()
+        lat = ogpt.latent_forward(cond, text, full_codes, wg, g)
+        t_lat = time.perf_counter() - t0
+        nfr = 16
+        t0 = time.perf_counter()
+        ovoc.bigvgan_forward(lat[:, :nfr], mel.transpose(1, 2), wb, cfg["bigvgan"], ecapa_dims(cfg["bigvgan"]))
+        t_voc = time.perf_counter() - t0
+    # reference recomputes conditioning twice per sentence (model.py:540,670)
+    per_sentence = 2 * t_cond + t_prefill + (T - 1) * t_tok + t_lat + t_voc * (T / nfr)
+    audio = T * 1024 / 24000.0
+    return {
+        "value": round(audio / per_sentence, 4), "unit": "audio_sec_per_sec", "cores": cores, "kind": "port",
+        "sample": (f"oracle (torch fp32, {cores} threads): conditioning {t_cond:.2f}s x2, prefill s={32 + L + 2} {t_prefill:.2f}s, "
+                   f"{nsamp} greedy steps -> {t_tok * 1e3:.1f} ms/token extrapolated to T={T}, latent pass T={T} {t_lat:.2f}s, "
+                   f"BigVGAN+ECAPA on {nfr} frames {t_voc:.2f}s scaled x{T / nfr:.0f}"),
+    }
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
+    from itts_hip import config as icfg
+    from itts_hip import synth
+
+    cfg = icfg.micro() if a.micro else icfg.indextts_1_5()
+    if a.micro:
+        a.text_tokens, a.mel_tokens, a.prompt_frames = 11, 24, 61
+    g = cfg["gpt"]
+    device = f"cuda:{local}"
+    eng = build_engine_dp(cfg, a.dtype, device, rank, world)
+    from itts_hip.infer_core import remove_long_silence
+
+    L, T, NS, BU = a.text_tokens, a.mel_tokens, a.sentences, a.batch
+    B = BU * NS
+    mel = torch.from_numpy(synth.prompt_mel(a.prompt_frames, seed=7)).to(device)  # resident in HBM
+    texts = np.stack([synth.text_ids(L, 11 + rank * 1000 + i, g["number_text_tokens"]) for i in range(B)]).astype(np.int32)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    dec_ms, dec_steps = [0.0], [0]
+
+    def step(timed: bool):
+        cond = eng.conditioning(mel)
+        spk = eng.ecapa(mel.transpose(1, 2))
+        eng.prefill(cond, texts, T, 10.0, True)
+        if timed:
+            ev[0].record(eng.stream)
+        eng.decode(T - 1)
+        if timed:
+            ev[1].record(eng.stream)
+        codes = eng.fetch()
+        eng._exit()
+        if timed:
+            dec_ms[0] += ev[0].elapsed_time(ev[1])
+            dec_steps[0] += T - 1
+        lats = []
+        for i in range(B):
+            c, n = remove_long_silence(codes[i:i + 1].astype(np.int64), g["stop_mel_token"])
+            lats.append(eng.latent(cond, texts[i], c[0, :int(n[0])]))
+        nsamp = 0
+        outs = []
+        if all(l.shape[1] == lats[0].shape[1] for l in lats):
+            wav = eng.bigvgan(torch.cat(lats, 0), spk.expand(B, -1).contiguous())
+            outs.append(wav)
+        else:
+            for l in lats:
+                outs.append(eng.bigvgan(l, spk))
+        host = [torch.clamp(32767 * w, -32767.0, 32767.0).to(torch.int16).cpu() for w in outs]
+        for w in host:
+            nsamp += w.numel()
+        return nsamp
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if world > 1:
+            import torch.distributed as dist
+
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step(False)
+    sync_all()
+    t0 = time.perf_counter()
+    samples = 0
+    for _ in range(a.steps):
+        samples += step(True)
+    sync_all()
+    dt = time.perf_counter() - t0
+    tot = torch.tensor([dt, float(samples)], dtype=torch.float64, device=device)
+    if world > 1:
+        import torch.distributed as dist
+
+        tmax = tot.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        dt = float(tmax[0])
+        samples = float(tot[1])
+    audio_s = samples / 24000.0
+    if rank != 0:
+        return
+    # ---- roofline of the dominant kernel group: the per-token decode step ----
+    D, NL, V = g["model_dim"], g["layers"], g["number_mel_codes"]
+    esz = 2 if a.dtype == "bf16" else 4
+    w_params = NL * (12 * D * D + 13 * D) + 4 * D + D * V + V
+    s_bar = (32 + L + 2 + 1) + T / 2.0
+    kv_per_pos = 2 * NL * D * esz
+    step_bytes = w_params * esz + B * kv_per_pos * s_bar
+    ms_step = dec_ms[0] / max(dec_steps[0], 1)
+    achieved = step_bytes / (ms_step * 1e-3) / 1e9
+    out = {
+        "metric": "audio_sec_per_sec", "value": round(audio_s / dt, 3), "unit": "audio-s/s", "n_gpus": world,
+        "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 2), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
+        "rtf": round(dt / audio_s, 5),
+        "config": {"workload": ("IndexTTS-1.5, %d utterance(s)/GPU x %d sentences x (L=%d text tokens, T=%d mel codes), "
+                                "prompt %d frames, greedy fixed-length decode, rep_penalty 10" % (BU, NS, L, T, a.prompt_frames)),
+                   "utterances_per_gpu": BU, "decode_batch": B, "audio_sec_per_step_per_gpu": round(audio_s / a.steps / world, 3)},
+        "roofline": {"bound": "hbm", "kernel": "gpt decode step (hipGraph: 97 gemv + 24 cache-attention + sampler)",
+                     "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                     "algorithmic_bytes_per_launch": int(step_bytes), "avg_launch_ms": round(ms_step, 4),
+                     "decode_tokens_per_s": round(B * 1e3 / ms_step, 1)},
+    }
+    if not a.no_cpu_baseline and world == 1:
+        out["cpu_baseline"] = cpu_baseline(cfg, a)
+    print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()

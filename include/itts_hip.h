@@ -59,6 +59,13 @@ int itts_attention(void* o, const void* q, const void* k, const void* v, int B, 
                    int ldq, int ldk, int ldv, int ldo, float scale, int causal, const int* kv_start, int dtype,
                    itts_stream stream);
 
+/* Decode-step batched GEMV (GPT2 Conv1D on one token per row, HF GPT2Attention/GPT2MLP):
+ * Y[b, n] (+)= act(prologue(X)[b, :] . W[n, :] + bias[n]); X, Y fp32; prologue 0 none, 1 LayerNorm, 2 LN o LN.
+ * version 0 = auto, 1 = generic kernel, 2 = register-resident kernel (B <= 4). */
+int itts_gemv(float* Y, const float* X, const void* W, const float* bias, int B, int N, int K, int act, int accumulate,
+              int prologue, const float* ln_gamma, const float* ln_beta, const float* ln2_gamma, const float* ln2_beta,
+              int dtype_w, int version, itts_stream stream);
+
 int itts_transpose(void* y, const void* x, int B, int R, int C, int dtype, itts_stream stream);
 
 /* ---- engine level ----------------------------------------------------------------------------------- */

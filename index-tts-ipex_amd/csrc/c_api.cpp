@@ -65,6 +65,17 @@ int itts_attention(void* o, const void* q, const void* k, const void* v, int B, 
   return attention_simple(a, dtype, (hipStream_t)stream);
 }
 
+int itts_gemv(float* Y, const float* X, const void* W, const float* bias, int B, int N, int K, int act, int accumulate,
+              int prologue, const float* ln_gamma, const float* ln_beta, const float* ln2_gamma, const float* ln2_beta,
+              int dtype_w, int version, itts_stream stream) {
+  (void)hipGetLastError();
+  GemvArgs g;
+  g.X = X; g.W = W; g.Y = Y; g.bias = bias; g.B = B; g.N = N; g.K = K; g.ldy = N; g.act = act; g.accumulate = accumulate;
+  g.prologue = prologue; g.ln_gamma = ln_gamma; g.ln_beta = ln_beta; g.ln2_gamma = ln2_gamma; g.ln2_beta = ln2_beta;
+  if (version == 2 || (version == 0 && gemv2_supported(g))) return gemv2(g, dtype_w, (hipStream_t)stream);
+  return gemv(g, dtype_w, (hipStream_t)stream);
+}
+
 int itts_transpose(void* y, const void* x, int B, int R, int C, int dtype, itts_stream stream) {
   (void)hipGetLastError();  // drop stale errors left by other HIP users (torch)
   return transpose_brc(y, x, B, R, C, dtype, (hipStream_t)stream);

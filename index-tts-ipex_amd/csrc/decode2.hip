@@ -1,0 +1,754 @@
+// Decode-step kernels, second generation (the per-token loop is launch/latency bound at B <= 8:
+// SURVEY.md 8d, MI355X_MICROARCH "launches-baseline"), so each kernel here is built to
+//   * touch every weight byte exactly once with 16-byte lane loads that are ALL issued before the first use
+//     (deep memory-level parallelism, no LDS round trip for streamed weights - cdna_hip_programming "GEMV" row),
+//   * keep the tiny activation vectors in LDS (fused LayerNorm / ln_f+final_norm / split-KV combine prologues),
+//   * spread over >= 256 workgroups so every CU pulls on HBM.
+#include "itts_decode.h"
+
+namespace itts {
+namespace {
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// weights are read exactly once per step: non-temporal 16-byte loads (MI355X_MICROARCH "nt-weights")
+template <typename TW> struct V8;
+template <> struct V8<bf16_t> {
+  u32x4 raw;
+  __device__ __forceinline__ void load(const bf16_t* p) { raw = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p)); }
+  __device__ __forceinline__ float get(int i) const {
+    const uint32_t w = raw[i >> 1];
+    return __uint_as_float((i & 1) ? (w & 0xFFFF0000u) : (w << 16));
+  }
+};
+template <> struct V8<float> {
+  f32x4 a, b;
+  __device__ __forceinline__ void load(const float* p) {
+    a = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
+    b = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p + 4));
+  }
+  __device__ __forceinline__ float get(int i) const { return i < 4 ? a[i] : b[i - 4]; }
+};
+
+// ---------------------------------------------------------------------------------------------
+// gemv2: Y[b, n] (+)= act( prologue(X)[b, :] . W[n, :] + bias[n] )
+//   prologue: 0 plain, 1 LayerNorm, 2 LayerNorm o LayerNorm (ln_f then final_norm)
+// block = 4 waves; wave w owns RPW rows; each lane holds RPW x NCH 16-byte weight fragments in registers.
+// Single-latency structure: the weight fragments, the activation rows, gamma and beta are all requested
+// before anything is consumed; LayerNorm statistics are one shifted-moment pass (pivot = x[0]) reduced
+// with ONE barrier; the normalised rows go to LDS for the dot-product phase.
+// ---------------------------------------------------------------------------------------------
+template <int NB>
+struct RowStats {
+  float mean[NB], rstd[NB];
+};
+
+// sum[b], sq[b] (shifted moments of this thread's elements) -> per-row mean / rstd, one barrier
+template <int NB>
+__device__ __forceinline__ RowStats<NB> reduce_stats(const float (&sum)[NB], const float (&sq)[NB],
+                                                     const float (&pivot)[NB], int K, float eps,
+                                                     float (*red)[2 * NB], int lane, int wave) {
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    const float s = wave_sum(sum[b]), q = wave_sum(sq[b]);
+    if (lane == 0) {
+      red[wave][2 * b] = s;
+      red[wave][2 * b + 1] = q;
+    }
+  }
+  __syncthreads();
+  RowStats<NB> st;
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    const float s = red[0][2 * b] + red[1][2 * b] + red[2][2 * b] + red[3][2 * b];
+    const float q = red[0][2 * b + 1] + red[1][2 * b + 1] + red[2][2 * b + 1] + red[3][2 * b + 1];
+    const float md = s / K;
+    st.mean[b] = pivot[b] + md;
+    st.rstd[b] = rsqrtf(fmaxf(q / K - md * md, 0.f) + eps);
+  }
+  return st;
+}
+
+template <typename TW, int NB, int RPW, int NCH>
+__global__ __launch_bounds__(256) void gemv2_kernel(GemvArgs g) {
+  constexpr int XCH = (NB * NCH + 1) / 2;  // float4 chunks of X per thread (NB*K <= NB*512*NCH floats)
+  extern __shared__ __attribute__((aligned(16))) float sx[];  // [NB][K]
+  __shared__ float red[2][4][2 * NB];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int K = g.K, B = g.B, BK = B * K;
+  const TW* __restrict__ W = (const TW*)g.W;
+  const int n0 = (blockIdx.x * 4 + wave) * RPW;
+  // 1. request everything: weight fragments, activation rows, LayerNorm parameters, pivots
+  V8<TW> w[RPW][NCH];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int k = c * 512 + lane * 8;
+    if (k < K) {
+#pragma unroll
+      for (int r = 0; r < RPW; ++r) {
+        const int n = min(n0 + r, g.N - 1);
+        w[r][c].load(W + (size_t)n * K + k);
+      }
+    }
+  }
+  float4 x[XCH], gm[XCH], bt[XCH], gm2[XCH], bt2[XCH];
+  const bool ln = g.prologue >= 1, ln2 = g.prologue == 2;
+#pragma unroll
+  for (int j = 0; j < XCH; ++j) {
+    const int i = tid * 4 + j * 1024;
+    if (i < BK) {
+      x[j] = *reinterpret_cast<const float4*>(g.X + i);
+      const int col = i % K;
+      if (ln) {
+        gm[j] = *reinterpret_cast<const float4*>(g.ln_gamma + col);
+        bt[j] = *reinterpret_cast<const float4*>(g.ln_beta + col);
+      }
+      if (ln2) {
+        gm2[j] = *reinterpret_cast<const float4*>(g.ln2_gamma + col);
+        bt2[j] = *reinterpret_cast<const float4*>(g.ln2_beta + col);
+      }
+    }
+  }
+  float pivot[NB];
+#pragma unroll
+  for (int b = 0; b < NB; ++b) pivot[b] = (ln && b < B) ? g.X[(size_t)b * K] : 0.f;
+  // 2. LayerNorm(s) in registers, result to LDS
+  for (int pass = 0; pass < 2; ++pass) {
+    if (pass == 0 ? !ln : !ln2) break;
+    float sum[NB], sq[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) sum[b] = sq[b] = 0.f;
+    if (pass == 1) {
+#pragma unroll
+      for (int b = 0; b < NB; ++b) pivot[b] = 0.f;  // LayerNorm output: mean ~ beta, well conditioned
+    }
+#pragma unroll
+    for (int j = 0; j < XCH; ++j) {
+      const int i = tid * 4 + j * 1024;
+      if (i < BK) {
+        const int b = i / K;
+        const float v[4] = {x[j].x, x[j].y, x[j].z, x[j].w};
+#pragma unroll
+        for (int bb = 0; bb < NB; ++bb)
+          if (bb == b) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float d = v[e] - pivot[bb];
+              sum[bb] += d;
+              sq[bb] = fmaf(d, d, sq[bb]);
+            }
+          }
+      }
+    }
+    const RowStats<NB> st = reduce_stats<NB>(sum, sq, pivot, K, g.ln_eps, red[pass], lane, wave);
+#pragma unroll
+    for (int j = 0; j < XCH; ++j) {
+      const int i = tid * 4 + j * 1024;
+      if (i < BK) {
+        const int b = i / K;
+        float m = 0.f, r = 1.f;
+#pragma unroll
+        for (int bb = 0; bb < NB; ++bb)
+          if (bb == b) {
+            m = st.mean[bb];
+            r = st.rstd[bb];
+          }
+        const float4 G = pass ? gm2[j] : gm[j], Bt = pass ? bt2[j] : bt[j];
+        x[j].x = (x[j].x - m) * r * G.x + Bt.x;
+        x[j].y = (x[j].y - m) * r * G.y + Bt.y;
+        x[j].z = (x[j].z - m) * r * G.z + Bt.z;
+        x[j].w = (x[j].w - m) * r * G.w + Bt.w;
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < XCH; ++j) {
+    const int i = tid * 4 + j * 1024;
+    if (i < BK) *reinterpret_cast<float4*>(sx + i) = x[j];
+  }
+  __syncthreads();
+  if (n0 >= g.N) return;
+  // 3. dot products
+  float acc[RPW][NB];
+#pragma unroll
+  for (int r = 0; r < RPW; ++r)
+#pragma unroll
+    for (int b = 0; b < NB; ++b) acc[r][b] = 0.f;
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int k = c * 512 + lane * 8;
+    if (k < K) {
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        if (b >= B) break;
+        const float4 x0 = *reinterpret_cast<const float4*>(sx + b * K + k);
+        const float4 x1 = *reinterpret_cast<const float4*>(sx + b * K + k + 4);
+        const float xv[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+#pragma unroll
+        for (int r = 0; r < RPW; ++r)
+#pragma unroll
+          for (int i = 0; i < 8; ++i) acc[r][b] = fmaf(xv[i], w[r][c].get(i), acc[r][b]);
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < RPW; ++r)
+#pragma unroll
+    for (int b = 0; b < NB; ++b) acc[r][b] = wave_sum(acc[r][b]);
+  if (lane == 0) {
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+      const int n = n0 + r;
+      if (n >= g.N) continue;
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        if (b >= B) break;
+        float v = acc[r][b] + (g.bias ? g.bias[n] : 0.f);
+        v = act_apply(g.act, v);
+        float* y = g.Y + (size_t)b * g.ldy + n;
+        *y = g.accumulate ? (*y + v) : v;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// gemv_bf16: the throughput-path GEMV (bf16 weights).  Same contract as gemv2, built from the measured
+// anatomy of these 3-10 us kernels (tools/ubench_gemv.hip; DESIGN.md "decode GEMV"):
+//   * branch-free: every load has a clamped address and is unconditional, so hipcc's in-order vmcnt
+//     bookkeeping is exact - the activations (requested FIRST) are consumed while the weight fragments
+//     (requested second) are still streaming;
+//   * LayerNorm statistics with DPP row reductions (4 DPP + 2 bpermute instead of 6 bpermute);
+//   * activations are kept in LDS as bf16 pairs and multiplied with v_dot2c_f32_bf16: 4 VALU ops per
+//     16-byte weight fragment instead of 8 cvt + 8 fma (the kernels are short enough to be issue-bound);
+//   * the output can be written as bf16 (gelu(fc) feeding proj2) to halve the next kernel's LDS fill.
+// ---------------------------------------------------------------------------------------------
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float v) {
+  return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+  v = dpp_add<0xB1>(v);   // quad_perm [1,0,3,2]
+  v = dpp_add<0x4E>(v);   // quad_perm [2,3,0,1]
+  v = dpp_add<0x141>(v);  // row_half_mirror
+  v = dpp_add<0x140>(v);  // row_mirror: every lane now holds the sum of its 16-lane row
+  v += __shfl_xor(v, 16, 64);
+  v += __shfl_xor(v, 32, 64);
+  return v;
+}
+__device__ __forceinline__ uint32_t pack_bf16(float a, float b) {
+  bf16x2_t v = {(bf16_t)a, (bf16_t)b};
+  return __builtin_bit_cast(uint32_t, v);
+}
+__device__ __forceinline__ float dot2(uint32_t a, uint32_t b, float c) {
+  return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, a), __builtin_bit_cast(bf16x2_t, b), c, false);
+}
+
+// PRO: 0 plain, 1 LayerNorm, 2 LayerNorm o LayerNorm.  XBF: X is bf16 [B, K] (else fp32).  YBF: Y is bf16.
+template <int NB, int RPW, int NCH, int PRO, bool XBF, bool YBF>
+__global__ __launch_bounds__(256) void gemv_bf16_kernel(GemvArgs g) {
+  constexpr int XCH = XBF ? (NB * NCH * 512 + 2047) / 2048 : (NB * NCH * 512 + 1023) / 1024;  // 16-byte chunks / thread
+  extern __shared__ __attribute__((aligned(16))) uint32_t sxb[];  // [NB][K/2] bf16 pairs
+  __shared__ float red[2][4][2 * NB];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int K = g.K, BK = NB * K;
+  const int n0 = (blockIdx.x * 4 + wave) * RPW;
+  // ---- 1. activations (+ LayerNorm parameters) first, weights second; all unconditional ----
+  u32x4 xr[XCH];           // XBF: 8 bf16; else 4 floats
+  f32x4 gm[PRO >= 1 ? XCH : 1], bt[PRO >= 1 ? XCH : 1], gm2[PRO == 2 ? XCH : 1], bt2[PRO == 2 ? XCH : 1];
+  int xb[XCH];
+  bool xok[XCH];
+  constexpr int EPC = XBF ? 8 : 4;  // elements per chunk
+#pragma unroll
+  for (int j = 0; j < XCH; ++j) {
+    const int i = (tid + j * 256) * EPC;
+    xok[j] = i < BK;
+    const int ic = xok[j] ? i : BK - EPC;
+    xb[j] = ic / K;
+    if (XBF) xr[j] = *reinterpret_cast<const u32x4*>((const bf16_t*)g.X + ic);
+    else xr[j] = *reinterpret_cast<const u32x4*>(g.X + ic);
+    if (PRO >= 1) {
+      const int col = ic - xb[j] * K;
+      gm[j] = *reinterpret_cast<const f32x4*>(g.ln_gamma + col);
+      bt[j] = *reinterpret_cast<const f32x4*>(g.ln_beta + col);
+      if (PRO == 2) {
+        gm2[j] = *reinterpret_cast<const f32x4*>(g.ln2_gamma + col);
+        bt2[j] = *reinterpret_cast<const f32x4*>(g.ln2_beta + col);
+      }
+    }
+  }
+  float pivot[NB];
+#pragma unroll
+  for (int b = 0; b < NB; ++b) pivot[b] = PRO >= 1 ? g.X[(size_t)b * K] : 0.f;
+  const bf16_t* __restrict__ W = (const bf16_t*)g.W;
+  u32x4 w[RPW][NCH];
+  const int klast = (NCH - 1) * 512 + lane * 8;
+  const bool kok = klast < K;
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int k = c == NCH - 1 ? (kok ? klast : K - 8) : c * 512 + lane * 8;
+#pragma unroll
+    for (int r = 0; r < RPW; ++r)
+      w[r][c] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(W + (size_t)min(n0 + r, g.N - 1) * K + k));
+  }
+  // ---- 2. LayerNorm(s) in registers (one barrier each), bf16 pairs to LDS ----
+  if (!XBF) {
+    float xv[XCH][4];
+#pragma unroll
+    for (int j = 0; j < XCH; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) xv[j][e] = __uint_as_float(xr[j][e]);
+#pragma unroll
+    for (int pass = 0; pass < PRO; ++pass) {
+      float s[NB], q[NB];
+#pragma unroll
+      for (int b = 0; b < NB; ++b) s[b] = q[b] = 0.f;
+#pragma unroll
+      for (int j = 0; j < XCH; ++j)
+#pragma unroll
+        for (int bb = 0; bb < NB; ++bb) {
+          const bool m = xok[j] && xb[j] == bb;
+          const float pv = pass == 0 ? pivot[bb] : 0.f;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float d = m ? xv[j][e] - pv : 0.f;
+            s[bb] += d;
+            q[bb] = fmaf(d, d, q[bb]);
+          }
+        }
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        s[b] = wave_sum_dpp(s[b]);
+        q[b] = wave_sum_dpp(q[b]);
+      }
+      if (lane == 0)
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+          red[pass][wave][2 * b] = s[b];
+          red[pass][wave][2 * b + 1] = q[b];
+        }
+      __syncthreads();
+      float mean[NB], rstd[NB];
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        const float S = red[pass][0][2 * b] + red[pass][1][2 * b] + red[pass][2][2 * b] + red[pass][3][2 * b];
+        const float Q = red[pass][0][2 * b + 1] + red[pass][1][2 * b + 1] + red[pass][2][2 * b + 1] + red[pass][3][2 * b + 1];
+        const float md = S / K;
+        mean[b] = (pass == 0 ? pivot[b] : 0.f) + md;
+        rstd[b] = rsqrtf(fmaxf(Q / K - md * md, 0.f) + g.ln_eps);
+      }
+#pragma unroll
+      for (int j = 0; j < XCH; ++j) {
+        float m = mean[0], r = rstd[0];
+#pragma unroll
+        for (int bb = 1; bb < NB; ++bb) {
+          m = xb[j] == bb ? mean[bb] : m;
+          r = xb[j] == bb ? rstd[bb] : r;
+        }
+        const f32x4 G = pass ? gm2[j] : gm[j], Bt = pass ? bt2[j] : bt[j];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) xv[j][e] = (xv[j][e] - m) * r * G[e] + Bt[e];
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < XCH; ++j)
+      if (xok[j]) {
+        const int i = (tid + j * 256) * 4;
+        uint2 p;
+        p.x = pack_bf16(xv[j][0], xv[j][1]);
+        p.y = pack_bf16(xv[j][2], xv[j][3]);
+        *reinterpret_cast<uint2*>(sxb + i / 2) = p;
+      }
+  } else {
+#pragma unroll
+    for (int j = 0; j < XCH; ++j)
+      if (xok[j]) *reinterpret_cast<u32x4*>(sxb + (tid + j * 256) * 4) = xr[j];
+  }
+  __syncthreads();
+  // ---- 3. dot products: 4 x v_dot2c per weight fragment and batch row ----
+  float acc[RPW][NB];
+#pragma unroll
+  for (int r = 0; r < RPW; ++r)
+#pragma unroll
+    for (int b = 0; b < NB; ++b) acc[r][b] = 0.f;
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int k = c == NCH - 1 ? (kok ? klast : K - 8) : c * 512 + lane * 8;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      u32x4 xq = *reinterpret_cast<const u32x4*>(sxb + (b * K + k) / 2);
+      if (c == NCH - 1)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) xq[e] = kok ? xq[e] : 0u;
+#pragma unroll
+      for (int r = 0; r < RPW; ++r)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[r][b] = dot2(w[r][c][e], xq[e], acc[r][b]);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < RPW; ++r)
+#pragma unroll
+    for (int b = 0; b < NB; ++b) acc[r][b] = wave_sum_dpp(acc[r][b]);
+  if (lane == 0) {
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+      const int n = n0 + r;
+      if (n < g.N) {
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+          if (b < g.B) {
+            float v = acc[r][b] + (g.bias ? g.bias[n] : 0.f);
+            v = act_apply(g.act, v);
+            if (YBF) {
+              ((bf16_t*)g.Y)[(size_t)b * g.ldy + n] = (bf16_t)v;
+            } else {
+              float* y = g.Y + (size_t)b * g.ldy + n;
+              *y = g.accumulate ? (*y + v) : v;
+            }
+          }
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// decode_attn2: single-query attention over the KV cache with this step's K/V append fused in.
+// One 1024-thread workgroup per (head, row).  LPK lanes share one key row with 16-byte loads (a wave reads
+// 1 KiB of contiguous K and 1 KiB of V per step); every key slot runs an online softmax (running max, sum,
+// partial context) so K and V are read in ONE pass with both loads of a step in flight together; slots are
+// merged with max-rescaling through shuffles and LDS.  Output type TO: fp32 or bf16 (feeds the proj GEMV).
+// ---------------------------------------------------------------------------------------------
+template <typename TC> struct CacheVec;
+template <> struct CacheVec<bf16_t> {
+  static constexpr int VEC = 8, LPK = 8;
+  uint4 raw;
+  __device__ __forceinline__ void load(const bf16_t* p) { raw = *reinterpret_cast<const uint4*>(p); }
+  __device__ __forceinline__ float get(int i) const {
+    const uint32_t w = (&raw.x)[i >> 1];
+    return __uint_as_float((i & 1) ? (w & 0xFFFF0000u) : (w << 16));
+  }
+};
+template <> struct CacheVec<float> {
+  static constexpr int VEC = 4, LPK = 16;
+  float4 raw;
+  __device__ __forceinline__ void load(const float* p) { raw = *reinterpret_cast<const float4*>(p); }
+  __device__ __forceinline__ float get(int i) const { return (&raw.x)[i]; }
+};
+
+template <typename TC, typename TO>
+__global__ __launch_bounds__(1024) void decode_attn2_kernel(TO* __restrict__ ctx, const float* __restrict__ qkv,
+                                                            TC* __restrict__ kc, TC* __restrict__ vc,
+                                                            const int* __restrict__ len, const int* __restrict__ kv_start,
+                                                            const int* __restrict__ prefix, int H, int Smax, float scale) {
+  constexpr int DH = 64, VEC = CacheVec<TC>::VEC, LPK = CacheVec<TC>::LPK, NT = 1024, NW = NT / 64, SLOTS = NT / LPK;
+  __shared__ float sq[DH];
+  __shared__ float sm[NW], sl[NW];
+  __shared__ float so[NW][DH];
+  const int h = blockIdx.x, b = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int D = H * DH;
+  const int pos = prefix[0] + len[b];
+  const int S = pos + 1;
+  TC* kb = kc + ((size_t)b * H + h) * Smax * DH;
+  TC* vb = vc + ((size_t)b * H + h) * Smax * DH;
+  const float* qv = qkv + (size_t)b * 3 * D + h * DH;
+  if (tid < DH) {
+    sq[tid] = qv[tid] * scale;
+    stf(kb + (size_t)pos * DH + tid, qv[D + tid]);
+    stf(vb + (size_t)pos * DH + tid, qv[2 * D + tid]);
+  }
+  __syncthreads();
+  const int ks = kv_start[b];
+  const int slot = tid / LPK, sub = tid % LPK;
+  float qr[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) qr[i] = sq[sub * VEC + i];
+  float m = -INFINITY, l = 0.f, acc[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
+  for (int jb = 0; jb < S; jb += 2 * SLOTS) {
+    // two keys per iteration: all four 16-byte loads are requested before the first use
+    const int ja = jb + slot, jc = jb + SLOTS + slot;
+    const int jal = min(ja, S - 1), jcl = min(jc, S - 1);  // clamped: loads are unconditional
+    CacheVec<TC> ka, va, kc2, vc2;
+    ka.load(kb + (size_t)jal * DH + sub * VEC);
+    va.load(vb + (size_t)jal * DH + sub * VEC);
+    kc2.load(kb + (size_t)jcl * DH + sub * VEC);
+    vc2.load(vb + (size_t)jcl * DH + sub * VEC);
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int j = u ? jc : ja;
+      const CacheVec<TC>& kk = u ? kc2 : ka;
+      const CacheVec<TC>& vv = u ? vc2 : va;
+      const bool own = j == pos;  // the row appended this step: take it from qkv with the cache's rounding
+      float sc = 0.f;
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) {
+        const float kval = own ? (float)(TC)qv[D + sub * VEC + i] : kk.get(i);
+        sc = fmaf(qr[i], kval, sc);
+      }
+#pragma unroll
+      for (int o = 1; o < LPK; o <<= 1) sc += __shfl_xor(sc, o, 64);
+      const bool ok = j < S && j >= ks;
+      sc = ok ? sc : -INFINITY;
+      const float mn = fmaxf(m, sc);
+      const float corr = mn > -INFINITY ? __expf(m - mn) : 1.f;  // m = -inf -> exp(-inf) = 0 (acc, l are 0 anyway)
+      const float p = ok ? __expf(sc - mn) : 0.f;
+      l = l * corr + p;
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) {
+        const float vval = own ? (float)(TC)qv[2 * D + sub * VEC + i] : vv.get(i);
+        acc[i] = fmaf(p, vval, acc[i] * corr);
+      }
+      m = mn;
+    }
+  }
+  // merge the 64/LPK key slots of this wave (lanes with equal `sub`)
+  float M = m;
+#pragma unroll
+  for (int o = LPK; o < 64; o <<= 1) M = fmaxf(M, __shfl_xor(M, o, 64));
+  const float sc0 = M > -INFINITY ? __expf(m - M) : 0.f;
+  l *= sc0;
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) acc[i] *= sc0;
+#pragma unroll
+  for (int o = LPK; o < 64; o <<= 1) {
+    l += __shfl_xor(l, o, 64);
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) acc[i] += __shfl_xor(acc[i], o, 64);
+  }
+  if (lane < LPK)
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) so[wave][lane * VEC + i] = acc[i];
+  if (lane == 0) {
+    sm[wave] = M;
+    sl[wave] = l;
+  }
+  __syncthreads();
+  if (tid < DH) {
+    float MM = sm[0];
+#pragma unroll
+    for (int i = 1; i < NW; ++i) MM = fmaxf(MM, sm[i]);
+    float o = 0.f, L = 0.f;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) {
+      const float e = sm[i] > -INFINITY ? __expf(sm[i] - MM) : 0.f;
+      o = fmaf(e, so[i][tid], o);
+      L = fmaf(e, sl[i], L);
+    }
+    stf(ctx + (size_t)b * D + h * DH + tid, o / L);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// sampler2: repetition penalty + argmax + bookkeeping, one 1024-thread block per row; the per-row length
+// counter is advanced by the row's own block (no cross-block step counter, no extra launch).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void sampler2_kernel(SamplerArgs a) {
+  __shared__ float sv[16];
+  __shared__ int si[16];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* __restrict__ lg = a.logits + (size_t)b * a.V;
+  uint8_t* seen = a.seen + (size_t)b * a.V;
+  float best = -INFINITY;
+  int bi = 0x7fffffff;
+#pragma unroll 4
+  for (int i = tid; i < a.V; i += 1024) {
+    float v = lg[i];
+    if (a.penalty != 1.f && seen[i]) v = v < 0.f ? v * a.penalty : v / a.penalty;
+    if (a.suppress_stop && i == a.stop) v = -INFINITY;
+    if (v > best || (v == best && i < bi)) {
+      best = v;
+      bi = i;
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(best, o, 64);
+    const int oi = __shfl_xor(bi, o, 64);
+    if (ov > best || (ov == best && oi < bi)) {
+      best = ov;
+      bi = oi;
+    }
+  }
+  if (lane == 0) {
+    sv[wave] = best;
+    si[wave] = bi;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    for (int w = 1; w < 16; ++w)
+      if (sv[w] > best || (sv[w] == best && si[w] < bi)) {
+        best = sv[w];
+        bi = si[w];
+      }
+    const int k = a.step[b];
+    si[1] = -1;
+    if (k < a.max_gen) {  // graph replays past the end are no-ops
+      const int unf = a.unfinished[b];
+      const int tok = unf ? bi : a.stop;
+      a.ids[(size_t)b * a.max_gen + k] = tok;
+      a.cur_tok[b] = tok;
+      seen[tok] = 1;
+      a.unfinished[b] = unf && tok != a.stop;
+      a.step[b] = k + 1;
+      si[0] = tok;
+      si[1] = k + 2;  // position of the token fed at the next step: 0, 2, 3, ... (model.py:153-155)
+    }
+  }
+  // next step's input row h[b] = mel_emb[tok] + mel_pos[k + 2], fused here (one launch less per token)
+  __syncthreads();
+  if (a.h_next && si[1] > 0) {
+    const int tok = si[0], p = min(si[1], a.pos_rows - 1);
+    for (int i = tid; i < a.D; i += 1024) {
+      float v;
+      if (a.emb_bf16)
+        v = (float)((const bf16_t*)a.emb)[(size_t)tok * a.D + i] + (float)((const bf16_t*)a.pos)[(size_t)p * a.D + i];
+      else
+        v = ((const float*)a.emb)[(size_t)tok * a.D + i] + ((const float*)a.pos)[(size_t)p * a.D + i];
+      a.h_next[(size_t)b * a.D + i] = v;
+    }
+  }
+}
+
+template <typename TW>
+__global__ void decode_embed2_kernel(float* __restrict__ h, const TW* __restrict__ emb, const TW* __restrict__ pos,
+                                     const int* __restrict__ tok, const int* __restrict__ len, int D) {
+  const int b = blockIdx.x;
+  const int t = tok[b];
+  const int p = len[b] + 1;  // positions 0, 2, 3, ... (model.py:153-155)
+  for (int i = threadIdx.x; i < D; i += blockDim.x)
+    h[(size_t)b * D + i] = ldf(emb + (size_t)t * D + i) + ldf(pos + (size_t)p * D + i);
+}
+
+template <typename TW, int NB, int RPW, int NCH>
+int launch_gemv2(const GemvArgs& g, hipStream_t s) {
+  const int rows_per_block = 4 * RPW;
+  dim3 grid((g.N + rows_per_block - 1) / rows_per_block), blk(256);
+  const size_t lds = (size_t)NB * g.K * 4;
+  hipLaunchKernelGGL((gemv2_kernel<TW, NB, RPW, NCH>), grid, blk, lds, s, g);
+  ITTS_HIP_CHECK(hipGetLastError());
+  return OK;
+}
+
+template <typename TW, int NB>
+int dispatch_gemv2(const GemvArgs& g, hipStream_t s) {
+  // rows per wave chosen so the grid stays >= ~300 workgroups
+  const int nch = (g.K + 511) / 512;
+  if (nch <= 1) return g.N >= 4096 ? launch_gemv2<TW, NB, 4, 1>(g, s) : launch_gemv2<TW, NB, 1, 1>(g, s);
+  if (nch <= 3) return g.N >= 3072 ? launch_gemv2<TW, NB, 2, 3>(g, s) : launch_gemv2<TW, NB, 1, 3>(g, s);
+  if (nch <= 10) return launch_gemv2<TW, NB, 1, 10>(g, s);
+  set_error("gemv2: K too large");
+  return E_INVALID;
+}
+
+}  // namespace
+
+bool gemv2_supported(const GemvArgs& g) {
+  const int nb = g.B <= 2 ? g.B : 4;
+  return g.B >= 1 && g.B <= 4 && g.K % 8 == 0 && g.K <= 5120 && (size_t)nb * g.K * 4 <= 64 * 1024 && g.prologue <= 2;
+}
+
+int gemv2(const GemvArgs& g, int tw, hipStream_t s) {
+  ITTS_REQUIRE(g.X && g.W && g.Y && g.N > 0, "gemv2: bad args");
+  ITTS_REQUIRE(gemv2_supported(g), "gemv2: unsupported shape");
+#define GO(TW)                                                  \
+  if (g.B == 1) return dispatch_gemv2<TW, 1>(g, s);             \
+  if (g.B == 2) return dispatch_gemv2<TW, 2>(g, s);             \
+  return dispatch_gemv2<TW, 4>(g, s);
+  if (tw == F32) {
+    GO(float)
+  }
+  GO(bf16_t)
+#undef GO
+}
+
+template <int NB, int RPW, int NCH, int PRO, bool XBF, bool YBF>
+static int launch_gemv_bf16(const GemvArgs& g, hipStream_t s) {
+  dim3 grid((g.N + 4 * RPW - 1) / (4 * RPW)), blk(256);
+  hipLaunchKernelGGL((gemv_bf16_kernel<NB, RPW, NCH, PRO, XBF, YBF>), grid, blk, (size_t)NB * g.K * 2, s, g);
+  ITTS_HIP_CHECK(hipGetLastError());
+  return OK;
+}
+
+template <int NB>
+static int dispatch_gemv_bf16(const GemvArgs& g, hipStream_t s) {
+  const int nch = (g.K + 511) / 512;
+  // the shapes of the decode step; rows per wave from the tools/ubench_gemv.hip sweep
+  if (nch <= 1) {  // micro configs
+    if (g.prologue == 1 && !g.x_bf16 && g.y_bf16) return launch_gemv_bf16<NB, 1, 1, 1, false, true>(g, s);
+    if (g.prologue == 1 && !g.x_bf16 && !g.y_bf16) return launch_gemv_bf16<NB, 1, 1, 1, false, false>(g, s);
+    if (g.prologue == 2 && !g.x_bf16 && !g.y_bf16) return launch_gemv_bf16<NB, 1, 1, 2, false, false>(g, s);
+    if (g.prologue == 0 && g.x_bf16 && !g.y_bf16) return launch_gemv_bf16<NB, 1, 1, 0, true, false>(g, s);
+  } else if (nch <= 3) {
+    if (g.prologue == 1 && !g.x_bf16 && g.y_bf16) return launch_gemv_bf16<NB, 2, 3, 1, false, true>(g, s);    // fc
+    if (g.prologue == 1 && !g.x_bf16 && !g.y_bf16) return launch_gemv_bf16<NB, 2, 3, 1, false, false>(g, s);  // qkv
+    if (g.prologue == 2 && !g.x_bf16 && !g.y_bf16) return launch_gemv_bf16<NB, 4, 3, 2, false, false>(g, s);  // head
+    if (g.prologue == 0 && g.x_bf16 && !g.y_bf16) return launch_gemv_bf16<NB, 2, 3, 0, true, false>(g, s);    // proj
+  } else if (nch <= 4) {
+    if (g.prologue == 0 && g.x_bf16 && !g.y_bf16) return launch_gemv_bf16<NB, 2, 4, 0, true, false>(g, s);
+  } else if (nch <= 10) {
+    if (g.prologue == 0 && g.x_bf16 && !g.y_bf16) return launch_gemv_bf16<NB, 2, 10, 0, true, false>(g, s);   // proj2
+  }
+  set_error("gemv_bf16: no instantiation for this shape");
+  return E_INVALID;
+}
+
+bool gemv_bf16_supported(const GemvArgs& g) {
+  const int nch = (g.K + 511) / 512;
+  if (!(g.B >= 1 && g.B <= 4 && g.K % 8 == 0 && g.K >= 64 && nch <= 10)) return false;
+  if (g.x_bf16) return g.prologue == 0 && !g.y_bf16 && (nch <= 1 || nch == 3 || nch == 4 || (nch > 4 && nch <= 10));
+  if (g.prologue == 0 || nch > 3) return false;
+  return !(g.prologue == 2 && g.y_bf16);
+}
+
+int gemv_bf16(const GemvArgs& g, hipStream_t s) {
+  ITTS_REQUIRE(g.X && g.W && g.Y && g.N > 0, "gemv_bf16: bad args");
+  ITTS_REQUIRE(gemv_bf16_supported(g), "gemv_bf16: unsupported shape");
+  ITTS_REQUIRE(!(g.accumulate && g.y_bf16), "gemv_bf16: accumulate needs an fp32 output");
+  if (g.B == 1) return dispatch_gemv_bf16<1>(g, s);
+  if (g.B == 2) return dispatch_gemv_bf16<2>(g, s);
+  return dispatch_gemv_bf16<4>(g, s);
+}
+
+int decode_attn2(void* ctx, int to, const float* qkv, void* kc, void* vc, const int* len, const int* kv_start,
+                 const int* prefix_dev, int B, int H, int dh, int Smax, int tc, hipStream_t s) {
+  ITTS_REQUIRE(dh == 64, "decode_attn2: head dim must be 64");
+  const float scale = 1.f / sqrtf((float)dh);
+  dim3 grid(H, B);
+  if (tc == F32 && to == F32)
+    hipLaunchKernelGGL((decode_attn2_kernel<float, float>), grid, dim3(1024), 0, s, (float*)ctx, qkv, (float*)kc, (float*)vc, len, kv_start, prefix_dev, H, Smax, scale);
+  else if (tc == BF16 && to == BF16)
+    hipLaunchKernelGGL((decode_attn2_kernel<bf16_t, bf16_t>), grid, dim3(1024), 0, s, (bf16_t*)ctx, qkv, (bf16_t*)kc, (bf16_t*)vc, len, kv_start, prefix_dev, H, Smax, scale);
+  else if (tc == BF16 && to == F32)
+    hipLaunchKernelGGL((decode_attn2_kernel<bf16_t, float>), grid, dim3(1024), 0, s, (float*)ctx, qkv, (bf16_t*)kc, (bf16_t*)vc, len, kv_start, prefix_dev, H, Smax, scale);
+  else {
+    set_error("decode_attn2: dtype combination");
+    return E_INVALID;
+  }
+  ITTS_HIP_CHECK(hipGetLastError());
+  return OK;
+}
+
+int sampler2_step(const SamplerArgs& a, int B, hipStream_t s) {
+  hipLaunchKernelGGL(sampler2_kernel, dim3(B), dim3(1024), 0, s, a);
+  ITTS_HIP_CHECK(hipGetLastError());
+  return OK;
+}
+
+int decode_embed2(float* h, const void* emb, const void* pos, const int* tok, const int* len, int B, int D, int tw,
+                  hipStream_t s) {
+  if (tw == F32)
+    hipLaunchKernelGGL(decode_embed2_kernel<float>, dim3(B), dim3(256), 0, s, h, (const float*)emb, (const float*)pos, tok, len, D);
+  else
+    hipLaunchKernelGGL(decode_embed2_kernel<bf16_t>, dim3(B), dim3(256), 0, s, h, (const bf16_t*)emb, (const bf16_t*)pos, tok, len, D);
+  ITTS_HIP_CHECK(hipGetLastError());
+  return OK;
+}
+
+}  // namespace itts

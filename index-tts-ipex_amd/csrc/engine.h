@@ -108,7 +108,7 @@ struct DecodeState {
   size_t cache_bytes = 0;
   void *kc = nullptr, *vc = nullptr;  // [layers][B][H][Smax][dh]
   float *h = nullptr, *qkv = nullptr, *ctx = nullptr, *act = nullptr, *hn = nullptr, *logits = nullptr;
-  int *step = nullptr, *n_unf = nullptr, *n_unf_next = nullptr, *prefix_dev = nullptr;
+  int *len = nullptr, *prefix_dev = nullptr;  // len[b]: tokens generated so far by row b
   int *kv_start = nullptr, *cur_tok = nullptr, *ids = nullptr, *unfinished = nullptr;
   uint8_t* seen = nullptr;
   int cap_B = 0, cap_gen = 0;
@@ -178,6 +178,7 @@ struct Engine {
   // internals
   int gpt_layers_full(float* h, int B, int S, const int* kv_start_dev, bool write_cache, hipStream_t s);
   int decode_step_launch(hipStream_t s);
+  int head_and_sample(hipStream_t s);
   int ensure_decode_state(int B, int Smax, int max_gen, hipStream_t s);
   template <typename F>
   int two_pass(F&& body, hipStream_t s) {

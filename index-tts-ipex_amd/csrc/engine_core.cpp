@@ -9,7 +9,7 @@ namespace itts {
 Engine::~Engine() {
   if (ws) (void)hipFree(ws);
   DecodeState& d = ds;
-  void* ptrs[] = {d.kc, d.vc, d.h, d.qkv, d.ctx, d.act, d.hn, d.logits, d.step, d.n_unf, d.n_unf_next, d.prefix_dev,
+  void* ptrs[] = {d.kc, d.vc, d.h, d.qkv, d.ctx, d.act, d.hn, d.logits, d.len, d.prefix_dev,
                   d.kv_start, d.cur_tok, d.ids, d.unfinished, d.seen};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);

@@ -12,8 +12,13 @@ struct GemvArgs {
   int B = 0, N = 0, K = 0, ldy = 0;
   int act = ACT_NONE;
   int accumulate = 0;                // Y += result (residual stream)
-  const float* ln_gamma = nullptr;   // fused LayerNorm of X (over K) when non-null
+  int prologue = 0;                  // 0 plain, 1 LayerNorm(X), 2 LN2(LN(X))
+  int x_bf16 = 0;                    // X is bf16 [B, K] (gemv_bf16 only)
+  int y_bf16 = 0;                    // Y is bf16 [B, ldy] (gemv_bf16 only; no accumulate)
+  const float* ln_gamma = nullptr;
   const float* ln_beta = nullptr;
+  const float* ln2_gamma = nullptr;
+  const float* ln2_beta = nullptr;
   float ln_eps = 1e-5f;
 };
 
@@ -23,21 +28,30 @@ struct SamplerArgs {
   int* ids = nullptr;             // [B, max_gen]
   int* cur_tok = nullptr;         // [B]
   int* unfinished = nullptr;      // [B]
-  int* step = nullptr;            // [1] tokens generated so far
-  int* n_unfinished = nullptr;    // [1] rows still running after the last completed step
-  int* n_unfinished_next = nullptr;
+  int* step = nullptr;            // [B] tokens generated so far, per row
   int V = 0, max_gen = 0, stop = 0, suppress_stop = 0;
   float penalty = 1.f;
+  // fused input embedding of the next step: h_next[b] = emb[tok] + pos[k + 2]
+  float* h_next = nullptr;
+  const void* emb = nullptr;
+  const void* pos = nullptr;
+  int D = 0, pos_rows = 0, emb_bf16 = 0;
 };
 
-int decode_embed(float* h, const void* emb, const void* pos, const int* tok, const int* step, int B, int D, int tw,
-                 hipStream_t s);
 int gemv(const GemvArgs& g, int tw, hipStream_t s);
-int decode_attn(float* ctx, const float* qkv, void* kc, void* vc, const int* step, const int* kv_start,
-                const int* prefix_dev, int B, int H, int dh, int Smax, int tc, hipStream_t s);
 int double_ln(float* y, const float* x, const float* g1, const float* b1, const float* g2, const float* b2, int rows,
               int D, float eps, hipStream_t s);
-int sampler_step(const SamplerArgs& a, int B, hipStream_t s);
 int kv_scatter(void* kc, void* vc, const void* qkv, int B, int S, int H, int dh, int Smax, int tq, int tc, hipStream_t s);
+
+// second generation (decode2.hip)
+bool gemv2_supported(const GemvArgs& g);
+int gemv2(const GemvArgs& g, int tw, hipStream_t s);
+int decode_attn2(void* ctx, int to, const float* qkv, void* kc, void* vc, const int* len, const int* kv_start,
+                 const int* prefix_dev, int B, int H, int dh, int Smax, int tc, hipStream_t s);
+bool gemv_bf16_supported(const GemvArgs& g);
+int gemv_bf16(const GemvArgs& g, hipStream_t s);
+int sampler2_step(const SamplerArgs& a, int B, hipStream_t s);
+int decode_embed2(float* h, const void* emb, const void* pos, const int* tok, const int* len, int B, int D, int tw,
+                  hipStream_t s);
 
 }  // namespace itts

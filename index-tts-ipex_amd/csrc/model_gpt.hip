@@ -32,9 +32,8 @@ __global__ void gpt_embed_rows_kernel(float* __restrict__ h, const RowDesc* __re
   }
 }
 
-__global__ void init_decode_state_kernel(uint8_t* seen, int* unfinished, int* cur_tok, int* step, int* n_unf,
-                                         int* n_unf_next, int* prefix_dev, int B, int V, int fake_id, int start_tok,
-                                         int prefix) {
+__global__ void init_decode_state_kernel(uint8_t* seen, int* unfinished, int* cur_tok, int* len, int* prefix_dev,
+                                         int B, int V, int fake_id, int start_tok, int prefix) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < (long)B * V) {
     const int v = (int)(i % V);
@@ -43,13 +42,9 @@ __global__ void init_decode_state_kernel(uint8_t* seen, int* unfinished, int* cu
   if (i < B) {
     unfinished[i] = 1;
     cur_tok[i] = start_tok;
+    len[i] = 0;
   }
-  if (i == 0) {
-    step[0] = 0;
-    n_unf[0] = B;
-    n_unf_next[0] = 0;
-    prefix_dev[0] = prefix;
-  }
+  if (i == 0) prefix_dev[0] = prefix;
 }
 
 }  // namespace
@@ -140,12 +135,8 @@ int Engine::ensure_decode_state(int B, int Smax, int max_gen, hipStream_t s) {
     ITTS_TRY(dev_alloc((void**)&d.unfinished, (size_t)cb * 4));
     ITTS_TRY(dev_alloc((void**)&d.ids, (size_t)cb * cg * 4));
     ITTS_TRY(dev_alloc((void**)&d.seen, (size_t)cb * V));
-    if (!d.step) {
-      ITTS_TRY(dev_alloc((void**)&d.step, 64));
-      d.n_unf = d.step + 4;
-      d.n_unf_next = d.step + 8;
-      d.prefix_dev = d.step + 12;
-    }
+    ITTS_TRY(dev_alloc((void**)&d.len, (size_t)cb * 4));
+    if (!d.prefix_dev) ITTS_TRY(dev_alloc((void**)&d.prefix_dev, 64));
     d.cap_B = cb;
     d.cap_gen = cg;
   }
@@ -207,8 +198,7 @@ int Engine::gpt_prefill(const float* cond_dev, const int32_t* text_ids, int B, i
       ITTS_HIP_CHECK(hipMemcpyAsync(ds.kv_start, kvs.data(), B * 4, hipMemcpyHostToDevice, s));
       const long n = (long)B * V;
       hipLaunchKernelGGL(init_decode_state_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, ds.seen,
-                         ds.unfinished, ds.cur_tok, ds.step, ds.n_unf, ds.n_unf_next, ds.prefix_dev, B, V, 1,
-                         c.start_mel_token, sp);
+                         ds.unfinished, ds.cur_tok, ds.len, ds.prefix_dev, B, V, 1, c.start_mel_token, sp);
       if (adt == F32)
         hipLaunchKernelGGL(gpt_embed_rows_kernel<float>, dim3(B * S0), dim3(256), 0, s, h, rd_dev, cond_dev,
                            (const float*)gpt.text_emb, (const float*)gpt.text_pos, (const float*)gpt.mel_emb,
@@ -223,35 +213,7 @@ int Engine::gpt_prefill(const float* cond_dev, const int32_t* text_ids, int B, i
     ITTS_TRY(gpt_layers_full(h, B, S0, ds.kv_start, true, s));
     // logits of the last position only (generate takes logits[:, -1, :])
     K(copy_rows(ds.h, D, h + (size_t)(S0 - 1) * D, S0 * D, B, D, F32, s));
-    K(double_ln(ds.hn, ds.h, gpt.ln_f.g, gpt.ln_f.b, gpt.final_norm.g, gpt.final_norm.b, B, D, 1e-5f, s));
-    if (!dry) {
-      GemvArgs g;
-      g.X = ds.hn;
-      g.W = gpt.head.w;
-      g.Y = ds.logits;
-      g.bias = gpt.head.b;
-      g.B = B;
-      g.N = V;
-      g.K = D;
-      g.ldy = V;
-      ITTS_TRY(gemv(g, gpt.head.dt, s));
-      SamplerArgs sa;
-      sa.logits = ds.logits;
-      sa.seen = ds.seen;
-      sa.ids = ds.ids;
-      sa.cur_tok = ds.cur_tok;
-      sa.unfinished = ds.unfinished;
-      sa.step = ds.step;
-      sa.n_unfinished = ds.n_unf;
-      sa.n_unfinished_next = ds.n_unf_next;
-      sa.V = V;
-      sa.max_gen = ds.max_gen;
-      sa.stop = c.stop_mel_token;
-      sa.suppress_stop = suppress;
-      sa.penalty = penalty;
-      ITTS_TRY(tap("logits0", ds.logits, F32, (int64_t)B * V, s));
-      ITTS_TRY(sampler_step(sa, B, s));
-    }
+    if (!dry) ITTS_TRY(head_and_sample(s));
     return OK;
   };
   ITTS_TRY(two_pass(body, s));
@@ -261,72 +223,11 @@ int Engine::gpt_prefill(const float* cond_dev, const int32_t* text_ids, int B, i
   return OK;
 }
 
-// one decode step: embed -> 24 x {LN+QKV gemv, cache attention, proj gemv (+res), LN+FC gemv (gelu), proj2 gemv (+res)}
-// -> ln_f/final_norm -> mel_head gemv -> sampler.  Every length/position is read from device memory.
-int Engine::decode_step_launch(hipStream_t s) {
+// ln_f -> final_norm -> mel_head -> repetition penalty / argmax / bookkeeping (lm_head, model.py:48,180)
+int Engine::head_and_sample(hipStream_t s) {
   const itts_config& c = cfg;
-  const int D = c.model_dim, H = c.heads, dh = D / H, V = c.number_mel_codes, B = ds.B;
-  ITTS_TRY(decode_embed(ds.h, gpt.mel_emb, gpt.mel_pos, ds.cur_tok, ds.step, B, D, adt, s));
-  for (int l = 0; l < c.layers; ++l) {
-    const GptLayerW& L = gpt.layers[l];
-    GemvArgs g;
-    g.B = B;
-    // qkv = LN1(h) Wqkv + b
-    g.X = ds.h;
-    g.W = L.attn.w;
-    g.Y = ds.qkv;
-    g.bias = L.attn.b;
-    g.N = 3 * D;
-    g.K = D;
-    g.ldy = 3 * D;
-    g.ln_gamma = L.ln1.g;
-    g.ln_beta = L.ln1.b;
-    ITTS_TRY(gemv(g, L.attn.dt, s));
-    const size_t lo = (size_t)l * B * H * ds.Smax * dh * es;
-    ITTS_TRY(decode_attn(ds.ctx, ds.qkv, (char*)ds.kc + lo, (char*)ds.vc + lo, ds.step, ds.kv_start, ds.prefix_dev, B, H, dh,
-                         ds.Smax, adt, s));
-    // h += ctx Wproj + b
-    GemvArgs p;
-    p.B = B;
-    p.X = ds.ctx;
-    p.W = L.proj.w;
-    p.Y = ds.h;
-    p.bias = L.proj.b;
-    p.N = D;
-    p.K = D;
-    p.ldy = D;
-    p.accumulate = 1;
-    ITTS_TRY(gemv(p, L.proj.dt, s));
-    // act = gelu_new(LN2(h) Wfc + b)
-    GemvArgs f;
-    f.B = B;
-    f.X = ds.h;
-    f.W = L.fc.w;
-    f.Y = ds.act;
-    f.bias = L.fc.b;
-    f.N = 4 * D;
-    f.K = D;
-    f.ldy = 4 * D;
-    f.act = ACT_GELU_NEW;
-    f.ln_gamma = L.ln2.g;
-    f.ln_beta = L.ln2.b;
-    ITTS_TRY(gemv(f, L.fc.dt, s));
-    // h += act Wproj2 + b
-    GemvArgs q;
-    q.B = B;
-    q.X = ds.act;
-    q.W = L.proj2.w;
-    q.Y = ds.h;
-    q.bias = L.proj2.b;
-    q.N = D;
-    q.K = 4 * D;
-    q.ldy = D;
-    q.accumulate = 1;
-    ITTS_TRY(gemv(q, L.proj2.dt, s));
-  }
-  ITTS_TRY(double_ln(ds.hn, ds.h, gpt.ln_f.g, gpt.ln_f.b, gpt.final_norm.g, gpt.final_norm.b, B, D, 1e-5f, s));
+  const int D = c.model_dim, V = c.number_mel_codes, B = ds.B;
   GemvArgs g;
-  g.X = ds.hn;
   g.W = gpt.head.w;
   g.Y = ds.logits;
   g.bias = gpt.head.b;
@@ -334,22 +235,124 @@ int Engine::decode_step_launch(hipStream_t s) {
   g.N = V;
   g.K = D;
   g.ldy = V;
-  ITTS_TRY(gemv(g, gpt.head.dt, s));
+  g.X = ds.h;
+  g.prologue = 2;
+  g.ln_gamma = gpt.ln_f.g;
+  g.ln_beta = gpt.ln_f.b;
+  g.ln2_gamma = gpt.final_norm.g;
+  g.ln2_beta = gpt.final_norm.b;
+  if (adt == BF16 && gemv_bf16_supported(g)) {
+    ITTS_TRY(gemv_bf16(g, s));
+  } else if (gemv2_supported(g)) {
+    ITTS_TRY(gemv2(g, gpt.head.dt, s));
+  } else {
+    ITTS_TRY(double_ln(ds.hn, ds.h, gpt.ln_f.g, gpt.ln_f.b, gpt.final_norm.g, gpt.final_norm.b, B, D, 1e-5f, s));
+    g.X = ds.hn;
+    g.prologue = 0;
+    ITTS_TRY(gemv(g, gpt.head.dt, s));
+  }
+  ITTS_TRY(tap("logits0", ds.logits, F32, (int64_t)B * V, s));
   SamplerArgs sa;
   sa.logits = ds.logits;
   sa.seen = ds.seen;
   sa.ids = ds.ids;
   sa.cur_tok = ds.cur_tok;
   sa.unfinished = ds.unfinished;
-  sa.step = ds.step;
-  sa.n_unfinished = ds.n_unf;
-  sa.n_unfinished_next = ds.n_unf_next;
+  sa.step = ds.len;
   sa.V = V;
   sa.max_gen = ds.max_gen;
   sa.stop = c.stop_mel_token;
   sa.suppress_stop = ds.suppress_stop;
   sa.penalty = ds.penalty;
-  return sampler_step(sa, B, s);
+  sa.h_next = ds.h;  // the sampler also prepares the next step's input embedding
+  sa.emb = gpt.mel_emb;
+  sa.pos = gpt.mel_pos;
+  sa.D = D;
+  sa.pos_rows = c.max_mel_tokens + 3;
+  sa.emb_bf16 = adt == BF16;
+  return sampler2_step(sa, B, s);
+}
+
+// one decode step: 24 x {LN+QKV gemv, cache attention (+append), proj gemv (+res),
+// LN+FC gemv (gelu), proj2 gemv (+res)} -> head.  Every length / position is read from device memory, so the
+// captured graph is identical for every step and every prefix length.
+int Engine::decode_step_launch(hipStream_t s) {
+  const itts_config& c = cfg;
+  const int D = c.model_dim, H = c.heads, dh = D / H, B = ds.B;
+  // ds.h already holds mel_emb[tok] + mel_pos[...] of this step (written by the previous step's sampler)
+  const bool fast = adt == BF16 && B <= 4;  // bf16 activations between the decode kernels (ctx, act)
+  auto run = [&](GemvArgs& g, int dt) -> int {
+    if (fast && gemv_bf16_supported(g)) return gemv_bf16(g, s);
+    ITTS_REQUIRE(!g.x_bf16 && !g.y_bf16, "decode: bf16 activation without the bf16 GEMV");
+    return gemv2_supported(g) ? gemv2(g, dt, s) : gemv(g, dt, s);
+  };
+  GemvArgs probe;
+  probe.B = B;
+  probe.K = 4 * D;
+  probe.x_bf16 = 1;
+  probe.N = D;
+  const bool bf_act = fast && gemv_bf16_supported(probe);
+  probe.K = D;
+  const bool bf_ctx = fast && gemv_bf16_supported(probe);
+  for (int l = 0; l < c.layers; ++l) {
+    const GptLayerW& L = gpt.layers[l];
+    GemvArgs g;  // qkv = LN1(h) Wqkv + b
+    g.B = B;
+    g.X = ds.h;
+    g.W = L.attn.w;
+    g.Y = ds.qkv;
+    g.bias = L.attn.b;
+    g.N = 3 * D;
+    g.K = D;
+    g.ldy = 3 * D;
+    g.prologue = 1;
+    g.ln_gamma = L.ln1.g;
+    g.ln_beta = L.ln1.b;
+    ITTS_TRY(run(g, L.attn.dt));
+    const size_t lo = (size_t)l * B * H * ds.Smax * dh * es;
+    ITTS_TRY(decode_attn2(ds.ctx, bf_ctx ? BF16 : F32, ds.qkv, (char*)ds.kc + lo, (char*)ds.vc + lo, ds.len, ds.kv_start,
+                          ds.prefix_dev, B, H, dh, ds.Smax, adt, s));
+    GemvArgs p;  // h += ctx Wproj + b
+    p.B = B;
+    p.X = ds.ctx;
+    p.x_bf16 = bf_ctx;
+    p.W = L.proj.w;
+    p.Y = ds.h;
+    p.bias = L.proj.b;
+    p.N = D;
+    p.K = D;
+    p.ldy = D;
+    p.accumulate = 1;
+    ITTS_TRY(run(p, L.proj.dt));
+    GemvArgs f;  // act = gelu_new(LN2(h) Wfc + b)
+    f.B = B;
+    f.X = ds.h;
+    f.W = L.fc.w;
+    f.Y = ds.act;
+    f.y_bf16 = bf_act;
+    f.bias = L.fc.b;
+    f.N = 4 * D;
+    f.K = D;
+    f.ldy = 4 * D;
+    f.act = ACT_GELU_NEW;
+    f.prologue = 1;
+    f.ln_gamma = L.ln2.g;
+    f.ln_beta = L.ln2.b;
+    ITTS_TRY(run(f, L.fc.dt));
+    GemvArgs q;  // h += act Wproj2 + b
+    q.B = B;
+    q.X = ds.act;
+    q.x_bf16 = bf_act;
+    q.W = L.proj2.w;
+    q.Y = ds.h;
+    q.bias = L.proj2.b;
+    q.N = D;
+    q.K = 4 * D;
+    q.ldy = D;
+    q.accumulate = 1;
+    ITTS_TRY(run(q, L.proj2.dt));
+  }
+  return head_and_sample(s);
 }
 
 int Engine::gpt_decode(int nsteps, hipStream_t s) {
@@ -395,11 +398,16 @@ int Engine::gpt_status(int* steps, int* n_unf, hipStream_t s) {
     set_error("gpt_status: no active generation");
     return E_STATE;
   }
-  int host[16];
-  ITTS_HIP_CHECK(hipMemcpyAsync(host, ds.step, 64, hipMemcpyDeviceToHost, s));
+  std::vector<int> host(ds.B + 1);
+  ITTS_HIP_CHECK(hipMemcpyAsync(host.data(), ds.len, 4, hipMemcpyDeviceToHost, s));
+  ITTS_HIP_CHECK(hipMemcpyAsync(host.data() + 1, ds.unfinished, (size_t)ds.B * 4, hipMemcpyDeviceToHost, s));
   ITTS_HIP_CHECK(hipStreamSynchronize(s));
   if (steps) *steps = host[0];
-  if (n_unf) *n_unf = host[4];
+  if (n_unf) {
+    int n = 0;
+    for (int b = 0; b < ds.B; ++b) n += host[1 + b] != 0;
+    *n_unf = n;
+  }
   return OK;
 }
 

@@ -1,0 +1,73 @@
+"""Host-side integer logic of the `IndexTTS.infer` / `infer_fast` orchestration (product code, numpy only).
+
+Mirrors /root/reference/indextts/infer.py: `remove_long_silence` (:244-298), `bucket_sentences` (:303-315),
+`pad_tokens_cat` (:316-318).  Parity with the reference's own function is pinned by
+tests/golden/silence_cases.npz (tests/test_host_logic.py)."""
+from __future__ import annotations
+
+from typing import Dict, List, Sequence, Tuple
+
+import numpy as np
+
+
+def remove_long_silence(codes: np.ndarray, stop_mel_token: int, silent_token: int = 52,
+                        max_consecutive: int = 30) -> Tuple[np.ndarray, np.ndarray]:
+    """codes int [B, T] -> (codes', code_lens[B]).  Each row is cut at its first stop token; a row holding more
+    than `max_consecutive` silent tokens in total keeps at most 10 consecutive ones (infer.py:262-280); ragged
+    rows are right-padded with the stop token (:287) and the batch is clipped to the longest kept row (:294-296)."""
+    codes = np.asarray(codes)
+    assert codes.ndim == 2
+    lens: List[int] = []
+    rows: List[np.ndarray] = []
+    fixed = False
+    for code in codes:
+        hit = np.nonzero(code == stop_mel_token)[0]
+        n = int(hit[0]) if len(hit) else code.shape[0]
+        if int((code == silent_token).sum()) > max_consecutive:
+            body = code[:n]
+            is_sil = body == silent_token
+            # run position of each silent token inside its run (0-based); non-silent tokens reset the run
+            idx = np.arange(n)
+            last_non = np.maximum.accumulate(np.where(~is_sil, idx, -1))
+            run_pos = idx - last_non - 1
+            keep = (~is_sil) | (run_pos < 10)
+            rows.append(body[keep])
+            n = int(keep.sum())
+            fixed = True
+        else:
+            rows.append(code[:n])
+        lens.append(n)
+    if fixed:
+        width = max(r.shape[0] for r in rows)
+        out = np.full((len(rows), width), stop_mel_token, dtype=codes.dtype)
+        for i, r in enumerate(rows):
+            out[i, : r.shape[0]] = r
+        codes = out
+    m = max(lens)
+    if m < codes.shape[1]:
+        codes = codes[:, :m]
+    return codes, np.asarray(lens, dtype=np.int64)
+
+
+def bucket_sentences(sentences: Sequence[Sequence], bucket_max_size: int = 4) -> List[List[Dict]]:
+    """infer.py:303-315: keep order if everything fits one bucket, else sort by length into buckets."""
+    outputs = [{"idx": i, "sent": s, "len": len(s)} for i, s in enumerate(sentences)]
+    if len(outputs) <= bucket_max_size:
+        return [outputs]
+    buckets: List[List[Dict]] = []
+    for item in sorted(outputs, key=lambda x: x["len"]):
+        if not buckets or len(buckets[-1]) >= bucket_max_size:
+            buckets.append([item])
+        else:
+            buckets[-1].append(item)
+    return buckets
+
+
+def pad_tokens_cat(tokens: Sequence[np.ndarray], stop_text_token: int) -> np.ndarray:
+    """infer.py:316-318: right-pad id rows with the stop text token into [B, Lmax]."""
+    rows = [np.asarray(t).reshape(-1) for t in tokens]
+    width = max(r.shape[0] for r in rows)
+    out = np.full((len(rows), width), stop_text_token, dtype=np.int32)
+    for i, r in enumerate(rows):
+        out[i, : r.shape[0]] = r
+    return out

@@ -59,6 +59,7 @@ _PROTOS = {
     "itts_gemm": (i32, [C.POINTER(GemmArgs), vp]),
     "itts_layernorm": (i32, [vp, i32, vp, i32, vp, vp, i32, i32, f32, vp]),
     "itts_attention": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, f32, i32, vp, i32, vp]),
+    "itts_gemv": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, i32, i32, vp]),
     "itts_transpose": (i32, [vp, vp, i32, i32, i32, i32, vp]),
     "itts_engine_create": (i32, [C.POINTER(Config), C.POINTER(vp)]),
     "itts_engine_destroy": (None, [vp]),

@@ -20,12 +20,29 @@ from .config import ecapa_dims, perceiver_inner
 
 
 class _B:
+    """Collects tensor specs, then materialises them on a thread pool (numpy releases the GIL)."""
+
     def __init__(self, seed: int, prefix: str = ""):
         self.seed, self.prefix, self.sd = seed, prefix, {}
+        self.jobs = []
 
-    def t(self, name, shape, std=1.0, mean=0.0):
-        self.sd[name] = prng.tensor(self.prefix + name, self.seed, tuple(shape), std=std, mean=mean)
-        return self.sd[name]
+    def t(self, name, shape, std=1.0, mean=0.0, post=None):
+        self.jobs.append((name, tuple(shape), std, mean, post))
+
+    def build(self):
+        from concurrent.futures import ThreadPoolExecutor
+        import os
+
+        def run(job):
+            name, shape, std, mean, post = job
+            x = prng.tensor(self.prefix + name, self.seed, shape, std=std, mean=mean)
+            return name, (post(x) if post else x)
+
+        with ThreadPoolExecutor(max_workers=min(16, os.cpu_count() or 4)) as ex:
+            for name, x in ex.map(run, self.jobs):
+                self.sd[name] = x
+        self.jobs = []
+        return self.sd
 
     def lin(self, name, out_f, in_f, gain=1.0, bias=True, extra=()):
         self.t(name + ".weight", (out_f, in_f, *extra), std=gain / math.sqrt(in_f * int(np.prod(extra or (1,)))))
@@ -40,8 +57,7 @@ class _B:
         self.t(name + ".weight", (d,), std=0.1, mean=1.0)
         self.t(name + ".bias", (d,), std=0.05)
         self.t(name + ".running_mean", (d,), std=0.1)
-        self.sd[name + ".running_var"] = np.abs(prng.tensor(self.prefix + name + ".running_var", self.seed, (d,),
-                                                            std=0.2, mean=1.0)) + np.float32(0.05)
+        self.t(name + ".running_var", (d,), std=0.2, mean=1.0, post=lambda x: np.abs(x) + np.float32(0.05))
         self.sd[name + ".num_batches_tracked"] = np.array(1, dtype=np.int64)
 
 
@@ -110,8 +126,11 @@ def gpt_state_dict(cfg, seed: int = 1234) -> Dict[str, np.ndarray]:
     for i in range(NL):
         p = f"gpt.h.{i}."
         b.ln(p + "ln_1", D)
-        w = b.t(p + "attn.c_attn.weight", (D, 3 * D), std=1.0 / math.sqrt(D))
-        w[:, : 2 * D] *= np.float32(2.5)  # sharper attention: larger Q,K projections
+        def sharpen(w, D=D):  # sharper attention: larger Q,K projections
+            w[:, : 2 * D] *= np.float32(2.5)
+            return w
+
+        b.t(p + "attn.c_attn.weight", (D, 3 * D), std=1.0 / math.sqrt(D), post=sharpen)
         b.t(p + "attn.c_attn.bias", (3 * D,), std=0.05)
         b.t(p + "attn.c_proj.weight", (D, D), std=0.5 / math.sqrt(D))
         b.t(p + "attn.c_proj.bias", (D,), std=0.05)
@@ -124,7 +143,7 @@ def gpt_state_dict(cfg, seed: int = 1234) -> Dict[str, np.ndarray]:
     b.ln("final_norm", D)
     b.lin("text_head", g["number_text_tokens"] + 1, D)
     b.lin("mel_head", g["number_mel_codes"], D, gain=3.0)
-    return b.sd
+    return b.build()
 
 
 def bigvgan_state_dict(cfg, seed: int = 1234) -> Dict[str, np.ndarray]:
@@ -179,7 +198,7 @@ def bigvgan_state_dict(cfg, seed: int = 1234) -> Dict[str, np.ndarray]:
     b.lin("cond_layer", C0, h["speaker_embedding_dim"], gain=0.5, extra=(1,))
     for i in range(len(h["upsample_rates"])):
         b.lin(f"conds.{i}", C0 // (2 ** (i + 1)), h["speaker_embedding_dim"], gain=0.5, extra=(1,))
-    return b.sd
+    return b.build()
 
 
 def dvae_state_dict(cfg, seed: int = 1234) -> Dict[str, np.ndarray]:
@@ -204,7 +223,7 @@ def dvae_state_dict(cfg, seed: int = 1234) -> Dict[str, np.ndarray]:
         idx += 1
     b.lin(f"decoder.{idx}", v["channels"], dec[-1], extra=(1,))
     b.t("codebook.embed", (cb, v["num_tokens"]), std=1.0)
-    return b.sd
+    return b.build()
 
 
 # ---- synthetic inputs ---------------------------------------------------------------

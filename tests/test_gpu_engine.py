@@ -107,6 +107,26 @@ def test_greedy_bf16_report(eng16, gold):
     assert first_div >= 1  # the first token must survive bf16 rounding on this fixture
 
 
+def test_decode_logits_trace_bf16(eng16, gold):
+    """bf16 throughput path (dot2 GEMV, bf16 KV cache): per-step logits within a stated tolerance of the fp32
+    reference trace for as long as the greedy ids agree."""
+    c, g = gold("micro_conditioning"), gold("micro_decode_b1")
+    cond = torch.from_numpy(c["cond"])
+    eng16.prefill(cond, g["text"], 24)
+    n = g["logits"].shape[1]
+    worst = 0.0
+    for k in range(n):
+        codes, lg = eng16.fetch(logits=True)
+        worst = max(worst, rms_rel(lg, g["logits"][:, k]))
+        if codes[0, k] != g["codes"][0, k]:
+            break
+        if k + 1 < n:
+            eng16.decode(1)
+    eng16._exit()
+    print(f"bf16 decode: {k + 1} steps compared, worst logits rel-RMS {worst:.4f}")
+    assert k >= 3 and worst < 5e-2
+
+
 def test_latent(eng32, eng16, gold):
     c, g = gold("micro_conditioning"), gold("micro_latent")
     cond = torch.from_numpy(c["cond"])
