@@ -248,41 +248,44 @@ __device__ __forceinline__ float dot2(uint32_t a, uint32_t b, float c) {
 }
 
 // PRO: 0 plain, 1 LayerNorm, 2 LayerNorm o LayerNorm.  XBF: X is bf16 [B, K] (else fp32).  YBF: Y is bf16.
+// Every batch row uses the SAME thread <-> element mapping, so a row's result does not depend on its position in
+// the batch (the padding/batch invariance the reference's tests/padding_test.py checks).
 template <int NB, int RPW, int NCH, int PRO, bool XBF, bool YBF>
 __global__ __launch_bounds__(256) void gemv_bf16_kernel(GemvArgs g) {
-  constexpr int XCH = XBF ? (NB * NCH * 512 + 2047) / 2048 : (NB * NCH * 512 + 1023) / 1024;  // 16-byte chunks / thread
-  extern __shared__ __attribute__((aligned(16))) uint32_t sxb[];  // [NB][K/2] bf16 pairs
+  constexpr int EPC = XBF ? 8 : 4;                                  // elements per 16-byte chunk
+  constexpr int KCH = (NCH * 512 + 256 * EPC - 1) / (256 * EPC);    // chunks per row per thread
+  extern __shared__ __attribute__((aligned(16))) uint32_t sxb[];    // [NB][K/2] bf16 pairs
   __shared__ float red[2][4][2 * NB];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int K = g.K, BK = NB * K;
+  const int K = g.K;
   const int n0 = (blockIdx.x * 4 + wave) * RPW;
   // ---- 1. activations (+ LayerNorm parameters) first, weights second; all unconditional ----
-  u32x4 xr[XCH];           // XBF: 8 bf16; else 4 floats
-  f32x4 gm[PRO >= 1 ? XCH : 1], bt[PRO >= 1 ? XCH : 1], gm2[PRO == 2 ? XCH : 1], bt2[PRO == 2 ? XCH : 1];
-  int xb[XCH];
-  bool xok[XCH];
-  constexpr int EPC = XBF ? 8 : 4;  // elements per chunk
+  u32x4 xr[NB][KCH];  // XBF: 8 bf16; else 4 floats
+  f32x4 gm[PRO >= 1 ? KCH : 1], bt[PRO >= 1 ? KCH : 1], gm2[PRO == 2 ? KCH : 1], bt2[PRO == 2 ? KCH : 1];
+  bool xok[KCH];
 #pragma unroll
-  for (int j = 0; j < XCH; ++j) {
+  for (int j = 0; j < KCH; ++j) {
     const int i = (tid + j * 256) * EPC;
-    xok[j] = i < BK;
-    const int ic = xok[j] ? i : BK - EPC;
-    xb[j] = ic / K;
-    if (XBF) xr[j] = *reinterpret_cast<const u32x4*>((const bf16_t*)g.X + ic);
-    else xr[j] = *reinterpret_cast<const u32x4*>(g.X + ic);
+    xok[j] = i < K;
+    const int ic = xok[j] ? i : K - EPC;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      const size_t ro = (size_t)min(b, g.B - 1) * K + ic;
+      if (XBF) xr[b][j] = *reinterpret_cast<const u32x4*>((const bf16_t*)g.X + ro);
+      else xr[b][j] = *reinterpret_cast<const u32x4*>(g.X + ro);
+    }
     if (PRO >= 1) {
-      const int col = ic - xb[j] * K;
-      gm[j] = *reinterpret_cast<const f32x4*>(g.ln_gamma + col);
-      bt[j] = *reinterpret_cast<const f32x4*>(g.ln_beta + col);
+      gm[j] = *reinterpret_cast<const f32x4*>(g.ln_gamma + ic);
+      bt[j] = *reinterpret_cast<const f32x4*>(g.ln_beta + ic);
       if (PRO == 2) {
-        gm2[j] = *reinterpret_cast<const f32x4*>(g.ln2_gamma + col);
-        bt2[j] = *reinterpret_cast<const f32x4*>(g.ln2_beta + col);
+        gm2[j] = *reinterpret_cast<const f32x4*>(g.ln2_gamma + ic);
+        bt2[j] = *reinterpret_cast<const f32x4*>(g.ln2_beta + ic);
       }
     }
   }
   float pivot[NB];
 #pragma unroll
-  for (int b = 0; b < NB; ++b) pivot[b] = PRO >= 1 ? g.X[(size_t)b * K] : 0.f;
+  for (int b = 0; b < NB; ++b) pivot[b] = PRO >= 1 ? g.X[(size_t)min(b, g.B - 1) * K] : 0.f;
   const bf16_t* __restrict__ W = (const bf16_t*)g.W;
   u32x4 w[RPW][NCH];
   const int klast = (NCH - 1) * 512 + lane * 8;
@@ -296,31 +299,28 @@ __global__ __launch_bounds__(256) void gemv_bf16_kernel(GemvArgs g) {
   }
   // ---- 2. LayerNorm(s) in registers (one barrier each), bf16 pairs to LDS ----
   if (!XBF) {
-    float xv[XCH][4];
+    float xv[NB][KCH][4];
 #pragma unroll
-    for (int j = 0; j < XCH; ++j)
+    for (int b = 0; b < NB; ++b)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) xv[j][e] = __uint_as_float(xr[j][e]);
+      for (int j = 0; j < KCH; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) xv[b][j][e] = __uint_as_float(xr[b][j][e]);
 #pragma unroll
     for (int pass = 0; pass < PRO; ++pass) {
       float s[NB], q[NB];
 #pragma unroll
-      for (int b = 0; b < NB; ++b) s[b] = q[b] = 0.f;
+      for (int b = 0; b < NB; ++b) {
+        s[b] = q[b] = 0.f;
+        const float pv = pass == 0 ? pivot[b] : 0.f;
 #pragma unroll
-      for (int j = 0; j < XCH; ++j)
-#pragma unroll
-        for (int bb = 0; bb < NB; ++bb) {
-          const bool m = xok[j] && xb[j] == bb;
-          const float pv = pass == 0 ? pivot[bb] : 0.f;
+        for (int j = 0; j < KCH; ++j)
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            const float d = m ? xv[j][e] - pv : 0.f;
-            s[bb] += d;
-            q[bb] = fmaf(d, d, q[bb]);
+            const float d = xok[j] ? xv[b][j][e] - pv : 0.f;
+            s[b] += d;
+            q[b] = fmaf(d, d, q[b]);
           }
-        }
-#pragma unroll
-      for (int b = 0; b < NB; ++b) {
         s[b] = wave_sum_dpp(s[b]);
         q[b] = wave_sum_dpp(q[b]);
       }
@@ -331,41 +331,38 @@ __global__ __launch_bounds__(256) void gemv_bf16_kernel(GemvArgs g) {
           red[pass][wave][2 * b + 1] = q[b];
         }
       __syncthreads();
-      float mean[NB], rstd[NB];
 #pragma unroll
       for (int b = 0; b < NB; ++b) {
         const float S = red[pass][0][2 * b] + red[pass][1][2 * b] + red[pass][2][2 * b] + red[pass][3][2 * b];
         const float Q = red[pass][0][2 * b + 1] + red[pass][1][2 * b + 1] + red[pass][2][2 * b + 1] + red[pass][3][2 * b + 1];
         const float md = S / K;
-        mean[b] = (pass == 0 ? pivot[b] : 0.f) + md;
-        rstd[b] = rsqrtf(fmaxf(Q / K - md * md, 0.f) + g.ln_eps);
-      }
+        const float mean = (pass == 0 ? pivot[b] : 0.f) + md;
+        const float rstd = rsqrtf(fmaxf(Q / K - md * md, 0.f) + g.ln_eps);
 #pragma unroll
-      for (int j = 0; j < XCH; ++j) {
-        float m = mean[0], r = rstd[0];
+        for (int j = 0; j < KCH; ++j) {
+          const f32x4 G = pass ? gm2[j] : gm[j], Bt = pass ? bt2[j] : bt[j];
 #pragma unroll
-        for (int bb = 1; bb < NB; ++bb) {
-          m = xb[j] == bb ? mean[bb] : m;
-          r = xb[j] == bb ? rstd[bb] : r;
+          for (int e = 0; e < 4; ++e) xv[b][j][e] = (xv[b][j][e] - mean) * rstd * G[e] + Bt[e];
         }
-        const f32x4 G = pass ? gm2[j] : gm[j], Bt = pass ? bt2[j] : bt[j];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) xv[j][e] = (xv[j][e] - m) * r * G[e] + Bt[e];
       }
     }
 #pragma unroll
-    for (int j = 0; j < XCH; ++j)
-      if (xok[j]) {
-        const int i = (tid + j * 256) * 4;
-        uint2 p;
-        p.x = pack_bf16(xv[j][0], xv[j][1]);
-        p.y = pack_bf16(xv[j][2], xv[j][3]);
-        *reinterpret_cast<uint2*>(sxb + i / 2) = p;
-      }
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+      for (int j = 0; j < KCH; ++j)
+        if (xok[j]) {
+          const int i = (tid + j * 256) * 4;
+          uint2 p;
+          p.x = pack_bf16(xv[b][j][0], xv[b][j][1]);
+          p.y = pack_bf16(xv[b][j][2], xv[b][j][3]);
+          *reinterpret_cast<uint2*>(sxb + (b * K + i) / 2) = p;
+        }
   } else {
 #pragma unroll
-    for (int j = 0; j < XCH; ++j)
-      if (xok[j]) *reinterpret_cast<u32x4*>(sxb + (tid + j * 256) * 4) = xr[j];
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+      for (int j = 0; j < KCH; ++j)
+        if (xok[j]) *reinterpret_cast<u32x4*>(sxb + (b * K + (tid + j * 256) * 8) / 2) = xr[b][j];
   }
   __syncthreads();
   // ---- 3. dot products: 4 x v_dot2c per weight fragment and batch row ----
