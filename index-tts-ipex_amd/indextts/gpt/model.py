@@ -1,0 +1,82 @@
+"""`UnifiedVoice` drop-in (/root/reference/indextts/gpt/model.py:300-708) on the HIP engine.
+
+Implements the inference surface `infer.py` and `tests/padding_test.py` use: `get_conditioning`,
+`inference_speech(...)`, `forward(..., return_latent=True)`, `post_init_gpt2_config`."""
+from __future__ import annotations
+
+import warnings
+
+import numpy as np
+import torch
+
+
+class UnifiedVoice:
+    def __init__(self, engine, gpt_cfg):
+        self._eng = engine
+        for k in ("stop_mel_token", "start_mel_token", "start_text_token", "stop_text_token", "mel_length_compression",
+                  "max_mel_tokens", "max_text_tokens", "model_dim", "layers", "heads", "number_mel_codes",
+                  "number_text_tokens"):
+            setattr(self, k, gpt_cfg[k])
+        self.cond_num = gpt_cfg.get("condition_num_latent", 32)
+        self._cond_key, self._cond = None, None
+
+    # no-ops kept for call compatibility (infer.py:50-52,59)
+    def eval(self):
+        return self
+
+    def to(self, *a, **k):
+        return self
+
+    def half(self):
+        return self
+
+    def post_init_gpt2_config(self, use_deepspeed=False, kv_cache=False, half=False):
+        return None
+
+    @torch.no_grad()
+    def get_conditioning(self, speech_conditioning_input, cond_mel_lengths=None):
+        """[1, n_mels, F] -> [1, 32, D]; cached per prompt tensor (the reference recomputes it twice per sentence,
+        model.py:540,670).  Only full-length single prompts are supported (what infer.py passes)."""
+        x = speech_conditioning_input
+        if x.ndim == 2:
+            x = x.unsqueeze(0)
+        if cond_mel_lengths is not None and int(torch.as_tensor(cond_mel_lengths).reshape(-1)[0]) != x.shape[-1]:
+            raise NotImplementedError("partial-length conditioning prompts")
+        key = (x.data_ptr(), tuple(x.shape), x._version)
+        if key != self._cond_key:
+            self._cond, self._cond_key = self._eng.conditioning(x), key
+        return self._cond
+
+    @torch.no_grad()
+    def inference_speech(self, speech_conditioning_mel, text_inputs, cond_mel_lengths=None, input_tokens=None,
+                         num_return_sequences=1, max_generate_length=None, typical_sampling=False, typical_mass=.9,
+                         **hf_generate_kwargs):
+        """Greedy decode of mel codes [b, <= max_generate_length] (model.py:655-708).  HF `generate` kwargs are
+        accepted; anything but greedy search (do_sample=False, num_beams=1) is not implemented yet and falls back
+        to greedy with a warning."""
+        if input_tokens is not None or num_return_sequences != 1:
+            raise NotImplementedError("input_tokens / num_return_sequences > 1")
+        if hf_generate_kwargs.get("do_sample", False) or hf_generate_kwargs.get("num_beams", 1) != 1 or typical_sampling:
+            warnings.warn("itts_hip: sampling / beam search are not implemented; decoding greedily", RuntimeWarning)
+        cond = self.get_conditioning(speech_conditioning_mel, cond_mel_lengths)
+        ids = text_inputs.detach().cpu().numpy() if isinstance(text_inputs, torch.Tensor) else np.asarray(text_inputs)
+        if ids.ndim == 1:
+            ids = ids[None]
+        max_gen = self.max_mel_tokens - 1 if max_generate_length is None else int(max_generate_length)
+        rep = float(hf_generate_kwargs.get("repetition_penalty", 1.0) or 1.0)
+        codes = self._eng.generate(cond, ids, max_gen, repetition_penalty=rep)
+        return torch.from_numpy(codes).to(self._eng.device)
+
+    @torch.no_grad()
+    def forward(self, speech_conditioning_latent, text_inputs, text_lengths, mel_codes, wav_lengths,
+                cond_mel_lengths=None, types=None, text_first=True, raw_mels=None, return_attentions=False,
+                return_latent=False, clip_inputs=False):
+        """Only the `return_latent=True`, batch-1 form infer.py:194-200 uses (model.py:521-589)."""
+        if not return_latent or not text_first or raw_mels is not None or types is not None:
+            raise NotImplementedError("UnifiedVoice.forward: only return_latent=True inference is implemented")
+        cond = self.get_conditioning(speech_conditioning_latent, cond_mel_lengths)
+        t = text_inputs.detach().cpu().numpy().reshape(-1)
+        c = mel_codes.detach().cpu().numpy().reshape(-1)
+        return self._eng.latent(cond, t, c)
+
+    __call__ = forward

@@ -1,0 +1,19 @@
+"""Checkpoint reader: what `load_checkpoint(model, path)` consumes (/root/reference/indextts/utils/checkpoint.py:25-34):
+a torch pickle, optionally nested under "model"; returns numpy fp32 state dict for the weight packer."""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+
+def read_state_dict(path: str, key: str = None):
+    ck = torch.load(path, map_location="cpu", weights_only=False)
+    if key is not None and key in ck:
+        ck = ck[key]
+    elif "model" in ck and isinstance(ck["model"], dict):
+        ck = ck["model"]
+    out = {}
+    for k, v in ck.items():
+        if isinstance(v, torch.Tensor) and not k.startswith("inference_model."):
+            out[k] = v.detach().float().numpy() if v.dtype.is_floating_point else v.numpy()
+    return out

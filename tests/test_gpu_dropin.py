@@ -1,0 +1,106 @@
+"""GPU: the drop-in surface - `anti_alias_activation_cuda.forward` replacement, `Activation1d(fused)`, and
+`IndexTTS.infer` / `tts.gpt.inference_speech` on a synthetic micro checkpoint, checked against the oracle."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from itts_hip import config as icfg  # noqa: E402
+from itts_hip import synth  # noqa: E402
+from oracle import gpt as ogpt  # noqa: E402
+from oracle import pipeline as opipe  # noqa: E402
+from oracle import vocoder as ovoc  # noqa: E402
+
+CFG = icfg.micro()
+
+
+def test_native_op_dropin(gold):
+    from indextts.BigVGAN.alias_free_activation.cuda import load
+
+    op = load.load()
+    g = gold("micro_act1d_a")
+    x = torch.from_numpy(g["x"]).cuda()
+    y = op.forward(x, torch.from_numpy(g["filt"]).view(1, 1, 12).cuda(), torch.from_numpy(g["filt_down"]).view(1, 1, 12).cuda(),
+                   torch.from_numpy(g["alpha"]).cuda(), torch.from_numpy(g["beta"]).cuda())
+    assert y.shape == x.shape and y.dtype == x.dtype
+    assert float((y.cpu() - torch.from_numpy(g["y"])).abs().max()) < 2e-5 * float(np.abs(g["y"]).max())
+    with pytest.raises(RuntimeError):
+        op.forward(x.cpu(), torch.zeros(12), torch.zeros(12), torch.zeros(8), torch.zeros(8))
+    with pytest.raises(RuntimeError):
+        op.forward(x.transpose(1, 2), torch.zeros(12), torch.zeros(12), torch.zeros(8), torch.zeros(8))
+
+
+def test_activation1d_module(gold):
+    from indextts.BigVGAN.alias_free_activation.cuda.activation1d import Activation1d
+
+    class SnakeBeta(torch.nn.Module):  # parameter holder with the reference's attribute names (activations.py:63-122)
+        def __init__(self, a, b):
+            super().__init__()
+            self.alpha, self.beta, self.alpha_logscale = torch.nn.Parameter(a), torch.nn.Parameter(b), True
+
+    g = gold("micro_act1d_b")
+    act = Activation1d(SnakeBeta(torch.from_numpy(g["alpha"]), torch.from_numpy(g["beta"]))).cuda()
+    y = act(torch.from_numpy(g["x"]).cuda())
+    assert float((y.cpu() - torch.from_numpy(g["y"])).abs().max()) < 2e-5 * float(np.abs(g["y"]).max())
+
+
+@pytest.fixture(scope="module")
+def tts():
+    from indextts.infer import IndexTTS
+
+    sds = {"gpt": synth.gpt_state_dict(CFG, 1234), "bigvgan": synth.bigvgan_state_dict(CFG, 1234),
+           "dvae": synth.dvae_state_dict(CFG, 1234)}
+    return IndexTTS(cfg=CFG, model_dir="/nonexistent", is_fp16=False, state_dicts=sds)
+
+
+def test_indextts_infer_matches_oracle(tts):
+    mel = torch.from_numpy(synth.prompt_mel(61, seed=7))
+    sents = [synth.text_ids(11, 11, CFG.gpt.number_text_tokens).astype(np.int32),
+             synth.text_ids(7, 12, CFG.gpt.number_text_tokens).astype(np.int32)]
+    with pytest.warns(RuntimeWarning):  # default kwargs ask for beam-sample: decoded greedily with a warning
+        sr, wav = tts.infer(prompt_mel=mel, text=sents, output_path=None, max_mel_tokens=24)
+    assert sr == 24000 and wav.dtype == np.int16 and wav.ndim == 2 and wav.shape[1] == 1
+    wg = ogpt.to_torch(synth.gpt_state_dict(CFG, 1234))
+    wb = ogpt.to_torch(synth.bigvgan_state_dict(CFG, 1234))
+    parts = []
+    for s in sents:
+        _, _, w = opipe.infer_sentence(mel, torch.from_numpy(s).view(1, -1), wg, wb, CFG, max_mel_tokens=24)
+        parts.append(w)
+    ref = torch.cat(parts, dim=1).numpy().T
+    assert ref.shape == wav.shape, (ref.shape, wav.shape)
+    err = np.sqrt(((wav.astype(np.float64) - ref) ** 2).mean()) / np.sqrt((ref.astype(np.float64) ** 2).mean())
+    assert err < 2e-3, err  # int16 quantisation + fp32 tolerance
+
+
+def test_padding_test_through_dropin(tts, gold):
+    """tests/padding_test.py flow through `tts.gpt.inference_speech` with its kwargs."""
+    g1, g5 = gold("micro_decode_b1"), gold("micro_decode_b5")
+    mel = torch.from_numpy(gold("micro_conditioning")["mel"]).cuda()
+    kwargs = dict(cond_mel_lengths=torch.tensor([mel.shape[-1]]), do_sample=False, top_p=0.8, top_k=None, temperature=1.0,
+                  num_return_sequences=1, length_penalty=0.0, num_beams=1, repetition_penalty=10.0, max_generate_length=24)
+    base = tts.gpt.inference_speech(mel, torch.from_numpy(g1["text"]).cuda(), **kwargs)
+    assert np.array_equal(base.cpu().numpy(), g1["codes"])
+    batch = tts.gpt.inference_speech(mel, torch.from_numpy(g5["text"]).cuda(), **kwargs)
+    assert np.array_equal(batch.cpu().numpy(), g5["codes"])
+    codes, lens = tts.remove_long_silence(base)
+    assert codes.shape[1] == int(lens[0])
+
+
+def test_dropin_misc(tts, gold, tmp_path):
+    from indextts.vqvae.xtts_dvae import DiscreteVAE
+
+    g = gold("micro_dvae")
+    mel, _ = DiscreteVAE(tts.engine).decode(torch.from_numpy(g["codes"]))
+    assert float((mel.float().cpu() - torch.from_numpy(g["mel"])).abs().max()) < 1e-4 * float(np.abs(g["mel"]).max())
+    calls = []
+    tts.set_gr_progress_callback(lambda v, d: calls.append(v))
+    out = tts.infer_fast(prompt_mel=torch.from_numpy(synth.prompt_mel(61, seed=7)), text=[[5, 6, 7, 8, 9]],
+                         output_path=str(tmp_path / "o" / "x.wav"), do_sample=False, num_beams=1, max_mel_tokens=8)
+    assert out.endswith("x.wav") and calls
+    from scipy.io import wavfile
+
+    sr, data = wavfile.read(out)
+    assert sr == 24000 and data.dtype == np.int16 and data.shape[0] % 1024 == 0
+    with pytest.raises(TypeError):
+        tts.infer(text=[[5, 6]])
