@@ -87,8 +87,14 @@ def cpu_baseline(cfg, a):
     from oracle import vocoder as ovoc
     from itts_hip.config import ecapa_dims
 
-    cores = os.cpu_count() or 1
+    # the box's CPU share, not the host's core count (an 8-GPU host exposes >100 cores to os.cpu_count())
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, int(os.environ.get("ITTS_CPU_BASELINE_THREADS", "16"))))
     torch.set_num_threads(cores)
+    print(f"[cpu_baseline] oracle on {cores} threads ...", file=sys.stderr, flush=True)
     g = cfg["gpt"]
     wg = ogpt.to_torch(synth.gpt_state_dict(cfg, 1234))
     wb = ogpt.to_torch(synth.bigvgan_state_dict(cfg, 1234))
@@ -99,10 +105,12 @@ def cpu_baseline(cfg, a):
         t0 = time.perf_counter()
         cond = ogpt.get_conditioning(mel, wg, g)
         t_cond = time.perf_counter() - t0
+        print(f"[cpu_baseline] conditioning {t_cond:.2f}s", file=sys.stderr, flush=True)
         nsamp = 24
         t0 = time.perf_counter()
         codes = ogpt.greedy_generate(cond, text, wg, g, nsamp, suppress_eos=True)
         t_gen = time.perf_counter() - t0
+        print(f"[cpu_baseline] {nsamp} greedy steps {t_gen:.2f}s", file=sys.stderr, flush=True)
         # prefill alone, to separate it from the per-token cost
         t0 = time.perf_counter()
         ogpt.greedy_generate(cond, text, wg, g, 1, suppress_eos=True)
@@ -112,6 +120,7 @@ def cpu_baseline(cfg, a):
         t0 = time.perf_counter()
         lat = ogpt.latent_forward(cond, text, full_codes, wg, g)
         t_lat = time.perf_counter() - t0
+        print(f"[cpu_baseline] latent pass {t_lat:.2f}s", file=sys.stderr, flush=True)
         nfr = 16
         t0 = time.perf_counter()
         ovoc.bigvgan_forward(lat[:, :nfr], mel.transpose(1, 2), wb, cfg["bigvgan"], ecapa_dims(cfg["bigvgan"]))

@@ -449,10 +449,22 @@ __global__ __launch_bounds__(1024) void decode_attn2_kernel(TO* __restrict__ ctx
   const int h = blockIdx.x, b = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int D = H * DH;
-  const int pos = prefix[0] + len[b];
-  const int S = pos + 1;
   TC* kb = kc + ((size_t)b * H + h) * Smax * DH;
   TC* vb = vc + ((size_t)b * H + h) * Smax * DH;
+  const int slot = tid / LPK, sub = tid % LPK;
+  // (a) the first two key rows of every slot are requested before ANYTHING else: their addresses depend on no
+  //     device scalar (rows are clamped to the cache capacity; rows >= S are masked out below)
+  CacheVec<TC> kcur[2], vcur[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int j = min(u * SLOTS + slot, Smax - 1);
+    kcur[u].load(kb + (size_t)j * DH + sub * VEC);
+    vcur[u].load(vb + (size_t)j * DH + sub * VEC);
+  }
+  // (b) per-row scalars, the query, and the K/V append of this step
+  const int pos = prefix[0] + len[b];
+  const int S = pos + 1;
+  const int ks = kv_start[b];
   const float* qv = qkv + (size_t)b * 3 * D + h * DH;
   if (tid < DH) {
     sq[tid] = qv[tid] * scale;
@@ -460,49 +472,52 @@ __global__ __launch_bounds__(1024) void decode_attn2_kernel(TO* __restrict__ ctx
     stf(vb + (size_t)pos * DH + tid, qv[2 * D + tid]);
   }
   __syncthreads();
-  const int ks = kv_start[b];
-  const int slot = tid / LPK, sub = tid % LPK;
-  float qr[VEC];
+  float qr[VEC], kown[VEC], vown[VEC];  // the appended row with the cache's rounding, never read back from HBM
 #pragma unroll
-  for (int i = 0; i < VEC; ++i) qr[i] = sq[sub * VEC + i];
+  for (int i = 0; i < VEC; ++i) {
+    qr[i] = sq[sub * VEC + i];
+    kown[i] = (float)(TC)qv[D + sub * VEC + i];
+    vown[i] = (float)(TC)qv[2 * D + sub * VEC + i];
+  }
   float m = -INFINITY, l = 0.f, acc[VEC];
 #pragma unroll
   for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
+  // (c) online softmax over the slot's keys, next pair of rows prefetched while the current pair is consumed
+#pragma unroll 1
   for (int jb = 0; jb < S; jb += 2 * SLOTS) {
-    // two keys per iteration: all four 16-byte loads are requested before the first use
-    const int ja = jb + slot, jc = jb + SLOTS + slot;
-    const int jal = min(ja, S - 1), jcl = min(jc, S - 1);  // clamped: loads are unconditional
-    CacheVec<TC> ka, va, kc2, vc2;
-    ka.load(kb + (size_t)jal * DH + sub * VEC);
-    va.load(vb + (size_t)jal * DH + sub * VEC);
-    kc2.load(kb + (size_t)jcl * DH + sub * VEC);
-    vc2.load(vb + (size_t)jcl * DH + sub * VEC);
+    CacheVec<TC> knext[2], vnext[2];
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-      const int j = u ? jc : ja;
-      const CacheVec<TC>& kk = u ? kc2 : ka;
-      const CacheVec<TC>& vv = u ? vc2 : va;
-      const bool own = j == pos;  // the row appended this step: take it from qkv with the cache's rounding
+      const int j = min(jb + (2 + u) * SLOTS + slot, Smax - 1);
+      knext[u].load(kb + (size_t)j * DH + sub * VEC);
+      vnext[u].load(vb + (size_t)j * DH + sub * VEC);
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int j = jb + u * SLOTS + slot;
+      const bool own = j == pos;
+      const bool ok = j < S && j >= ks;
       float sc = 0.f;
 #pragma unroll
-      for (int i = 0; i < VEC; ++i) {
-        const float kval = own ? (float)(TC)qv[D + sub * VEC + i] : kk.get(i);
-        sc = fmaf(qr[i], kval, sc);
-      }
+      for (int i = 0; i < VEC; ++i) sc = fmaf(qr[i], own ? kown[i] : kcur[u].get(i), sc);
 #pragma unroll
       for (int o = 1; o < LPK; o <<= 1) sc += __shfl_xor(sc, o, 64);
-      const bool ok = j < S && j >= ks;
-      sc = ok ? sc : -INFINITY;
+      sc = ok ? sc : -INFINITY;  // also discards whatever an out-of-range (uninitialised) row produced
       const float mn = fmaxf(m, sc);
-      const float corr = mn > -INFINITY ? __expf(m - mn) : 1.f;  // m = -inf -> exp(-inf) = 0 (acc, l are 0 anyway)
+      const float corr = mn > -INFINITY ? __expf(m - mn) : 1.f;
       const float p = ok ? __expf(sc - mn) : 0.f;
       l = l * corr + p;
 #pragma unroll
       for (int i = 0; i < VEC; ++i) {
-        const float vval = own ? (float)(TC)qv[2 * D + sub * VEC + i] : vv.get(i);
+        const float vval = ok ? (own ? vown[i] : vcur[u].get(i)) : 0.f;
         acc[i] = fmaf(p, vval, acc[i] * corr);
       }
       m = mn;
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      kcur[u] = knext[u];
+      vcur[u] = vnext[u];
     }
   }
   // merge the 64/LPK key slots of this wave (lanes with equal `sub`)

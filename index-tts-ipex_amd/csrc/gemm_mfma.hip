@@ -5,8 +5,8 @@
 // v_mfma_f32_16x16x32_bf16.  Both operands are k-contiguous in memory (A rows are channels-last activations,
 // W rows are [tap][Cin]), which is exactly the MFMA operand map of cdna_hip_programming.md section 3:
 // lane l holds A[row l&15][k = 8(l>>4) .. +8] and W[n = l&15][k = 8(l>>4) .. +8] as one 16-byte fragment.
-// Workgroup = 4 waves (2 x 2), tile BM x BN, K consumed in 32-channel chunks (a chunk never straddles a
-// tap because Cin % 32 == 0), two chunks per barrier.  Global -> register -> LDS staging with the next
+// Workgroup = 4 waves (2 x 2), tile BM x BN, K consumed in 32-channel chunks per tap (Cin % 8 == 0; the tail chunk of
+// a tap is zero-filled on the A side, so Cin = 24 / 48 of the last BigVGAN stages also run here), two chunks per barrier.  Global -> register -> LDS staging with the next
 // chunk pair requested before the MFMAs of the current one (register double buffering, one barrier per
 // pair).  LDS rows are padded to 80 bytes: bank(20*r) is a conflict-free pattern for ds_read_b128.
 // The conv "shift" is folded into the A-row index (zero / reflect padding, dilation, nearest-upsampled
@@ -45,7 +45,7 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmArgs g) {
   const bf16_t* __restrict__ W = (const bf16_t*)g.W + (size_t)phase * g.N * K;
   const int T = g.T > 0 ? g.T : g.M;
   const int Tin = T / g.in_up;
-  const int cpt = g.Cin / CK;           // chunks per tap
+  const int cpt = (g.Cin + CK - 1) / CK;  // chunks per tap (the last one may be partial)
   const int nchunk = g.taps * cpt;
   const int npair = (nchunk + 1) / 2;
 
@@ -67,7 +67,7 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmArgs g) {
   }
   const bf16_t* w_row[WROWS];
 #pragma unroll
-  for (int p = 0; p < WROWS; ++p) w_row[p] = W + (size_t)min(n0 + lr + 64 * p, g.N - 1) * K + lq * 8;
+  for (int p = 0; p < WROWS; ++p) w_row[p] = W + (size_t)min(n0 + lr + 64 * p, g.N - 1) * K;
 
   u32x4 ra[2][AROWS], rw[2][WROWS];
   auto load_pair = [&](int pr) {
@@ -77,20 +77,23 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmArgs g) {
       const bool live = ch < nchunk;
       const int chc = live ? ch : 0;
       const int tap = chc / cpt, c0 = (chc - tap * cpt) * CK;
+      const bool cok = lq * 8 < g.Cin - c0;   // this lane's 8 channels exist in the tap
+      const int cq = cok ? lq * 8 : 0;        // clamped (in-bounds) column for masked lanes
       const int off = g.phase_shift[phase] + tap * g.dil - g.pad_left;
 #pragma unroll
       for (int p = 0; p < AROWS; ++p) {
         int ts = a_t[p] + off;
         if (g.pad_mode == PAD_REFLECT && a_t[p] >= 0) ts = reflect_idx(ts, T);
-        const bool ok = live && ts >= 0 && ts < T;
+        const bool ok = live && cok && ts >= 0 && ts < T;
         const long r = a_base[p] + (ok ? ts / g.in_up : 0);
-        const u32x4 v = *reinterpret_cast<const u32x4*>(A + r * g.lda + c0 + lq * 8);
+        const u32x4 v = *reinterpret_cast<const u32x4*>(A + r * g.lda + c0 + cq);
         ra[c][p] = ok ? v : u32x4{0u, 0u, 0u, 0u};
       }
 #pragma unroll
       for (int p = 0; p < WROWS; ++p) {
-        const u32x4 v = *reinterpret_cast<const u32x4*>(w_row[p] + (size_t)chc * CK);
-        rw[c][p] = live ? v : u32x4{0u, 0u, 0u, 0u};
+        // masked lanes multiply zeros from A: their W fragment only has to be finite and in bounds
+        const u32x4 v = *reinterpret_cast<const u32x4*>(w_row[p] + (size_t)tap * g.Cin + c0 + cq);
+        rw[c][p] = (live && cok) ? v : u32x4{0u, 0u, 0u, 0u};
       }
     }
   };
@@ -191,7 +194,7 @@ int dispatch(const GemmArgs& g, hipStream_t s) {
 
 bool gemm_mfma_supported(const GemmArgs& g, int ta, int tw, int tc) {
   if (ta != BF16 || tw != BF16 || (tc != BF16 && tc != F32)) return false;
-  if (g.Cin % CK != 0 || g.lda % 8 != 0) return false;
+  if (g.Cin % 8 != 0 || g.lda % 8 != 0) return false;
   if (((uintptr_t)g.A & 15) || ((uintptr_t)g.W & 15)) return false;
   if (g.M < 16) return false;  // tiny M (speaker-conditioning 1x1 convs): the vector kernel is fine
   return true;
