@@ -181,10 +181,11 @@ def main():
         if timed:
             dec_ms[0] += ev[0].elapsed_time(ev[1])
             dec_steps[0] += T - 1
-        lats = []
+        clean = []
         for i in range(B):
             c, n = remove_long_silence(codes[i:i + 1].astype(np.int64), g["stop_mel_token"])
-            lats.append(eng.latent(cond, texts[i], c[0, :int(n[0])]))
+            clean.append(c[0, :int(n[0])])
+        lats = eng.latent_batch(cond, [texts[i] for i in range(B)], clean)
         nsamp = 0
         outs = []
         if all(l.shape[1] == lats[0].shape[1] for l in lats):

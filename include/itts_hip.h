@@ -117,6 +117,12 @@ int itts_gpt_fetch(itts_engine* e, int32_t* codes_host, float* logits_host, itts
 int itts_gpt_latent(itts_engine* e, const float* cond, const int32_t* text_ids_host, int L, const int32_t* codes_host,
                     int T, void* latent_out, itts_stream stream);
 
+/* Same for several sentences at once (concatenated ids / codes with per-sentence lengths): rows are stacked with
+ * left padding and masked keys, so each sentence's latent equals the batch-1 result.  latent_out = [sum T_i, D]. */
+int itts_gpt_latent_batch(itts_engine* e, const float* cond, const int32_t* text_ids_host, const int32_t* text_lens_host,
+                          const int32_t* codes_host, const int32_t* code_lens_host, int nseq, void* latent_out,
+                          itts_stream stream);
+
 /* V1-V5  BigVGAN.forward given the speaker embedding (BigVGAN/models.py:201-250):
  * latent [B, T, gpt_dim] (engine dtype), spk fp32 [B, spk_dim] -> wav fp32 [B, T * prod(up_rates)] */
 int itts_bigvgan(itts_engine* e, const void* latent, const float* spk, int B, int T, float* wav_out, itts_stream stream);

@@ -169,6 +169,13 @@ int itts_gpt_latent(itts_engine* e, const float* cond, const int32_t* text_ids_h
   ENG(e);
   return e->e.gpt_latent(cond, text_ids_host, L, codes_host, T, latent_out, (hipStream_t)s);
 }
+int itts_gpt_latent_batch(itts_engine* e, const float* cond, const int32_t* text_ids_host, const int32_t* text_lens_host,
+                          const int32_t* codes_host, const int32_t* code_lens_host, int nseq, void* latent_out,
+                          itts_stream s) {
+  ENG(e);
+  return e->e.gpt_latent_batch(cond, text_ids_host, text_lens_host, codes_host, code_lens_host, nseq, latent_out,
+                               (hipStream_t)s);
+}
 int itts_bigvgan(itts_engine* e, const void* latent, const float* spk, int B, int T, float* wav_out, itts_stream s) {
   ENG(e);
   return e->e.bigvgan(latent, spk, B, T, wav_out, (hipStream_t)s);

@@ -172,6 +172,8 @@ struct Engine {
   int gpt_fetch(int32_t* codes, float* logits, hipStream_t s);
   int gpt_latent(const float* cond, const int32_t* text_ids, int L, const int32_t* codes, int T, void* latent_out,
                  hipStream_t s);
+  int gpt_latent_batch(const float* cond, const int32_t* text_ids, const int* Ls, const int32_t* codes, const int* Ts,
+                       int nseq, void* latent_out, hipStream_t s);
   int bigvgan(const void* latent, const float* spk, int B, int T, float* wav, hipStream_t s);
   int dvae_decode(const int32_t* codes, int B, int T, void* mel_out, hipStream_t s);
 

@@ -11,6 +11,8 @@
 // pair).  LDS rows are padded to 80 bytes: bank(20*r) is a conflict-free pattern for ds_read_b128.
 // The conv "shift" is folded into the A-row index (zero / reflect padding, dilation, nearest-upsampled
 // source rows), so no im2col buffer ever exists in HBM.
+#include <cstdlib>
+
 #include "itts_kernels.h"
 
 namespace itts {
@@ -29,14 +31,16 @@ __device__ __forceinline__ int reflect_idx(int t, int T) {
   return t;
 }
 
-template <int BM, int BN, typename TC>
+template <int BM, int BN, typename TC, int NBUF>
 __global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmArgs g) {
   constexpr int WM = BM / 2, WN = BN / 2;      // wave tile
   constexpr int MT = WM / 16, NT = WN / 16;    // 16x16 MFMA tiles per wave
   constexpr int AROWS = BM / 64;               // A rows per thread per chunk (256 threads: 64 rows x 4 x 16 B)
   constexpr int WROWS = (BN + 63) / 64;
-  __shared__ __attribute__((aligned(16))) bf16_t sA[2][2][BM][LDSROW];  // [buffer][chunk][row][k]
-  __shared__ __attribute__((aligned(16))) bf16_t sW[2][2][BN][LDSROW];
+  // NBUF = 2: one barrier per chunk pair; NBUF = 1: two barriers but half the LDS -> more workgroups per CU, whose
+  // interleaving hides the global-load latency of this register-staged loop (cdna_hip_programming 'step-3 structure')
+  __shared__ __attribute__((aligned(16))) bf16_t sA[NBUF][2][BM][LDSROW];  // [buffer][chunk][row][k]
+  __shared__ __attribute__((aligned(16))) bf16_t sW[NBUF][2][BN][LDSROW];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN, phase = blockIdx.z;
@@ -119,7 +123,7 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmArgs g) {
   __syncthreads();
   const int fr = lane & 15, fk = (lane >> 4) * 8;
   for (int pr = 0; pr < npair; ++pr) {
-    const int buf = pr & 1;
+    const int buf = NBUF == 2 ? (pr & 1) : 0;
     if (pr + 1 < npair) load_pair(pr + 1);
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
@@ -133,7 +137,8 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmArgs g) {
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
     }
-    if (pr + 1 < npair) store_pair(buf ^ 1);
+    if (NBUF == 1) __syncthreads();  // every wave has consumed the buffer before it is overwritten
+    if (pr + 1 < npair) store_pair(NBUF == 2 ? (buf ^ 1) : 0);
     __syncthreads();
   }
 
@@ -169,10 +174,13 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmArgs g) {
   }
 }
 
+static int g_nbuf = 2;  // tuning knob (ITTS_GEMM_NBUF), read once
+
 template <int BM, int BN, typename TC>
 int launch(const GemmArgs& g, hipStream_t s) {
   dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, g.nphase);
-  hipLaunchKernelGGL((gemm_mfma_kernel<BM, BN, TC>), grid, dim3(256), 0, s, g);
+  if (g_nbuf == 1) hipLaunchKernelGGL((gemm_mfma_kernel<BM, BN, TC, 1>), grid, dim3(256), 0, s, g);
+  else hipLaunchKernelGGL((gemm_mfma_kernel<BM, BN, TC, 2>), grid, dim3(256), 0, s, g);
   ITTS_HIP_CHECK(hipGetLastError());
   return OK;
 }
@@ -201,6 +209,12 @@ bool gemm_mfma_supported(const GemmArgs& g, int ta, int tw, int tc) {
 }
 
 int gemm_mfma(const GemmArgs& g, int ta, int tw, int tc, hipStream_t s) {
+  static const bool once = [] {
+    const char* e = getenv("ITTS_GEMM_NBUF");
+    if (e) g_nbuf = atoi(e) == 1 ? 1 : 2;
+    return true;
+  }();
+  (void)once;
   ITTS_REQUIRE(g.A && g.W && g.C, "gemm_mfma: null pointer");
   ITTS_REQUIRE(gemm_mfma_supported(g, ta, tw, tc), "gemm_mfma: unsupported shape/dtype");
   ITTS_REQUIRE(g.nphase >= 1 && g.nphase <= 8 && g.in_up >= 1, "gemm_mfma: bad phase/upsample");

@@ -423,60 +423,92 @@ int Engine::gpt_fetch(int32_t* codes, float* logits, hipStream_t s) {
   return OK;
 }
 
-int Engine::gpt_latent(const float* cond_dev, const int32_t* text_ids, int L, const int32_t* codes, int T,
-                       void* latent_out, hipStream_t s) {
+// UnifiedVoice.forward(return_latent=True) for one or more sentences in ONE pass.  The reference runs it at batch 1
+// per sentence (infer.py:194-200); sentences are independent, so several are stacked here as left-padded rows
+// ([pad.., cond, text, mel] with the pad keys masked exactly like prepare_gpt_inputs' left padding), which fills the
+// MFMA tiles better without changing any row's result.  out = concatenated [sum T_i, D] latents in the engine dtype.
+int Engine::gpt_latent_batch(const float* cond_dev, const int32_t* text_ids, const int* Ls, const int32_t* codes,
+                             const int* Ts, int nseq, void* latent_out, hipStream_t s) {
   if (!finalized || !gpt.ok) {
     set_error("gpt_latent: GPT weights not bound");
     return E_STATE;
   }
   const itts_config& c = cfg;
-  ITTS_REQUIRE(cond_dev && text_ids && codes && latent_out && L > 0 && T > 0, "gpt_latent: bad arguments");
-  ITTS_REQUIRE(L + 2 <= c.max_text_tokens + 2 && T + 2 <= c.max_mel_tokens + 3, "gpt_latent: sequence too long");
+  ITTS_REQUIRE(cond_dev && text_ids && codes && latent_out && Ls && Ts && nseq > 0, "gpt_latent: bad arguments");
   const int D = c.model_dim, nl = c.cond_latents;
-  const int S = nl + (L + 2) + (T + 2);
-  std::vector<RowDesc> rd(S);
-  int k = 0;
-  for (int i = 0; i < nl; ++i) rd[k++] = {1, i, 0, 0};
-  rd[k++] = {2, c.start_text_token, 0, 0};
-  for (int i = 0; i < L; ++i) {
-    ITTS_REQUIRE(text_ids[i] >= 0 && text_ids[i] <= c.number_text_tokens, "gpt_latent: text id out of range");
-    rd[k++] = {2, text_ids[i], i + 1, 0};
+  int Smax = 0;
+  long Ttot = 0;
+  for (int i = 0; i < nseq; ++i) {
+    ITTS_REQUIRE(Ls[i] > 0 && Ts[i] > 0, "gpt_latent: empty sentence");
+    ITTS_REQUIRE(Ls[i] + 2 <= c.max_text_tokens + 2 && Ts[i] + 2 <= c.max_mel_tokens + 3, "gpt_latent: sequence too long");
+    Smax = std::max(Smax, nl + Ls[i] + 2 + Ts[i] + 2);
+    Ttot += Ts[i];
   }
-  rd[k++] = {2, c.stop_text_token, L + 1, 0};
-  rd[k++] = {3, c.start_mel_token, 0, 0};
-  for (int i = 0; i < T; ++i) {
-    ITTS_REQUIRE(codes[i] >= 0 && codes[i] < c.number_mel_codes, "gpt_latent: mel code out of range");
-    rd[k++] = {3, codes[i], i + 1, 0};
+  std::vector<RowDesc> rd((size_t)nseq * Smax);
+  std::vector<int> kvs(nseq), mel_row(nseq);
+  long to = 0, co = 0;
+  for (int b = 0; b < nseq; ++b) {
+    const int L = Ls[b], T = Ts[b];
+    const int S = nl + L + 2 + T + 2, pad = Smax - S;
+    kvs[b] = pad;
+    RowDesc* r = rd.data() + (size_t)b * Smax;
+    int k = 0;
+    for (int i = 0; i < pad; ++i) r[k++] = {0, 0, 0, 0};
+    for (int i = 0; i < nl; ++i) r[k++] = {1, i, 0, 0};
+    r[k++] = {2, c.start_text_token, 0, 0};
+    for (int i = 0; i < L; ++i) {
+      const int t = text_ids[to + i];
+      ITTS_REQUIRE(t >= 0 && t <= c.number_text_tokens, "gpt_latent: text id out of range");
+      r[k++] = {2, t, i + 1, 0};
+    }
+    r[k++] = {2, c.stop_text_token, L + 1, 0};
+    mel_row[b] = b * Smax + k;  // first mel row (the start token); model.py:578 keeps rows [0, T) of the mel part
+    r[k++] = {3, c.start_mel_token, 0, 0};
+    for (int i = 0; i < T; ++i) {
+      const int m = codes[co + i];
+      ITTS_REQUIRE(m >= 0 && m < c.number_mel_codes, "gpt_latent: mel code out of range");
+      r[k++] = {3, m, i + 1, 0};
+    }
+    r[k++] = {3, c.stop_mel_token, T + 1, 0};
+    to += L;
+    co += T;
   }
-  rd[k++] = {3, c.stop_mel_token, T + 1, 0};
   auto body = [&]() -> int {
     RowDesc* rd_dev = (RowDesc*)alloc(rd.size() * sizeof(RowDesc));
-    float* h = (float*)alloc((size_t)S * D * 4);
-    float* hn = (float*)alloc((size_t)T * D * 4);
+    int* kvs_dev = (int*)alloc((size_t)nseq * 4);
+    float* h = (float*)alloc((size_t)nseq * Smax * D * 4);
+    float* hn = (float*)alloc((size_t)Ttot * D * 4);
     if (!dry) {
       ITTS_HIP_CHECK(hipMemcpyAsync(rd_dev, rd.data(), rd.size() * sizeof(RowDesc), hipMemcpyHostToDevice, s));
+      ITTS_HIP_CHECK(hipMemcpyAsync(kvs_dev, kvs.data(), (size_t)nseq * 4, hipMemcpyHostToDevice, s));
       if (adt == F32)
-        hipLaunchKernelGGL(gpt_embed_rows_kernel<float>, dim3(S), dim3(256), 0, s, h, rd_dev, cond_dev,
+        hipLaunchKernelGGL(gpt_embed_rows_kernel<float>, dim3(nseq * Smax), dim3(256), 0, s, h, rd_dev, cond_dev,
                            (const float*)gpt.text_emb, (const float*)gpt.text_pos, (const float*)gpt.mel_emb,
                            (const float*)gpt.mel_pos, D);
       else
-        hipLaunchKernelGGL(gpt_embed_rows_kernel<bf16_t>, dim3(S), dim3(256), 0, s, h, rd_dev, cond_dev,
+        hipLaunchKernelGGL(gpt_embed_rows_kernel<bf16_t>, dim3(nseq * Smax), dim3(256), 0, s, h, rd_dev, cond_dev,
                            (const bf16_t*)gpt.text_emb, (const bf16_t*)gpt.text_pos, (const bf16_t*)gpt.mel_emb,
                            (const bf16_t*)gpt.mel_pos, D);
       ITTS_HIP_CHECK(hipGetLastError());
     }
-    const bool saved = ds.active;
-    (void)saved;
-    ITTS_TRY(gpt_layers_full(h, 1, S, nullptr, false, s));
-    // mel part = rows [nl + L + 2, +T+2); strip the two tokens added by the forward pass (model.py:578)
-    const float* mel_rows = h + (size_t)(nl + L + 2) * D;
-    K(double_ln(hn, mel_rows, gpt.ln_f.g, gpt.ln_f.b, gpt.final_norm.g, gpt.final_norm.b, T, D, 1e-5f, s));
-    K(cast_copy(latent_out, adt, hn, F32, (long)T * D, s));
+    ITTS_TRY(gpt_layers_full(h, nseq, Smax, nseq > 1 ? kvs_dev : nullptr, false, s));
+    long off = 0;
+    for (int b = 0; b < nseq; ++b) {
+      K(double_ln(hn + off * D, h + (size_t)mel_row[b] * D, gpt.ln_f.g, gpt.ln_f.b, gpt.final_norm.g, gpt.final_norm.b,
+                  Ts[b], D, 1e-5f, s));
+      off += Ts[b];
+    }
+    K(cast_copy(latent_out, adt, hn, F32, Ttot * D, s));
     return OK;
   };
   ITTS_TRY(two_pass(body, s));
-  ITTS_HIP_CHECK(hipStreamSynchronize(s));  // rd is a host buffer
+  ITTS_HIP_CHECK(hipStreamSynchronize(s));  // rd / kvs are host buffers
   return OK;
+}
+
+int Engine::gpt_latent(const float* cond_dev, const int32_t* text_ids, int L, const int32_t* codes, int T,
+                       void* latent_out, hipStream_t s) {
+  return gpt_latent_batch(cond_dev, text_ids, &L, codes, &T, 1, latent_out, s);
 }
 
 }  // namespace itts

@@ -234,6 +234,27 @@ class Engine:
         self._exit()
         return out
 
+    def latent_batch(self, cond: torch.Tensor, texts, codes) -> List[torch.Tensor]:
+        """Several sentences in one pass -> list of latents [1, T_i, D] (views of one buffer)."""
+        ts = [np.ascontiguousarray(t, dtype=np.int32).reshape(-1) for t in texts]
+        cs = [np.ascontiguousarray(c, dtype=np.int32).reshape(-1) for c in codes]
+        tl = np.asarray([t.shape[0] for t in ts], dtype=np.int32)
+        cl = np.asarray([c.shape[0] for c in cs], dtype=np.int32)
+        tcat, ccat = np.concatenate(ts), np.concatenate(cs)
+        cond = cond.to(device=self.device, dtype=torch.float32).contiguous().view(-1, self.ccfg.model_dim)
+        out = torch.empty(int(cl.sum()), self.ccfg.model_dim, dtype=self.tdt, device=self.device)
+        self._enter()
+        L.check(self.lib.itts_gpt_latent_batch(self.h, cond.data_ptr(), tcat.ctypes.data_as(C.c_void_p),
+                                               tl.ctypes.data_as(C.c_void_p), ccat.ctypes.data_as(C.c_void_p),
+                                               cl.ctypes.data_as(C.c_void_p), len(ts), out.data_ptr(), self._s()),
+                "gpt_latent_batch")
+        self._exit()
+        res, o = [], 0
+        for n in cl:
+            res.append(out[o:o + int(n)].unsqueeze(0))
+            o += int(n)
+        return res
+
     def bigvgan(self, latent: torch.Tensor, spk: torch.Tensor) -> torch.Tensor:
         """latent [B, T, D], spk [B, E] -> wav fp32 [B, 1, T*up]."""
         lat = self.to_act(latent)

@@ -72,6 +72,7 @@ _PROTOS = {
     "itts_gpt_status": (i32, [vp, C.POINTER(i32), C.POINTER(i32), vp]),
     "itts_gpt_fetch": (i32, [vp, vp, vp, vp]),
     "itts_gpt_latent": (i32, [vp, vp, vp, i32, vp, i32, vp, vp]),
+    "itts_gpt_latent_batch": (i32, [vp, vp, vp, vp, vp, vp, i32, vp, vp]),
     "itts_bigvgan": (i32, [vp, vp, vp, i32, i32, vp, vp]),
     "itts_dvae_decode": (i32, [vp, vp, i32, i32, vp, vp]),
     "itts_debug_fetch": (i64, [vp, C.c_char_p, vp, i64]),

@@ -136,6 +136,19 @@ def test_latent(eng32, eng16, gold):
     assert rms_rel(lat16, g["latent"]) < 3e-2
 
 
+def test_latent_batch_equals_single(eng32, gold):
+    """Stacked (left-padded, masked) sentences give each sentence its batch-1 latent."""
+    c, g = gold("micro_conditioning"), gold("micro_latent")
+    cond = torch.from_numpy(c["cond"])
+    t2 = synth.text_ids(7, 3, CFG.gpt.number_text_tokens).astype(np.int32)
+    c2 = synth.text_ids(13, 4, CFG.gpt.stop_mel_token - 1).astype(np.int32)
+    one = eng32.latent(cond, g["text"], g["codes"])
+    two = eng32.latent(cond, t2, c2)
+    both = eng32.latent_batch(cond, [g["text"], t2], [g["codes"], c2])
+    assert relerr(both[0], one.cpu().numpy()) < 2e-5 and relerr(both[1], two.cpu().numpy()) < 2e-5
+    assert relerr(both[0], g["latent"]) < 1e-4
+
+
 def test_ecapa(eng32, eng16, gold):
     g = gold("micro_ecapa")
     mel = torch.from_numpy(g["mel"]).transpose(1, 2)
