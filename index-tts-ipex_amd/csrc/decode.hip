@@ -99,8 +99,8 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvArgs g) {
     if (ln) {
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
-        gam[i] = g.ln_gamma[k0 + i];
-        bet[i] = g.ln_beta[k0 + i];
+        gam[i] = g.ln_gamma ? g.ln_gamma[k0 + i] : 1.f;
+        bet[i] = g.ln_beta ? g.ln_beta[k0 + i] : 0.f;
       }
     }
 #pragma unroll
@@ -169,7 +169,8 @@ __global__ __launch_bounds__(256) void double_ln_kernel(float* __restrict__ y, c
     }
     const float rstd = rsqrtf(block_sum(v) / D + eps);
     for (int i = tid; i < D; i += 256) {
-      const float o = ((pass ? buf[i] : xr[i]) - mean) * rstd * g[i] + bb[i];
+      float o = ((pass ? buf[i] : xr[i]) - mean) * rstd;
+      if (g) o = o * g[i] + bb[i];
       if (pass) y[(size_t)row * D + i] = o; else buf[i] = o;
     }
     __syncthreads();

@@ -100,11 +100,13 @@ __global__ __launch_bounds__(256) void gemv2_kernel(GemvArgs g) {
     if (i < BK) {
       x[j] = *reinterpret_cast<const float4*>(g.X + i);
       const int col = i % K;
-      if (ln) {
+      gm[j] = gm2[j] = make_float4(1.f, 1.f, 1.f, 1.f);
+      bt[j] = bt2[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (ln && g.ln_gamma) {  // null = plain normalisation (affine folded into W by the packer)
         gm[j] = *reinterpret_cast<const float4*>(g.ln_gamma + col);
         bt[j] = *reinterpret_cast<const float4*>(g.ln_beta + col);
       }
-      if (ln2) {
+      if (ln2 && g.ln2_gamma) {
         gm2[j] = *reinterpret_cast<const float4*>(g.ln2_gamma + col);
         bt2[j] = *reinterpret_cast<const float4*>(g.ln2_beta + col);
       }
@@ -247,7 +249,9 @@ __device__ __forceinline__ float dot2(uint32_t a, uint32_t b, float c) {
   return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, a), __builtin_bit_cast(bf16x2_t, b), c, false);
 }
 
-// PRO: 0 plain, 1 LayerNorm, 2 LayerNorm o LayerNorm.  XBF: X is bf16 [B, K] (else fp32).  YBF: Y is bf16.
+// PRO: 0 plain, 1 LayerNorm without affine (gamma/beta are folded into W by the packer), 2 LayerNorm(affine) then
+// LayerNorm without affine (ln_f, then final_norm folded into mel_head).  XBF: X is bf16 [B, K].  YBF: Y is bf16.
+// (A wave-specialised variant - dedicated activation waves - was measured slower: profiles/README.md.)
 // Every batch row uses the SAME thread <-> element mapping, so a row's result does not depend on its position in
 // the batch (the padding/batch invariance the reference's tests/padding_test.py checks).
 template <int NB, int RPW, int NCH, int PRO, bool XBF, bool YBF>
@@ -261,7 +265,7 @@ __global__ __launch_bounds__(256) void gemv_bf16_kernel(GemvArgs g) {
   const int n0 = (blockIdx.x * 4 + wave) * RPW;
   // ---- 1. activations (+ LayerNorm parameters) first, weights second; all unconditional ----
   u32x4 xr[NB][KCH];  // XBF: 8 bf16; else 4 floats
-  f32x4 gm[PRO >= 1 ? KCH : 1], bt[PRO >= 1 ? KCH : 1], gm2[PRO == 2 ? KCH : 1], bt2[PRO == 2 ? KCH : 1];
+  f32x4 gm[PRO == 2 ? KCH : 1], bt[PRO == 2 ? KCH : 1];
   bool xok[KCH];
 #pragma unroll
   for (int j = 0; j < KCH; ++j) {
@@ -274,13 +278,9 @@ __global__ __launch_bounds__(256) void gemv_bf16_kernel(GemvArgs g) {
       if (XBF) xr[b][j] = *reinterpret_cast<const u32x4*>((const bf16_t*)g.X + ro);
       else xr[b][j] = *reinterpret_cast<const u32x4*>(g.X + ro);
     }
-    if (PRO >= 1) {
+    if (PRO == 2) {
       gm[j] = *reinterpret_cast<const f32x4*>(g.ln_gamma + ic);
       bt[j] = *reinterpret_cast<const f32x4*>(g.ln_beta + ic);
-      if (PRO == 2) {
-        gm2[j] = *reinterpret_cast<const f32x4*>(g.ln2_gamma + ic);
-        bt2[j] = *reinterpret_cast<const f32x4*>(g.ln2_beta + ic);
-      }
     }
   }
   float pivot[NB];
@@ -339,11 +339,13 @@ __global__ __launch_bounds__(256) void gemv_bf16_kernel(GemvArgs g) {
         const float mean = (pass == 0 ? pivot[b] : 0.f) + md;
         const float rstd = rsqrtf(fmaxf(Q / K - md * md, 0.f) + g.ln_eps);
 #pragma unroll
-        for (int j = 0; j < KCH; ++j) {
-          const f32x4 G = pass ? gm2[j] : gm[j], Bt = pass ? bt2[j] : bt[j];
+        for (int j = 0; j < KCH; ++j)
 #pragma unroll
-          for (int e = 0; e < 4; ++e) xv[b][j][e] = (xv[b][j][e] - mean) * rstd * G[e] + Bt[e];
-        }
+          for (int e = 0; e < 4; ++e) {
+            float v = (xv[b][j][e] - mean) * rstd;
+            if (PRO == 2 && pass == 0) v = v * gm[j][e] + bt[j][e];
+            xv[b][j][e] = v;
+          }
       }
     }
 #pragma unroll

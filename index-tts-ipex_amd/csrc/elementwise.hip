@@ -37,7 +37,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(TO* __restrict__ y, cons
   const float rstd = rsqrtf(wave_sum(v) / D + eps);
   TO* yr = y + (size_t)row * ldy;
   for (int i = lane; i < D; i += 64) {
-    float o = (ldf(xr + i) - mean) * rstd * g[i] + bta[i];
+    float o = (ldf(xr + i) - mean) * rstd;
+    if (g) o = o * g[i] + bta[i];
     stf(yr + i, act_apply(act, o));
   }
 }
@@ -287,7 +288,7 @@ inline int nblk(long n, int bs = 256) { return (int)((n + bs - 1) / bs); }
 
 int layernorm(void* y, int ty, const void* x, int tx, const float* gamma, const float* beta, int rows, int D, int ldx,
               int ldy, float eps, int act, hipStream_t s) {
-  ITTS_REQUIRE(y && x && gamma && beta && rows > 0 && D > 0, "layernorm");
+  ITTS_REQUIRE(y && x && rows > 0 && D > 0 && (gamma == nullptr) == (beta == nullptr), "layernorm");
   dim3 grid((rows + 3) / 4), blk(256);
 #define LN(TI, TO) \
   hipLaunchKernelGGL((layernorm_kernel<TI, TO>), grid, blk, 0, s, (TO*)y, (const TI*)x, gamma, beta, rows, D, ldx, ldy, eps, act)

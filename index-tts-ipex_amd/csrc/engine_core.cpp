@@ -83,7 +83,7 @@ int Engine::conv(GemmArgs& g, int ta, int tw, int tc, hipStream_t s) {
 
 int Engine::ln(void* y, int ty, const void* x, int tx, const Norm& n, int rows, int D, hipStream_t s, int act, float eps) {
   if (dry) return OK;
-  return layernorm(y, ty, x, tx, n.g, n.b, rows, D, D, D, eps, act, s);
+  return layernorm(y, ty, x, tx, n.g, n.b, rows, D, D, D, eps, act, s);  // null gamma/beta = no affine
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -224,8 +224,7 @@ int Engine::finalize() {
     for (int i = 0; i < c.layers; ++i) {
       const std::string p = "gpt.h." + std::to_string(i) + ".";
       GptLayerW L;
-      L.ln1 = r.norm(p + "ln_1", D);
-      L.ln2 = r.norm(p + "ln_2", D);
+      // ln_1 / ln_2 gamma,beta are folded into c_attn / c_fc by the packer (L.ln1 / L.ln2 stay null = plain normalise)
       L.attn = r.lin(p + "attn.c_attn", wdt, 3 * D, D);
       L.proj = r.lin(p + "attn.c_proj", wdt, D, D);
       L.fc = r.lin(p + "mlp.c_fc", wdt, 4 * D, D);

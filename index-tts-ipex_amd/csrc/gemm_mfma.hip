@@ -174,7 +174,7 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmArgs g) {
   }
 }
 
-static int g_nbuf = 2;  // tuning knob (ITTS_GEMM_NBUF), read once
+static int g_nbuf = 1;  // 1 = single LDS buffer (more workgroups per CU; measured faster end to end), ITTS_GEMM_NBUF=2 to A/B
 
 template <int BM, int BN, typename TC>
 int launch(const GemmArgs& g, hipStream_t s) {
@@ -211,7 +211,7 @@ bool gemm_mfma_supported(const GemmArgs& g, int ta, int tw, int tc) {
 int gemm_mfma(const GemmArgs& g, int ta, int tw, int tc, hipStream_t s) {
   static const bool once = [] {
     const char* e = getenv("ITTS_GEMM_NBUF");
-    if (e) g_nbuf = atoi(e) == 1 ? 1 : 2;
+    if (e) g_nbuf = atoi(e) == 2 ? 2 : 1;
     return true;
   }();
   (void)once;

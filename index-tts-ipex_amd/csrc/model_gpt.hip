@@ -239,14 +239,14 @@ int Engine::head_and_sample(hipStream_t s) {
   g.prologue = 2;
   g.ln_gamma = gpt.ln_f.g;
   g.ln_beta = gpt.ln_f.b;
-  g.ln2_gamma = gpt.final_norm.g;
-  g.ln2_beta = gpt.final_norm.b;
+  g.ln2_gamma = nullptr;  // final_norm's affine is folded into mel_head by the packer
+  g.ln2_beta = nullptr;
   if (adt == BF16 && gemv_bf16_supported(g)) {
     ITTS_TRY(gemv_bf16(g, s));
   } else if (gemv2_supported(g)) {
     ITTS_TRY(gemv2(g, gpt.head.dt, s));
   } else {
-    ITTS_TRY(double_ln(ds.hn, ds.h, gpt.ln_f.g, gpt.ln_f.b, gpt.final_norm.g, gpt.final_norm.b, B, D, 1e-5f, s));
+    ITTS_TRY(double_ln(ds.hn, ds.h, gpt.ln_f.g, gpt.ln_f.b, nullptr, nullptr, B, D, 1e-5f, s));
     g.X = ds.hn;
     g.prologue = 0;
     ITTS_TRY(gemv(g, gpt.head.dt, s));

@@ -57,6 +57,12 @@ def convT_w(w: np.ndarray, u: int, p: int) -> np.ndarray:
     return out
 
 
+def fold_ln(w: np.ndarray, b: np.ndarray, gamma: np.ndarray, beta: np.ndarray):
+    """(W, c) applied to LayerNorm output g*z + b  ->  (W diag(g), W b + c) applied to the plain normalised z."""
+    w64 = w.astype(np.float64)
+    return (w64 * gamma.astype(np.float64)[None, :]).astype(np.float32), (b.astype(np.float64) + w64 @ beta.astype(np.float64)).astype(np.float32)
+
+
 def bn_fold(sd, name: str, eps: float = 1e-5):
     sc = sd[name + ".weight"] / np.sqrt(sd[name + ".running_var"] + eps)
     sh = sd[name + ".bias"] - sd[name + ".running_mean"] * sc
@@ -120,20 +126,24 @@ def pack_gpt(sd: Dict[str, np.ndarray], cfg) -> Packed:
         P[d + "ff2.weight"] = ("w", w2)
         P[d + "ff2.bias"] = ("f", sd[s + "1.2.bias"])
     P["perc.norm.gamma"] = ("f", sd[pe + "norm.gamma"])
-    # GPT-2 stack (inference_model.* aliases of a post-init state dict are ignored: SURVEY 3.1 step 3)
+    # GPT-2 stack (inference_model.* aliases of a post-init state dict are ignored: SURVEY 3.1 step 3).
+    # ln_1 / ln_2 affine parameters are folded into c_attn / c_fc:  W (g*z + b) + c = (W diag(g)) z + (W b + c), so the
+    # decode GEMV only normalises (no gamma/beta traffic in the per-token loop); same fold for final_norm -> mel_head.
     for i in range(g["layers"]):
         s = f"gpt.h.{i}."
-        for nn in ("ln_1", "ln_2"):
-            P[s + nn + ".weight"] = ("f", sd[s + nn + ".weight"])
-            P[s + nn + ".bias"] = ("f", sd[s + nn + ".bias"])
-        for nn in ("attn.c_attn", "attn.c_proj", "mlp.c_fc", "mlp.c_proj"):
-            P[s + nn + ".weight"] = ("w", np.ascontiguousarray(sd[s + nn + ".weight"].T))
-            P[s + nn + ".bias"] = ("f", sd[s + nn + ".bias"])
+        for nn, ln in (("attn.c_attn", "ln_1"), ("attn.c_proj", None), ("mlp.c_fc", "ln_2"), ("mlp.c_proj", None)):
+            w = np.ascontiguousarray(sd[s + nn + ".weight"].T)  # [out, in]
+            b = sd[s + nn + ".bias"]
+            if ln is not None:
+                w, b = fold_ln(w, b, sd[s + ln + ".weight"], sd[s + ln + ".bias"])
+            P[s + nn + ".weight"] = ("w", w)
+            P[s + nn + ".bias"] = ("f", b)
     for nn in ("weight", "bias"):
         P["gpt.ln_f." + nn] = ("f", sd["gpt.ln_f." + nn])
         P["gpt.final_norm." + nn] = ("f", sd["final_norm." + nn])
-    P["gpt.mel_head.weight"] = ("w", sd["mel_head.weight"])
-    P["gpt.mel_head.bias"] = ("f", sd["mel_head.bias"])
+    hw, hb = fold_ln(sd["mel_head.weight"], sd["mel_head.bias"], sd["final_norm.weight"], sd["final_norm.bias"])
+    P["gpt.mel_head.weight"] = ("w", hw)
+    P["gpt.mel_head.bias"] = ("f", hb)
     P["gpt.text_embedding"] = ("w", sd["text_embedding.weight"])
     P["gpt.mel_embedding"] = ("w", sd["mel_embedding.weight"])
     P["gpt.mel_pos"] = ("w", sd["mel_pos_embedding.emb.weight"])

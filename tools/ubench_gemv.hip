@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
+#include <algorithm>
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1);} } while (0)
 
@@ -325,6 +326,126 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemv4(float* __restrict__ Y, con
         for (int b = 0; b < NB; ++b) Y[(size_t)b * N + n0 + r] = acc[r][b];
 }
 
+template <int RPW, int NCH, int NB, bool LN, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void k_gemv4s(unsigned long long* __restrict__ STAMP, float* __restrict__ Y, const float* __restrict__ X,
+                                                      const unsigned short* __restrict__ W, const float* __restrict__ gam,
+                                                      const float* __restrict__ bet, int N, int K) {
+  constexpr int NT_ = WAVES * 64;
+  constexpr int XCH = (NB * NCH * 512 + NT_ * 4 - 1) / (NT_ * 4);
+  extern __shared__ __attribute__((aligned(16))) float sx[];
+  __shared__ float red[WAVES][2 * NB];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  unsigned long long st[8];
+  { unsigned long long t; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory"); if (lane == 0) st[0] = t; }
+  const int n0 = (blockIdx.x * WAVES + wave) * RPW, BK = NB * K;
+  float4 x[XCH], gm[XCH], bt[XCH];
+  int xb[XCH];
+  bool xok[XCH];
+#pragma unroll
+  for (int j = 0; j < XCH; ++j) {
+    const int i = tid * 4 + j * NT_ * 4;
+    xok[j] = i < BK;
+    const int ic = xok[j] ? i : BK - 4;
+    xb[j] = ic / K;
+    x[j] = *reinterpret_cast<const float4*>(X + ic);
+    if (LN) { const int col = ic - xb[j] * K; gm[j] = *reinterpret_cast<const float4*>(gam + col); bt[j] = *reinterpret_cast<const float4*>(bet + col); }
+  }
+  float pivot[NB];
+#pragma unroll
+  for (int b = 0; b < NB; ++b) pivot[b] = LN ? X[(size_t)b * K] : 0.f;
+  u32x4 w[RPW][NCH];
+  const int klast = (NCH - 1) * 512 + lane * 8;
+  const bool kok = klast < K;
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int k = c == NCH - 1 ? (kok ? klast : K - 8) : c * 512 + lane * 8;
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) w[r][c] = *reinterpret_cast<const u32x4*>(W + (size_t)min(n0 + r, N - 1) * K + k);
+  }
+  { unsigned long long t; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory"); if (lane == 0) st[1] = t; }
+  { float probe = x[0].x; asm volatile("" :: "v"(probe)); }
+  { unsigned long long t; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory"); if (lane == 0) st[2] = t; }
+  if (LN) {
+    float s[NB], q[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) s[b] = q[b] = 0.f;
+#pragma unroll
+    for (int j = 0; j < XCH; ++j) {
+      const float v[4] = {x[j].x, x[j].y, x[j].z, x[j].w};
+#pragma unroll
+      for (int bb = 0; bb < NB; ++bb) {
+        const bool m = xok[j] && xb[j] == bb;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const float d = m ? v[e] - pivot[bb] : 0.f; s[bb] += d; q[bb] = fmaf(d, d, q[bb]); }
+      }
+    }
+#pragma unroll
+    for (int b = 0; b < NB; ++b) { s[b] = wsum_dpp(s[b]); q[b] = wsum_dpp(q[b]); }
+    if (lane == 0)
+#pragma unroll
+      for (int b = 0; b < NB; ++b) { red[wave][2 * b] = s[b]; red[wave][2 * b + 1] = q[b]; }
+    __syncthreads();
+    float mean[NB], rstd[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      float S = 0, Q = 0;
+#pragma unroll
+      for (int ww = 0; ww < WAVES; ++ww) { S += red[ww][2 * b]; Q += red[ww][2 * b + 1]; }
+      const float md = S / K; mean[b] = pivot[b] + md; rstd[b] = rsqrtf(fmaxf(Q / K - md * md, 0.f) + 1e-5f);
+    }
+#pragma unroll
+    for (int j = 0; j < XCH; ++j) {
+      float m = mean[0], r = rstd[0];
+#pragma unroll
+      for (int bb = 1; bb < NB; ++bb) { m = xb[j] == bb ? mean[bb] : m; r = xb[j] == bb ? rstd[bb] : r; }
+      x[j].x = (x[j].x - m) * r * gm[j].x + bt[j].x; x[j].y = (x[j].y - m) * r * gm[j].y + bt[j].y;
+      x[j].z = (x[j].z - m) * r * gm[j].z + bt[j].z; x[j].w = (x[j].w - m) * r * gm[j].w + bt[j].w;
+    }
+  }
+  { unsigned long long t; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory"); if (lane == 0) st[3] = t; }
+#pragma unroll
+  for (int j = 0; j < XCH; ++j) { const int i = tid * 4 + j * NT_ * 4; if (xok[j]) *reinterpret_cast<float4*>(sx + i) = x[j]; }
+  __syncthreads();
+  { unsigned long long t; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory"); if (lane == 0) st[4] = t; }
+
+  float acc[RPW][NB];
+#pragma unroll
+  for (int r = 0; r < RPW; ++r)
+#pragma unroll
+    for (int b = 0; b < NB; ++b) acc[r][b] = 0.f;
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int k = c == NCH - 1 ? (kok ? klast : K - 8) : c * 512 + lane * 8;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      const float4 a = *reinterpret_cast<const float4*>(sx + b * K + k), bb = *reinterpret_cast<const float4*>(sx + b * K + k + 4);
+      float xv[8] = {a.x, a.y, a.z, a.w, bb.x, bb.y, bb.z, bb.w};
+      if (c == NCH - 1)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) xv[i] = kok ? xv[i] : 0.f;
+#pragma unroll
+      for (int r = 0; r < RPW; ++r)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[r][b] = fmaf(xv[i], bf(w[r][c][i >> 1], i & 1), acc[r][b]);
+    }
+  }
+  { unsigned long long t; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory"); if (lane == 0) st[5] = t; }
+#pragma unroll
+  for (int r = 0; r < RPW; ++r)
+#pragma unroll
+    for (int b = 0; b < NB; ++b) acc[r][b] = wsum_dpp(acc[r][b]);
+  { unsigned long long t; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory"); if (lane == 0) st[6] = t; }
+
+  if (lane == 0)
+#pragma unroll
+    for (int r = 0; r < RPW; ++r)
+      if (n0 + r < N)
+#pragma unroll
+        for (int b = 0; b < NB; ++b) Y[(size_t)b * N + n0 + r] = acc[r][b];
+  { unsigned long long t; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory"); if (lane == 0) st[7] = t; }
+  if (lane == 0 && wave == 0) for (int i = 0; i < 8; ++i) STAMP[(size_t)blockIdx.x * 8 + i] = st[i];
+}
+
 template <typename F>
 float timeit(F launch, int reps, hipStream_t s) {
   hipEvent_t a, b;
@@ -343,40 +464,42 @@ float timeit(F launch, int reps, hipStream_t s) {
 }
 
 int main() {
-  const int REP = 24;
   hipStream_t s; CK(hipStreamCreate(&s));
-  const size_t maxW = (size_t)8194 * 5120;
-  unsigned short* W; CK(hipMalloc(&W, REP * maxW * 2)); CK(hipMemset(W, 0x3c, REP * maxW * 2));
-  float *X, *Y, *g, *b;
-  CK(hipMalloc(&X, (size_t)1100 * 4 * 5120 * 4)); CK(hipMalloc(&Y, 4 * 8194 * 4 * REP)); CK(hipMalloc(&g, 5120 * 4)); CK(hipMalloc(&b, 5120 * 4));
-  CK(hipMemset(X, 0, (size_t)1100 * 4 * 5120 * 4)); CK(hipMemset(g, 0, 5120 * 4)); CK(hipMemset(b, 0, 5120 * 4));
-  printf("null kernel (480x256): %.2f us\n", timeit([&](int) { hipLaunchKernelGGL(k_null, dim3(480), dim3(256), 0, s, Y); }, REP, s));
-#define RUN(N, K, RPW, NCH, NB, MODE, NT, WAVES)                                                                          \
-  {                                                                                                                       \
-    const int blocks = (N + RPW * WAVES - 1) / (RPW * WAVES);                                                             \
-    float us = timeit([&](int i) { hipLaunchKernelGGL((k_gemv<RPW, NCH, NB, MODE, NT, WAVES>), dim3(blocks), dim3(WAVES * 64), \
-                                   NB * K * 4, s, Y + (size_t)i * 4 * 8194, X, W + (size_t)i * maxW, g, b, N, K); }, REP, s); \
-    printf("N=%5d K=%5d RPW=%d NB=%d MODE=%d NT=%d WAVES=%d blocks=%4d : %6.2f us  %7.1f GB/s\n", N, K, RPW, NB, MODE, NT, WAVES, \
-           blocks, us, (double)N * K * 2 / us / 1e3);                                                                     \
+  const int N = 3840, K = 1280, REP = 60, blocks = N / 8;
+  const size_t slab = (size_t)N * K;
+  unsigned short* W; CK(hipMalloc(&W, REP * slab * 2)); CK(hipMemset(W, 0x3c, REP * slab * 2));
+  float *X, *Y, *g, *b; unsigned long long* ST;
+  CK(hipMalloc(&X, 4 * 5120 * 4)); CK(hipMalloc(&Y, (size_t)4 * 8194 * 4 * REP)); CK(hipMalloc(&g, 5120 * 4)); CK(hipMalloc(&b, 5120 * 4));
+  CK(hipMalloc(&ST, (size_t)REP * blocks * 8 * 8));
+  CK(hipMemset(X, 0, 4 * 5120 * 4)); CK(hipMemset(g, 0, 5120 * 4)); CK(hipMemset(b, 0, 5120 * 4));
+  hipLaunchKernelGGL(k_set, dim3(1), dim3(1), 0, s, 0); CK(hipStreamSynchronize(s));
+  float us = timeit([&](int i) { hipLaunchKernelGGL((k_gemv4s<2, 3, 2, true, 4>), dim3(blocks), dim3(256), 2 * K * 4, s, ST + (size_t)i * blocks * 8,
+                                 Y + (size_t)i * 4 * 8194, X, W + (size_t)i * slab, g, b, N, K); }, REP, s);
+  printf("stamped kernel %.2f us/launch\n", us);
+  std::vector<unsigned long long> h((size_t)REP * blocks * 8);
+  CK(hipMemcpy(h.data(), ST, h.size() * 8, hipMemcpyDeviceToHost));
+  const char* names[] = {"start", "loads issued", "X arrived", "LN done", "LDS+barrier", "dot done (W arrived)", "reduced", "end"};
+  // s_memtime bases differ per XCD: only differences inside one block / one XCD group (blockIdx % 8) are meaningful
+  for (int ph = 1; ph < 8; ++ph) {
+    std::vector<double> v;
+    for (int r = 10; r < REP; ++r)
+      for (int bl = 0; bl < blocks; ++bl) v.push_back((double)(h[((size_t)r * blocks + bl) * 8 + ph] - h[((size_t)r * blocks + bl) * 8]));
+    std::sort(v.begin(), v.end());
+    printf("%-22s since own start: median %6.0f  p10 %6.0f  p90 %6.0f ticks\n", names[ph], v[v.size() / 2], v[v.size() / 10], v[v.size() * 9 / 10]);
   }
-#define RUN3(N, K, RPW, NCH, NB, LN, WAVES)                                                                             \
-  {                                                                                                                       \
-    const int blocks = (N + RPW * WAVES - 1) / (RPW * WAVES);                                                             \
-    float us = timeit([&](int i) { hipLaunchKernelGGL((k_gemv3<RPW, NCH, NB, LN, WAVES>), dim3(blocks), dim3(WAVES * 64), \
-                                   NB * K * 4, s, Y + (size_t)i * 4 * 8194, X, W + (size_t)i * maxW, g, b, N, K); }, REP, s); \
-    printf("[X-first] N=%5d K=%5d RPW=%d NB=%d LN=%d WAVES=%d blocks=%4d : %6.2f us  %7.1f GB/s\n", N, K, RPW, NB, LN, WAVES, \
-           blocks, us, (double)N * K * 2 / us / 1e3);                                                                     \
+  for (int x = 0; x < 8; x += 7) {
+    std::vector<double> skew, span, gap;
+    for (int r = 10; r < REP; ++r) {
+      unsigned long long t0 = ~0ull, t1 = 0, e1 = 0, ep = 0;
+      for (int bl = x; bl < blocks; bl += 8) {
+        t0 = std::min(t0, h[((size_t)r * blocks + bl) * 8]); t1 = std::max(t1, h[((size_t)r * blocks + bl) * 8]);
+        e1 = std::max(e1, h[((size_t)r * blocks + bl) * 8 + 7]); ep = std::max(ep, h[((size_t)(r - 1) * blocks + bl) * 8 + 7]);
+      }
+      skew.push_back((double)(t1 - t0)); span.push_back((double)(e1 - t0)); gap.push_back((double)t0 - (double)ep);
+    }
+    std::sort(skew.begin(), skew.end()); std::sort(span.begin(), span.end()); std::sort(gap.begin(), gap.end());
+    printf("XCD group %d: block start skew %6.0f, first start -> last end %6.0f, previous kernel last end -> first start %6.0f ticks\n", x,
+           skew[skew.size() / 2], span[span.size() / 2], gap[gap.size() / 2]);
   }
-#define RUN4(N, K, RPW, NCH, NB, LN, WAVES)                                                                             \
-  {                                                                                                                       \
-    const int blocks = (N + RPW * WAVES - 1) / (RPW * WAVES);                                                             \
-    float us = timeit([&](int i) { hipLaunchKernelGGL((k_gemv4<RPW, NCH, NB, LN, WAVES>), dim3(blocks), dim3(WAVES * 64), \
-                                   NB * K * 4, s, Y + (size_t)i * 4 * 8194, X, W + (size_t)i * maxW, g, b, N, K); }, REP, s); \
-    printf("[branch-free] N=%5d K=%5d RPW=%d NB=%d LN=%d WAVES=%d blocks=%4d : %6.2f us  %7.1f GB/s\n", N, K, RPW, NB, LN, WAVES, \
-           blocks, us, (double)N * K * 2 / us / 1e3);                                                                     \
-  }
-  RUN(3840, 1280, 2, 3, 2, 0, false, 4)
-  RUN4(3840, 1280, 2, 3, 1, false, 4) RUN4(3840, 1280, 2, 3, 2, false, 4) RUN4(3840, 1280, 2, 3, 4, false, 4)
-  RUN4(3840, 1280, 2, 3, 1, true, 4) RUN4(3840, 1280, 2, 3, 2, true, 4) RUN4(3840, 1280, 2, 3, 4, true, 4)
   return 0;
 }
