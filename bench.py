@@ -43,6 +43,7 @@ def parse():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--micro", action="store_true", help="tiny config (plumbing check)")
+    ap.add_argument("--no-graph", action="store_true", help="eager decode launches (for rocprofv3 --pmc passes)")
     return ap.parse_args()
 
 
@@ -73,7 +74,13 @@ def build_engine_dp(cfg, dtype, device, rank, world):
             arena = ieng.WeightArena.__new__(ieng.WeightArena)
             arena.dtype, arena.manifest, arena.nbytes = eng.dt, meta[0], meta[1]
             arena.buf = torch.empty(meta[1], dtype=torch.uint8, device=eng.device)
-        dist.broadcast(arena.buf, src=0)
+        if dist.get_backend() == "nccl":
+            dist.broadcast(arena.buf, src=0)  # RCCL over xGMI
+        else:  # gloo rehearsal on a shared GPU: stage through the host
+            host = arena.buf.cpu() if rank == 0 else torch.empty(meta[1], dtype=torch.uint8)
+            dist.broadcast(host, src=0)
+            if rank != 0:
+                arena.buf.copy_(host)
         eng.load_packed(None, arena=arena)
     eng.finalize()
     return eng
@@ -145,8 +152,14 @@ def main():
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        backend = os.environ.get("ITTS_DIST_BACKEND", "nccl")  # "gloo": rehearse N ranks on a one-GPU box
+        if backend != "nccl":
+            local = local % max(torch.cuda.device_count(), 1)
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+        else:
+            dist.init_process_group(backend)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
     from itts_hip import config as icfg
@@ -159,6 +172,9 @@ def main():
     device = f"cuda:{local}"
     eng = build_engine_dp(cfg, a.dtype, device, rank, world)
     from itts_hip.infer_core import remove_long_silence
+
+    if a.no_graph:
+        eng.debug(no_graph=True)
 
     L, T, NS, BU = a.text_tokens, a.mel_tokens, a.sentences, a.batch
     B = BU * NS
@@ -216,10 +232,10 @@ def main():
         samples += step(True)
     sync_all()
     dt = time.perf_counter() - t0
-    tot = torch.tensor([dt, float(samples)], dtype=torch.float64, device=device)
     if world > 1:
         import torch.distributed as dist
 
+        tot = torch.tensor([dt, float(samples)], dtype=torch.float64, device=device if dist.get_backend() == "nccl" else "cpu")
         tmax = tot.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
