@@ -439,7 +439,10 @@ template <> struct CacheVec<float> {
   __device__ __forceinline__ float get(int i) const { return (&raw.x)[i]; }
 };
 
-template <typename TC, typename TO>
+// NIT = key pairs per slot held in registers (NIT * 2 * SLOTS keys: 768 with bf16 at NIT = 3).  The first pair is
+// requested before any device scalar is read, the rest as soon as the sequence length is known, all before the first
+// use: the whole cache read costs two overlapped memory latencies instead of one per iteration.
+template <typename TC, typename TO, int NIT>
 __global__ __launch_bounds__(1024) void decode_attn2_kernel(TO* __restrict__ ctx, const float* __restrict__ qkv,
                                                             TC* __restrict__ kc, TC* __restrict__ vc,
                                                             const int* __restrict__ len, const int* __restrict__ kv_start,
@@ -454,14 +457,14 @@ __global__ __launch_bounds__(1024) void decode_attn2_kernel(TO* __restrict__ ctx
   TC* kb = kc + ((size_t)b * H + h) * Smax * DH;
   TC* vb = vc + ((size_t)b * H + h) * Smax * DH;
   const int slot = tid / LPK, sub = tid % LPK;
-  // (a) the first two key rows of every slot are requested before ANYTHING else: their addresses depend on no
+  // (a) the first pair of key/value rows of this slot, requested before ANYTHING else: their addresses depend on no
   //     device scalar (rows are clamped to the cache capacity; rows >= S are masked out below)
-  CacheVec<TC> kcur[2], vcur[2];
+  CacheVec<TC> kr[2 * NIT], vr[2 * NIT];
 #pragma unroll
   for (int u = 0; u < 2; ++u) {
     const int j = min(u * SLOTS + slot, Smax - 1);
-    kcur[u].load(kb + (size_t)j * DH + sub * VEC);
-    vcur[u].load(vb + (size_t)j * DH + sub * VEC);
+    kr[u].load(kb + (size_t)j * DH + sub * VEC);
+    vr[u].load(vb + (size_t)j * DH + sub * VEC);
   }
   // (b) per-row scalars, the query, and the K/V append of this step
   const int pos = prefix[0] + len[b];
@@ -481,46 +484,55 @@ __global__ __launch_bounds__(1024) void decode_attn2_kernel(TO* __restrict__ ctx
     kown[i] = (float)(TC)qv[D + sub * VEC + i];
     vown[i] = (float)(TC)qv[2 * D + sub * VEC + i];
   }
+  // (c) now that S is known: request every remaining row of the sequence at once (one more memory latency in total)
+#pragma unroll
+  for (int u = 2; u < 2 * NIT; ++u)
+    if (u * SLOTS < S) {  // block-uniform
+      const int j = min(u * SLOTS + slot, Smax - 1);
+      kr[u].load(kb + (size_t)j * DH + sub * VEC);
+      vr[u].load(vb + (size_t)j * DH + sub * VEC);
+    }
   float m = -INFINITY, l = 0.f, acc[VEC];
 #pragma unroll
   for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
-  // (c) online softmax over the slot's keys, next pair of rows prefetched while the current pair is consumed
-#pragma unroll 1
-  for (int jb = 0; jb < S; jb += 2 * SLOTS) {
-    CacheVec<TC> knext[2], vnext[2];
+  // (d) online softmax over the slot's keys
+  auto consume = [&](const CacheVec<TC>& kk, const CacheVec<TC>& vv, int j) {
+    const bool own = j == pos;
+    const bool ok = j < S && j >= ks;
+    float sc = 0.f;
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) sc = fmaf(qr[i], own ? kown[i] : kk.get(i), sc);
+    // sum over the LPK lanes of this key with DPP (quad swaps, half-row mirror, row mirror): no LDS crossbar trips
+    sc = dpp_add<0xB1>(sc);
+    sc = dpp_add<0x4E>(sc);
+    sc = dpp_add<0x141>(sc);
+    if (LPK == 16) sc = dpp_add<0x140>(sc);
+    sc = ok ? sc : -INFINITY;  // also discards whatever an out-of-range (uninitialised) row produced
+    const float mn = fmaxf(m, sc);
+    const float corr = mn > -INFINITY ? __expf(m - mn) : 1.f;
+    const float p = ok ? __expf(sc - mn) : 0.f;
+    l = l * corr + p;
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      const float vval = ok ? (own ? vown[i] : vv.get(i)) : 0.f;
+      acc[i] = fmaf(p, vval, acc[i] * corr);
+    }
+    m = mn;
+  };
+#pragma unroll
+  for (int u = 0; u < 2 * NIT; ++u)
+    if (u * SLOTS < S) consume(kr[u], vr[u], u * SLOTS + slot);  // block-uniform condition
+  // sequences longer than the register-resident window: stream the rest two rows at a time
+  for (int jb = 2 * NIT * SLOTS; jb < S; jb += 2 * SLOTS) {
+    CacheVec<TC> k2[2], v2[2];
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-      const int j = min(jb + (2 + u) * SLOTS + slot, Smax - 1);
-      knext[u].load(kb + (size_t)j * DH + sub * VEC);
-      vnext[u].load(vb + (size_t)j * DH + sub * VEC);
+      const int j = min(jb + u * SLOTS + slot, Smax - 1);
+      k2[u].load(kb + (size_t)j * DH + sub * VEC);
+      v2[u].load(vb + (size_t)j * DH + sub * VEC);
     }
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int j = jb + u * SLOTS + slot;
-      const bool own = j == pos;
-      const bool ok = j < S && j >= ks;
-      float sc = 0.f;
-#pragma unroll
-      for (int i = 0; i < VEC; ++i) sc = fmaf(qr[i], own ? kown[i] : kcur[u].get(i), sc);
-#pragma unroll
-      for (int o = 1; o < LPK; o <<= 1) sc += __shfl_xor(sc, o, 64);
-      sc = ok ? sc : -INFINITY;  // also discards whatever an out-of-range (uninitialised) row produced
-      const float mn = fmaxf(m, sc);
-      const float corr = mn > -INFINITY ? __expf(m - mn) : 1.f;
-      const float p = ok ? __expf(sc - mn) : 0.f;
-      l = l * corr + p;
-#pragma unroll
-      for (int i = 0; i < VEC; ++i) {
-        const float vval = ok ? (own ? vown[i] : vcur[u].get(i)) : 0.f;
-        acc[i] = fmaf(p, vval, acc[i] * corr);
-      }
-      m = mn;
-    }
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      kcur[u] = knext[u];
-      vcur[u] = vnext[u];
-    }
+    for (int u = 0; u < 2; ++u) consume(k2[u], v2[u], jb + u * SLOTS + slot);
   }
   // merge the 64/LPK key slots of this wave (lanes with equal `sub`)
   float M = m;
@@ -736,11 +748,11 @@ int decode_attn2(void* ctx, int to, const float* qkv, void* kc, void* vc, const 
   const float scale = 1.f / sqrtf((float)dh);
   dim3 grid(H, B);
   if (tc == F32 && to == F32)
-    hipLaunchKernelGGL((decode_attn2_kernel<float, float>), grid, dim3(1024), 0, s, (float*)ctx, qkv, (float*)kc, (float*)vc, len, kv_start, prefix_dev, H, Smax, scale);
+    hipLaunchKernelGGL((decode_attn2_kernel<float, float, 3>), grid, dim3(1024), 0, s, (float*)ctx, qkv, (float*)kc, (float*)vc, len, kv_start, prefix_dev, H, Smax, scale);
   else if (tc == BF16 && to == BF16)
-    hipLaunchKernelGGL((decode_attn2_kernel<bf16_t, bf16_t>), grid, dim3(1024), 0, s, (bf16_t*)ctx, qkv, (bf16_t*)kc, (bf16_t*)vc, len, kv_start, prefix_dev, H, Smax, scale);
+    hipLaunchKernelGGL((decode_attn2_kernel<bf16_t, bf16_t, 3>), grid, dim3(1024), 0, s, (bf16_t*)ctx, qkv, (bf16_t*)kc, (bf16_t*)vc, len, kv_start, prefix_dev, H, Smax, scale);
   else if (tc == BF16 && to == F32)
-    hipLaunchKernelGGL((decode_attn2_kernel<bf16_t, float>), grid, dim3(1024), 0, s, (float*)ctx, qkv, (bf16_t*)kc, (bf16_t*)vc, len, kv_start, prefix_dev, H, Smax, scale);
+    hipLaunchKernelGGL((decode_attn2_kernel<bf16_t, float, 3>), grid, dim3(1024), 0, s, (float*)ctx, qkv, (bf16_t*)kc, (bf16_t*)vc, len, kv_start, prefix_dev, H, Smax, scale);
   else {
     set_error("decode_attn2: dtype combination");
     return E_INVALID;

@@ -17,6 +17,18 @@ for r in rows:
 print(f"counter {want}: per-kernel totals (raw counter units; FETCH_SIZE/WRITE_SIZE are KiB, FETCH_SIZE under-reports 2x on gfx950)")
 for k, v in sorted(tot.items(), key=lambda kv: -kv[1])[:25]:
     print(f"{k:62s} n={cnt[k]:6d} total={v:14.1f} per_launch={v / cnt[k]:12.2f}")
-dec = sum(v for k, v in tot.items() if "gemv" in k or "decode_attn" in k or "sampler" in k)
-ndec = max(cnt.get(next((k for k in cnt if "sampler" in k), ""), 1) - 1, 1)
-print(f"decode-step kernels total={dec:.1f} over {ndec} steps -> per step {dec / ndec:.1f}")
+# decode-step kernels only: gemv / cache attention / sampler launches of the per-token loop.  The prefill's head gemv
+# and sampler (one launch each) are excluded by counting per kernel: launches_per_step * steps.
+nsamp = max((c for k, c in cnt.items() if "sampler" in k), default=1)
+steps = max(nsamp - 1, 1)
+dec = 0.0
+for k, v in tot.items():
+    if "gemv" in k or "decode_attn" in k or "sampler" in k:
+        per = v / cnt[k]
+        launches_in_loop = cnt[k] - (1 if cnt[k] % steps == 1 else 0)
+        dec += per * launches_in_loop
+print(f"decode-step kernels: {dec / steps:.1f} counter units per step over {steps} steps")
+if len(sys.argv) > 3:
+    import json
+
+    json.dump({"counter": want, "steps": steps, "per_step_units": dec / steps}, open(sys.argv[3], "w"))
