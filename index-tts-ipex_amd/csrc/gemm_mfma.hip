@@ -187,15 +187,14 @@ int launch(const GemmArgs& g, hipStream_t s) {
 
 template <typename TC>
 int dispatch(const GemmArgs& g, hipStream_t s) {
-  // tile choice: enough workgroups to cover 256 CUs, widest N tile that N fills
-  const long tiles128 = (long)((g.M + 127) / 128) * ((g.N + 127) / 128) * g.nphase;
-  if (g.N >= 128 && tiles128 >= 512) return launch<128, 128, TC>(g, s);
-  if (g.N > 32) {
-    const long tiles64 = (long)((g.M + 127) / 128) * ((g.N + 63) / 64) * g.nphase;
-    if (tiles64 >= 256 || g.M > 64) return launch<128, 64, TC>(g, s);
-    return launch<64, 64, TC>(g, s);
-  }
-  return launch<128, 32, TC>(g, s);
+  // tile choice: the K loop of one workgroup is latency-bound (register-staged, one chunk pair ahead), so what matters
+  // first is having several workgroups per CU (256 CUs); among shapes that do, prefer the larger tile (fewer LDS
+  // bytes per MFMA).
+  auto tiles = [&](int bm, int bn) { return (long)((g.M + bm - 1) / bm) * ((g.N + bn - 1) / bn) * g.nphase; };
+  if (g.N <= 32) return launch<128, 32, TC>(g, s);
+  if (g.N >= 128 && tiles(128, 128) >= 768) return launch<128, 128, TC>(g, s);
+  if (tiles(128, 64) >= 512 || g.M <= 64) return g.M <= 64 ? launch<64, 64, TC>(g, s) : launch<128, 64, TC>(g, s);
+  return launch<64, 64, TC>(g, s);
 }
 
 }  // namespace
