@@ -62,7 +62,7 @@ int itts_attention(void* o, const void* q, const void* k, const void* v, int B, 
   AttnArgs a;
   a.q = q; a.k = k; a.v = v; a.o = o; a.B = B; a.H = H; a.Sq = Sq; a.Sk = Sk; a.dqk = dqk; a.dv = dv;
   a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.scale = scale; a.causal = causal; a.kv_start = kv_start;
-  return attention_simple(a, dtype, (hipStream_t)stream);
+  return attention(a, dtype, (hipStream_t)stream);
 }
 
 int itts_gemv(float* Y, const float* X, const void* W, const float* bias, int B, int N, int K, int act, int accumulate,

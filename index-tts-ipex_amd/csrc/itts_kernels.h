@@ -57,5 +57,8 @@ struct AttnArgs {
   const int* kv_start = nullptr;  // per batch row: keys < kv_start[b] are masked (left padding)
 };
 int attention_simple(const AttnArgs& a, int dt, hipStream_t s);
+bool attention_mfma_supported(const AttnArgs& a, int dt);
+int attention_mfma(const AttnArgs& a, int dt, hipStream_t s);
+int attention(const AttnArgs& a, int dt, hipStream_t s);  // dispatcher
 
 }  // namespace itts

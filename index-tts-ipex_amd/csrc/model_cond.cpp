@@ -61,7 +61,7 @@ int Engine::conditioning(const void* mel, int F, float* cond_out, hipStream_t s)
       a.ldv = 3 * od;
       a.ldo = od;
       a.scale = 1.f / std::sqrt((float)dk);
-      K(attention_simple(a, adt, s));
+      K(force_simple ? attention_simple(a, adt, s) : attention(a, adt, s));
       ITTS_TRY(lin(x, adt, ctx, adt, od, L.out, Fo, od, s, ACT_NONE, x, od));
       // --- convolution module ---
       ITTS_TRY(ln(xn, adt, x, adt, L.norm_conv, Fo, od, s));
@@ -108,7 +108,7 @@ int Engine::conditioning(const void* mel, int F, float* cond_out, hipStream_t s)
       a.ldk = a.ldv = 2 * inner;
       a.ldo = inner;
       a.scale = 0.125f;
-      K(attention_simple(a, adt, s));
+      K(force_simple ? attention_simple(a, adt, s) : attention(a, adt, s));
       ITTS_TRY(lin(lat, adt, ao, adt, inner, L.to_out, nl, D, s, ACT_NONE, lat, D));
       ITTS_TRY(lin(hcat, adt, lat, adt, D, L.ff1, nl, 2 * ffi, s));
       K(geglu(gg, hcat, nl, ffi, ffp, adt, s));

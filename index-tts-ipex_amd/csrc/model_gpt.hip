@@ -84,7 +84,7 @@ int Engine::gpt_layers_full(float* h, int B, int S, const int* kv_start_dev, boo
     a.scale = 1.f / std::sqrt((float)dh);
     a.causal = 1;
     a.kv_start = kv_start_dev;
-    K(attention_simple(a, adt, s));
+    K(force_simple ? attention_simple(a, adt, s) : attention(a, adt, s));
     ITTS_TRY(lin(h, F32, ctx, adt, D, L.proj, M, D, s, ACT_NONE, h, D));
     ITTS_TRY(ln(xn, adt, h, F32, L.ln2, M, D, s));
     ITTS_TRY(lin(act, adt, xn, adt, D, L.fc, M, 4 * D, s, ACT_GELU_NEW));

@@ -194,3 +194,36 @@ def test_attention(lib, dt):
     # rows that are themselves padding (query < kv_start) are don't-care
     assert relerr(o.float()[0], ref[0]) < (2e-5 if dt == "f32" else 2e-2)
     assert relerr(o.float()[1, 7:], ref[1, 7:]) < (2e-5 if dt == "f32" else 2e-2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", [(1, 20, 621, 621, 1, 0), (2, 4, 96, 200, 1, 5), (1, 16, 32, 290, 0, 0), (3, 2, 17, 17, 1, 3),
+                                  (2, 5, 130, 130, 0, 0)])
+def test_attention_mfma_vs_simple(lib, case):
+    """bf16 flash attention on MFMA vs fp64 torch math: Sq != Sk (causal shifted), left padding, ragged tiles."""
+    B, H, Sq, Sk, causal, pad = case
+    dh, D = 64, H * 64
+    q = rnd("am.q", (B, Sq, D)).to(torch.bfloat16)
+    kv = rnd("am.kv", (B, Sk, 2 * D)).to(torch.bfloat16)
+    kvs = torch.tensor([(pad if b == B - 1 else 0) for b in range(B)], dtype=torch.int32)
+    qf = q.double().view(B, Sq, H, dh).transpose(1, 2)
+    kf, vf = [t.double().view(B, Sk, H, dh).transpose(1, 2) for t in kv.split(D, dim=2)]
+    att = (qf @ kf.transpose(-1, -2)) * 0.125
+    j = torch.arange(Sk)[None, :]
+    i = torch.arange(Sq)[:, None]
+    mask = torch.ones(B, 1, Sq, Sk, dtype=torch.bool)
+    if causal:
+        mask &= (j <= i + (Sk - Sq))[None, None]
+    for b in range(B):
+        mask[b] &= (j >= int(kvs[b]))[None]
+    ref = (torch.softmax(att.masked_fill(~mask, float("-inf")), -1).nan_to_num(0.0) @ vf).transpose(1, 2).reshape(B, Sq, D)
+    qd, kvd, kd = q.to(DEV), kv.to(DEV), kvs.to(DEV)
+    o = torch.full((B, Sq, D), float("nan"), dtype=torch.bfloat16, device=DEV)
+    L.check(lib.itts_attention(o.data_ptr(), qd.data_ptr(), kvd.data_ptr(), kvd.data_ptr() + D * 2, B, H, Sq, Sk, dh, dh,
+                               D, 2 * D, 2 * D, D, 0.125, causal, kd.data_ptr(), L.BF16, stream()))
+    torch.cuda.synchronize()
+    valid = mask.any(-1)[:, 0]  # [B, Sq] rows with at least one visible key
+    got = o.float().cpu()
+    assert torch.isfinite(got).all()
+    for b in range(B):
+        assert relerr(got[b][valid[b]], ref[b][valid[b]].float()) < 1.5e-2
