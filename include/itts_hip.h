@@ -66,6 +66,15 @@ int itts_gemv(float* Y, const float* X, const void* W, const float* bias, int B,
               int prologue, const float* ln_gamma, const float* ln_beta, const float* ln2_gamma, const float* ln2_beta,
               int dtype_w, int version, itts_stream stream);
 
+/* Decode-step projections at batch > 4 (same Conv1D call sites): X bf16 [B, K], W bf16 [N, K], weights streamed once,
+ * batch on MFMA; Y fp32 [B, N] (store, or += when accumulate) or bf16 when y_bf16.  K % 32 == 0, B <= 128. */
+int itts_skinny_gemm(void* Y, int y_bf16, const void* X, const void* W, const float* bias, int B, int N, int K, int act,
+                     int accumulate, itts_stream stream);
+
+/* y (bf16) = LayerNorm(x fp32) [passes == 2: LayerNorm again without affine], GPT-2 ln_1 / ln_2 / ln_f o final_norm */
+int itts_ln_rows_bf16(void* y, const float* x, const float* gamma, const float* beta, int rows, int D, float eps,
+                      int passes, itts_stream stream);
+
 int itts_transpose(void* y, const void* x, int B, int R, int C, int dtype, itts_stream stream);
 
 /* ---- engine level ----------------------------------------------------------------------------------- */

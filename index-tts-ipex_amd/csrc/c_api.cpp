@@ -76,6 +76,25 @@ int itts_gemv(float* Y, const float* X, const void* W, const float* bias, int B,
   return gemv(g, dtype_w, (hipStream_t)stream);
 }
 
+int itts_skinny_gemm(void* Y, int y_bf16, const void* X, const void* W, const float* bias, int B, int N, int K, int act,
+                     int accumulate, itts_stream stream) {
+  (void)hipGetLastError();
+  GemvArgs g;
+  g.X = (const float*)X; g.x_bf16 = 1; g.W = W; g.Y = (float*)Y; g.y_bf16 = y_bf16; g.bias = bias; g.B = B; g.N = N; g.K = K;
+  g.ldy = N; g.act = act; g.accumulate = accumulate;
+  return skinny_mfma(g, (hipStream_t)stream);
+}
+
+int itts_ln_rows_bf16(void* y, const float* x, const float* gamma, const float* beta, int rows, int D, float eps,
+                      int passes, itts_stream stream) {
+  (void)hipGetLastError();
+  if (!y || !x || rows <= 0) {
+    set_error("itts_ln_rows_bf16: bad arguments");
+    return E_INVALID;
+  }
+  return ln_rows_bf16(y, x, gamma, beta, rows, D, eps, passes, (hipStream_t)stream);
+}
+
 int itts_transpose(void* y, const void* x, int B, int R, int C, int dtype, itts_stream stream) {
   (void)hipGetLastError();  // drop stale errors left by other HIP users (torch)
   return transpose_brc(y, x, B, R, C, dtype, (hipStream_t)stream);

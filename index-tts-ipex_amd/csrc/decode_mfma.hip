@@ -68,7 +68,7 @@ __global__ __launch_bounds__(512) void skinny_mfma_kernel(GemvArgs g) {
 #pragma unroll
     for (int w = 0; w < SW; ++w) v += red[w][bt][e];
     if (g.bias) v += g.bias[n];
-    v = apply_act(v, g.act);
+    v = act_apply(g.act, v);
     const size_t o = (size_t)b * g.ldy + n;
     if (g.y_bf16)
       reinterpret_cast<bf16_t*>(g.Y)[o] = (bf16_t)v;

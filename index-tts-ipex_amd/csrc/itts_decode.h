@@ -54,4 +54,10 @@ int sampler2_step(const SamplerArgs& a, int B, hipStream_t s);
 int decode_embed2(float* h, const void* emb, const void* pos, const int* tok, const int* len, int B, int D, int tw,
                   hipStream_t s);
 
+// larger decode batches (decode_mfma.hip): X bf16 [B,K], W bf16 [N,K]; Y fp32 (store / accumulate) or bf16
+bool skinny_mfma_supported(const GemvArgs& g);
+int skinny_mfma(const GemvArgs& g, hipStream_t s);
+int ln_rows_bf16(void* y, const float* x, const float* g1, const float* b1, int rows, int D, float eps, int passes,
+                 hipStream_t s);
+
 }  // namespace itts

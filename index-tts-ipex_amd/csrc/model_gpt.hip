@@ -241,7 +241,14 @@ int Engine::head_and_sample(hipStream_t s) {
   g.ln_beta = gpt.ln_f.b;
   g.ln2_gamma = nullptr;  // final_norm's affine is folded into mel_head by the packer
   g.ln2_beta = nullptr;
-  if (adt == BF16 && gemv_bf16_supported(g)) {
+  if (adt == BF16 && B > 4 && D % 32 == 0 && D <= 2048) {
+    // batched decode: ln_f -> final_norm as a row kernel (bf16), head on the matrix cores
+    ITTS_TRY(ln_rows_bf16(ds.hn, ds.h, gpt.ln_f.g, gpt.ln_f.b, B, D, 1e-5f, 2, s));
+    g.X = ds.hn;
+    g.x_bf16 = 1;
+    g.prologue = 0;
+    ITTS_TRY(skinny_mfma(g, s));
+  } else if (adt == BF16 && gemv_bf16_supported(g)) {
     ITTS_TRY(gemv_bf16(g, s));
   } else if (gemv2_supported(g)) {
     ITTS_TRY(gemv2(g, gpt.head.dt, s));
@@ -281,7 +288,17 @@ int Engine::decode_step_launch(hipStream_t s) {
   const int D = c.model_dim, H = c.heads, dh = D / H, B = ds.B;
   // ds.h already holds mel_emb[tok] + mel_pos[...] of this step (written by the previous step's sampler)
   const bool fast = adt == BF16 && B <= 4;  // bf16 activations between the decode kernels (ctx, act)
+  const bool skinny = adt == BF16 && B > 4 && D % 32 == 0 && D <= 2048;  // weights once, batch on MFMA
   auto run = [&](GemvArgs& g, int dt) -> int {
+    if (skinny) {
+      if (g.prologue == 1) {  // LayerNorm as a row kernel; its affine lives in the projection
+        ITTS_TRY(ln_rows_bf16(ds.hn, g.X, g.ln_gamma, g.ln_beta, B, g.K, g.ln_eps, 1, s));
+        g.X = ds.hn;
+        g.x_bf16 = 1;
+        g.prologue = 0;
+      }
+      return skinny_mfma(g, s);
+    }
     if (fast && gemv_bf16_supported(g)) return gemv_bf16(g, s);
     ITTS_REQUIRE(!g.x_bf16 && !g.y_bf16, "decode: bf16 activation without the bf16 GEMV");
     return gemv2_supported(g) ? gemv2(g, dt, s) : gemv(g, dt, s);
@@ -291,9 +308,9 @@ int Engine::decode_step_launch(hipStream_t s) {
   probe.K = 4 * D;
   probe.x_bf16 = 1;
   probe.N = D;
-  const bool bf_act = fast && gemv_bf16_supported(probe);
+  const bool bf_act = skinny || (fast && gemv_bf16_supported(probe));
   probe.K = D;
-  const bool bf_ctx = fast && gemv_bf16_supported(probe);
+  const bool bf_ctx = skinny || (fast && gemv_bf16_supported(probe));
   for (int l = 0; l < c.layers; ++l) {
     const GptLayerW& L = gpt.layers[l];
     GemvArgs g;  // qkv = LN1(h) Wqkv + b

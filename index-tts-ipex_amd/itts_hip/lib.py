@@ -14,6 +14,7 @@ CSRC = os.path.normpath(os.path.join(_HERE, "..", "csrc"))
 LIB_PATH = os.environ.get("ITTS_HIP_LIB", os.path.join(CSRC, "libitts_hip.so"))
 
 F32, BF16 = 0, 1
+ACT_NONE, ACT_RELU, ACT_SILU, ACT_GELU_NEW, ACT_GELU_ERF, ACT_TANH, ACT_SIGMOID = range(7)  # csrc/itts_common.h enum Act
 ACT = {"none": 0, "relu": 1, "silu": 2, "gelu_new": 3, "gelu_erf": 4, "tanh": 5, "sigmoid": 6}
 
 vp, i32, f32, i64 = C.c_void_p, C.c_int, C.c_float, C.c_int64
@@ -60,6 +61,8 @@ _PROTOS = {
     "itts_layernorm": (i32, [vp, i32, vp, i32, vp, vp, i32, i32, f32, vp]),
     "itts_attention": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, f32, i32, vp, i32, vp]),
     "itts_gemv": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, i32, i32, vp]),
+    "itts_skinny_gemm": (i32, [vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
+    "itts_ln_rows_bf16": (i32, [vp, vp, vp, vp, i32, i32, f32, i32, vp]),
     "itts_transpose": (i32, [vp, vp, i32, i32, i32, i32, vp]),
     "itts_engine_create": (i32, [C.POINTER(Config), C.POINTER(vp)]),
     "itts_engine_destroy": (None, [vp]),

@@ -227,3 +227,50 @@ def test_attention_mfma_vs_simple(lib, case):
     assert torch.isfinite(got).all()
     for b in range(B):
         assert relerr(got[b][valid[b]], ref[b][valid[b]].float()) < 1.5e-2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", [(64, 3840, 1280, 0, 0, 0), (8, 1280, 5120, 0, 1, 0), (33, 5120, 1280, 1, 0, 1),
+                                  (128, 8194, 1280, 0, 0, 0), (5, 66, 128, 0, 0, 0), (17, 40, 96, 0, 1, 0)])
+def test_skinny_gemm(lib, case):
+    """decode projections at batch > 4: weights streamed once, batch on MFMA; vs fp64 math on the same bf16 inputs."""
+    B, N, K, gelu, acc, ybf = case
+    x = (rnd("sk.x", (B, K)) * 1.5).to(torch.bfloat16)
+    w = (rnd("sk.w", (N, K)) * 0.05).to(torch.bfloat16)
+    bias = rnd("sk.b", (N,))
+    y0 = rnd("sk.y", (B, N))
+    ref = x.double() @ w.double().T + bias.double()
+    if gelu:
+        ref = 0.5 * ref * (1 + torch.tanh(0.7978845608028654 * (ref + 0.044715 * ref ** 3)))
+    if acc:
+        ref = ref + y0.double()
+    xd, wd, bd = x.to(DEV), w.to(DEV), bias.to(DEV)
+    y = y0.to(DEV).clone() if not ybf else torch.empty(B, N, dtype=torch.bfloat16, device=DEV)
+    L.check(lib.itts_skinny_gemm(y.data_ptr(), ybf, xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), B, N, K,
+                                 L.ACT_GELU_NEW if gelu else L.ACT_NONE, acc, stream()))
+    torch.cuda.synchronize()
+    assert relerr(y.float(), ref.float()) < (1e-2 if ybf else 2e-5)
+    # rows do not depend on the rest of the batch (same row alone gives the same bits)
+    if not acc:
+        y1 = torch.empty(1, N, dtype=y.dtype, device=DEV)
+        r = B // 2
+        L.check(lib.itts_skinny_gemm(y1.data_ptr(), ybf, xd[r:r + 1].contiguous().data_ptr(), wd.data_ptr(), bd.data_ptr(), 1, N,
+                                     K, L.ACT_GELU_NEW if gelu else L.ACT_NONE, 0, stream()))
+        torch.cuda.synchronize()
+        assert torch.equal(y1[0], y[r])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("passes", [1, 2])
+def test_ln_rows_bf16(lib, passes):
+    rows, D = 37, 1280
+    x = rnd("lnr.x", (rows, D)) * 3 + 0.7
+    g, b = rnd("lnr.g", (D,)) * 0.2 + 1, rnd("lnr.b", (D,)) * 0.1
+    ref = torch.nn.functional.layer_norm(x.double(), (D,), g.double(), b.double(), 1e-5)
+    if passes == 2:
+        ref = torch.nn.functional.layer_norm(ref, (D,), None, None, 1e-5)
+    xd, gd, bd = x.to(DEV), g.to(DEV), b.to(DEV)
+    y = torch.empty(rows, D, dtype=torch.bfloat16, device=DEV)
+    L.check(lib.itts_ln_rows_bf16(y.data_ptr(), xd.data_ptr(), gd.data_ptr(), bd.data_ptr(), rows, D, 1e-5, passes, stream()))
+    torch.cuda.synchronize()
+    assert relerr(y.float(), ref.float()) < 6e-3
