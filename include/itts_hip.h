@@ -67,13 +67,16 @@ int itts_gemv(float* Y, const float* X, const void* W, const float* bias, int B,
               int dtype_w, int version, itts_stream stream);
 
 /* Decode-step projections at batch > 4 (same Conv1D call sites): X bf16 [B, K], W bf16 [N, K], weights streamed once,
- * batch on MFMA; Y fp32 [B, N] (store, or += when accumulate) or bf16 when y_bf16.  K % 32 == 0, B <= 128. */
+ * batch on MFMA; Y fp32 [B, N] (store, or += when accumulate) or bf16 when y_bf16.  K % 32 == 0, B <= 128.
+ * ksplit > 1 splits K over workgroups: raw sums go to partial[ksplit][B][N] (no bias / act / Y), to be absorbed by
+ * itts_ln_rows_bf16 (deterministic two-stage reduction, no atomics). */
 int itts_skinny_gemm(void* Y, int y_bf16, const void* X, const void* W, const float* bias, int B, int N, int K, int act,
-                     int accumulate, itts_stream stream);
+                     int accumulate, int ksplit, float* partial, itts_stream stream);
 
-/* y (bf16) = LayerNorm(x fp32) [passes == 2: LayerNorm again without affine], GPT-2 ln_1 / ln_2 / ln_f o final_norm */
-int itts_ln_rows_bf16(void* y, const float* x, const float* gamma, const float* beta, int rows, int D, float eps,
-                      int passes, itts_stream stream);
+/* y (bf16) = LayerNorm(x fp32) [passes == 2: LayerNorm again without affine], GPT-2 ln_1 / ln_2 / ln_f o final_norm.
+ * nsplit > 0: first x += partial_bias + sum_s partial[s] (the residual add of a split-K projection), written back. */
+int itts_ln_rows_bf16(void* y, float* x, const float* gamma, const float* beta, int rows, int D, float eps, int passes,
+                      const float* partial, int nsplit, const float* partial_bias, itts_stream stream);
 
 int itts_transpose(void* y, const void* x, int B, int R, int C, int dtype, itts_stream stream);
 

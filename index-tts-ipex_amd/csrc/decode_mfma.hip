@@ -15,31 +15,41 @@ namespace {
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 
-constexpr int SW = 8;  // waves per workgroup (K split)
-constexpr int SU = 5;  // k-steps in flight per wave
+constexpr int SW = 8;  // waves per workgroup (K split inside the workgroup)
 
-template <int BT>
+// NT = 16-feature tiles per workgroup (each wave multiplies the same X fragments into NT weight tiles: X is the larger
+// L2->CU stream at B = 64, so two tiles per workgroup halve it per output); gridDim.y = K split across workgroups
+// (ksplit > 1: raw partial sums go to g.partial[split][b][n]; bias / residual are applied by ln_rows_bf16).
+template <int BT, int NT, int SU>
 __global__ __launch_bounds__(512) void skinny_mfma_kernel(GemvArgs g) {
-  __shared__ float red[SW][BT][256];
+  __shared__ float red[SW][NT * BT][256];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int fr = lane & 15, fg = lane >> 4;
-  const int n0 = blockIdx.x * 16;
+  const int n0 = blockIdx.x * (16 * NT);
   const bf16_t* __restrict__ W = (const bf16_t*)g.W;
   const bf16_t* __restrict__ X = (const bf16_t*)g.X;
-  const int K = g.K, nks = K >> 5;
-  const bf16_t* wp = W + (size_t)min(n0 + fr, g.N - 1) * K + fg * 8;
+  const int K = g.K, nks_all = K >> 5;
+  const int S = gridDim.y, split = blockIdx.y;
+  const int per = (nks_all + S - 1) / S;
+  const int ks0 = split * per, nks = min(per, nks_all - ks0);  // this workgroup's k-steps [ks0, ks0 + nks)
+  const bf16_t* wp[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) wp[t] = W + (size_t)min(n0 + t * 16 + fr, g.N - 1) * K + fg * 8 + (size_t)ks0 * 32;
   const bf16_t* xp[BT];
 #pragma unroll
-  for (int bt = 0; bt < BT; ++bt) xp[bt] = X + (size_t)min(bt * 16 + fr, g.B - 1) * K + fg * 8;
-  f32x4v acc[BT];
+  for (int bt = 0; bt < BT; ++bt) xp[bt] = X + (size_t)min(bt * 16 + fr, g.B - 1) * K + fg * 8 + (size_t)ks0 * 32;
+  f32x4v acc[NT][BT];
 #pragma unroll
-  for (int bt = 0; bt < BT; ++bt) acc[bt] = f32x4v{0.f, 0.f, 0.f, 0.f};
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int bt = 0; bt < BT; ++bt) acc[t][bt] = f32x4v{0.f, 0.f, 0.f, 0.f};
   for (int k0 = wave; k0 < nks; k0 += SW * SU) {
-    bf16x8 wf[SU], xf[SU][BT];
+    bf16x8 wf[SU][NT], xf[SU][BT];
 #pragma unroll
     for (int u = 0; u < SU; ++u) {
       const int ks = min(k0 + u * SW, nks - 1);  // clamped loads, masked below: keeps the loads branch-free
-      wf[u] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(wp + (size_t)ks * 32));
+#pragma unroll
+      for (int t = 0; t < NT; ++t) wf[u][t] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(wp[t] + (size_t)ks * 32));
     }
 #pragma unroll
     for (int u = 0; u < SU; ++u) {
@@ -51,25 +61,34 @@ __global__ __launch_bounds__(512) void skinny_mfma_kernel(GemvArgs g) {
     for (int u = 0; u < SU; ++u) {
       if (k0 + u * SW < nks) {
 #pragma unroll
-        for (int bt = 0; bt < BT; ++bt) acc[bt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[u][bt], wf[u], acc[bt], 0, 0, 0);
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+          for (int bt = 0; bt < BT; ++bt)
+            acc[t][bt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[u][bt], wf[u][t], acc[t][bt], 0, 0, 0);
       }
     }
   }
 #pragma unroll
-  for (int bt = 0; bt < BT; ++bt)
+  for (int t = 0; t < NT; ++t)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) red[wave][bt][r * 64 + lane] = acc[bt][r];
+    for (int bt = 0; bt < BT; ++bt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[wave][t * BT + bt][r * 64 + lane] = acc[t][bt][r];
   __syncthreads();
-  for (int idx = tid; idx < BT * 256; idx += 512) {
-    const int bt = idx >> 8, e = idx & 255, r = e >> 6, l = e & 63;
-    const int b = bt * 16 + (l >> 4) * 4 + r, n = n0 + (l & 15);
+  for (int idx = tid; idx < NT * BT * 256; idx += 512) {
+    const int tb = idx >> 8, t = tb / BT, bt = tb - t * BT, e = idx & 255, r = e >> 6, l = e & 63;
+    const int b = bt * 16 + (l >> 4) * 4 + r, n = n0 + t * 16 + (l & 15);
     if (b >= g.B || n >= g.N) continue;
     float v = 0.f;
 #pragma unroll
-    for (int w = 0; w < SW; ++w) v += red[w][bt][e];
+    for (int w = 0; w < SW; ++w) v += red[w][tb][e];
+    const size_t o = (size_t)b * g.ldy + n;
+    if (S > 1) {
+      g.partial[((size_t)split * g.B + b) * g.ldy + n] = v;
+      continue;
+    }
     if (g.bias) v += g.bias[n];
     v = act_apply(g.act, v);
-    const size_t o = (size_t)b * g.ldy + n;
     if (g.y_bf16)
       reinterpret_cast<bf16_t*>(g.Y)[o] = (bf16_t)v;
     else if (g.accumulate)
@@ -79,26 +98,39 @@ __global__ __launch_bounds__(512) void skinny_mfma_kernel(GemvArgs g) {
   }
 }
 
-// y(bf16) = LN(x) [-> LN again for the head]; optional affine on the first pass
-__global__ __launch_bounds__(256) void ln_rows_bf16_kernel(bf16_t* __restrict__ y, const float* __restrict__ x,
+// y(bf16) = LN(x) [-> LN again for the head]; optional affine on the first pass.  With nsplit > 0 the row first absorbs a
+// split-K projection: x += bias + sum_s partial[s] (fixed order), written back to the fp32 residual stream.
+__global__ __launch_bounds__(256) void ln_rows_bf16_kernel(bf16_t* __restrict__ y, float* __restrict__ x,
                                                            const float* __restrict__ g1, const float* __restrict__ b1,
-                                                           int D, float eps, int passes) {
-  __shared__ float red[2][4];
+                                                           int D, float eps, int passes, const float* __restrict__ partial,
+                                                           int nsplit, const float* __restrict__ pbias, int rows) {
+  __shared__ float red[2][2][4];
   const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   constexpr int MAXE = 8;  // D <= 2048
   float v[MAXE];
-  const float* xr = x + (size_t)row * D;
+  float* xr = x + (size_t)row * D;
 #pragma unroll
   for (int i = 0; i < MAXE; ++i) v[i] = tid + i * 256 < D ? xr[tid + i * 256] : 0.f;
+  if (nsplit > 0) {
+#pragma unroll
+    for (int i = 0; i < MAXE; ++i) {
+      const int c = tid + i * 256;
+      if (c < D) {
+        float a = pbias ? pbias[c] : 0.f;
+        for (int sp = 0; sp < nsplit; ++sp) a += partial[((size_t)sp * rows + row) * D + c];
+        v[i] += a;
+        xr[c] = v[i];
+      }
+    }
+  }
   for (int pass = 0; pass < passes; ++pass) {
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < MAXE; ++i) s += v[i];
     s = wave_sum(s);
+    if (lane == 0) red[pass][0][wave] = s;
     __syncthreads();
-    if (lane == 0) red[0][wave] = s;
-    __syncthreads();
-    const float mean = (red[0][0] + red[0][1] + red[0][2] + red[0][3]) / D;
+    const float mean = (red[pass][0][0] + red[pass][0][1] + red[pass][0][2] + red[pass][0][3]) / D;
     float q = 0.f;
 #pragma unroll
     for (int i = 0; i < MAXE; ++i) {
@@ -106,9 +138,9 @@ __global__ __launch_bounds__(256) void ln_rows_bf16_kernel(bf16_t* __restrict__ 
       q = fmaf(d, d, q);
     }
     q = wave_sum(q);
-    if (lane == 0) red[1][wave] = q;
+    if (lane == 0) red[pass][1][wave] = q;
     __syncthreads();
-    const float rstd = rsqrtf((red[1][0] + red[1][1] + red[1][2] + red[1][3]) / D + eps);
+    const float rstd = rsqrtf((red[pass][1][0] + red[pass][1][1] + red[pass][1][2] + red[pass][1][3]) / D + eps);
 #pragma unroll
     for (int i = 0; i < MAXE; ++i) {
       const int c = tid + i * 256;
@@ -128,30 +160,40 @@ __global__ __launch_bounds__(256) void ln_rows_bf16_kernel(bf16_t* __restrict__ 
 
 bool skinny_mfma_supported(const GemvArgs& g) {
   return g.B >= 1 && g.B <= 128 && g.K % 32 == 0 && g.x_bf16 && g.prologue == 0 && !(g.accumulate && g.y_bf16) &&
-         !(((uintptr_t)g.W | (uintptr_t)g.X) & 15);
+         !(((uintptr_t)g.W | (uintptr_t)g.X) & 15) && g.ksplit >= 1 && (g.ksplit == 1 || (g.partial && g.act == ACT_NONE));
 }
 
-int skinny_mfma(const GemvArgs& g, hipStream_t s) {
-  ITTS_REQUIRE(g.X && g.W && g.Y && g.N > 0, "skinny_mfma: bad args");
-  ITTS_REQUIRE(skinny_mfma_supported(g), "skinny_mfma: unsupported shape");
-  const int bt = (g.B + 15) / 16;
-  dim3 grid((g.N + 15) / 16), blk(512);
-  if (bt <= 1)
-    hipLaunchKernelGGL(skinny_mfma_kernel<1>, grid, blk, 0, s, g);
-  else if (bt <= 2)
-    hipLaunchKernelGGL(skinny_mfma_kernel<2>, grid, blk, 0, s, g);
-  else if (bt <= 4)
-    hipLaunchKernelGGL(skinny_mfma_kernel<4>, grid, blk, 0, s, g);
+template <int BT>
+static int launch_skinny(const GemvArgs& g, hipStream_t s) {
+  // two feature tiles per workgroup once there are plenty of tiles (halves the X stream per output); otherwise one
+  const int tiles = (g.N + 15) / 16;
+  const bool nt2 = tiles * g.ksplit >= 300 && BT <= 4;
+  dim3 grid(nt2 ? (tiles + 1) / 2 : tiles, g.ksplit), blk(512);
+  if (nt2)
+    hipLaunchKernelGGL((skinny_mfma_kernel<BT, 2, 5>), grid, blk, 0, s, g);
   else
-    hipLaunchKernelGGL(skinny_mfma_kernel<8>, grid, blk, 0, s, g);
+    hipLaunchKernelGGL((skinny_mfma_kernel<BT, 1, 5>), grid, blk, 0, s, g);
   ITTS_HIP_CHECK(hipGetLastError());
   return OK;
 }
 
-int ln_rows_bf16(void* y, const float* x, const float* g1, const float* b1, int rows, int D, float eps, int passes,
-                 hipStream_t s) {
+int skinny_mfma(const GemvArgs& g, hipStream_t s) {
+  ITTS_REQUIRE(g.X && g.W && (g.Y || g.ksplit > 1) && g.N > 0, "skinny_mfma: bad args");
+  ITTS_REQUIRE(skinny_mfma_supported(g), "skinny_mfma: unsupported shape");
+  ITTS_REQUIRE(g.ksplit <= (g.K >> 5), "skinny_mfma: ksplit larger than the number of k-steps");
+  const int bt = (g.B + 15) / 16;
+  if (bt <= 1) return launch_skinny<1>(g, s);
+  if (bt <= 2) return launch_skinny<2>(g, s);
+  if (bt <= 4) return launch_skinny<4>(g, s);
+  return launch_skinny<8>(g, s);
+}
+
+int ln_rows_bf16(void* y, float* x, const float* g1, const float* b1, int rows, int D, float eps, int passes,
+                 const float* partial, int nsplit, const float* pbias, hipStream_t s) {
   ITTS_REQUIRE(D <= 2048 && passes >= 1 && passes <= 2, "ln_rows_bf16: D > 2048 or bad pass count");
-  hipLaunchKernelGGL(ln_rows_bf16_kernel, dim3(rows), dim3(256), 0, s, (bf16_t*)y, x, g1, b1, D, eps, passes);
+  ITTS_REQUIRE(nsplit == 0 || partial, "ln_rows_bf16: partial sums missing");
+  hipLaunchKernelGGL(ln_rows_bf16_kernel, dim3(rows), dim3(256), 0, s, (bf16_t*)y, x, g1, b1, D, eps, passes, partial, nsplit,
+                     pbias, rows);
   ITTS_HIP_CHECK(hipGetLastError());
   return OK;
 }

@@ -108,6 +108,9 @@ struct DecodeState {
   size_t cache_bytes = 0;
   void *kc = nullptr, *vc = nullptr;  // [layers][B][H][Smax][dh]
   float *h = nullptr, *qkv = nullptr, *ctx = nullptr, *act = nullptr, *hn = nullptr, *logits = nullptr;
+  float* partial = nullptr;           // [4][B][D] split-K partial sums of the residual projections (batched decode)
+  int pend_split = 0;                 // launch-time bookkeeping: partials waiting to be absorbed by the next LayerNorm
+  const float* pend_bias = nullptr;
   int *len = nullptr, *prefix_dev = nullptr;  // len[b]: tokens generated so far by row b
   int *kv_start = nullptr, *cur_tok = nullptr, *ids = nullptr, *unfinished = nullptr;
   uint8_t* seen = nullptr;

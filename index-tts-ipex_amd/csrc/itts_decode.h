@@ -20,6 +20,8 @@ struct GemvArgs {
   const float* ln2_gamma = nullptr;
   const float* ln2_beta = nullptr;
   float ln_eps = 1e-5f;
+  int ksplit = 1;            // skinny_mfma: K split across workgroups; > 1 writes raw sums to partial[split][B][ldy]
+  float* partial = nullptr;
 };
 
 struct SamplerArgs {
@@ -57,7 +59,7 @@ int decode_embed2(float* h, const void* emb, const void* pos, const int* tok, co
 // larger decode batches (decode_mfma.hip): X bf16 [B,K], W bf16 [N,K]; Y fp32 (store / accumulate) or bf16
 bool skinny_mfma_supported(const GemvArgs& g);
 int skinny_mfma(const GemvArgs& g, hipStream_t s);
-int ln_rows_bf16(void* y, const float* x, const float* g1, const float* b1, int rows, int D, float eps, int passes,
-                 hipStream_t s);
+int ln_rows_bf16(void* y, float* x, const float* g1, const float* b1, int rows, int D, float eps, int passes,
+                 const float* partial, int nsplit, const float* pbias, hipStream_t s);
 
 }  // namespace itts

@@ -129,6 +129,7 @@ int Engine::ensure_decode_state(int B, int Smax, int max_gen, hipStream_t s) {
     ITTS_TRY(dev_alloc((void**)&d.ctx, (size_t)cb * D * 4));
     ITTS_TRY(dev_alloc((void**)&d.act, (size_t)cb * 4 * D * 4));
     ITTS_TRY(dev_alloc((void**)&d.hn, (size_t)cb * D * 4));
+    ITTS_TRY(dev_alloc((void**)&d.partial, (size_t)4 * cb * D * 4));
     ITTS_TRY(dev_alloc((void**)&d.logits, (size_t)cb * V * 4));
     ITTS_TRY(dev_alloc((void**)&d.kv_start, (size_t)cb * 4));
     ITTS_TRY(dev_alloc((void**)&d.cur_tok, (size_t)cb * 4));
@@ -243,7 +244,8 @@ int Engine::head_and_sample(hipStream_t s) {
   g.ln2_beta = nullptr;
   if (adt == BF16 && B > 4 && D % 32 == 0 && D <= 2048) {
     // batched decode: ln_f -> final_norm as a row kernel (bf16), head on the matrix cores
-    ITTS_TRY(ln_rows_bf16(ds.hn, ds.h, gpt.ln_f.g, gpt.ln_f.b, B, D, 1e-5f, 2, s));
+    ITTS_TRY(ln_rows_bf16(ds.hn, ds.h, gpt.ln_f.g, gpt.ln_f.b, B, D, 1e-5f, 2, ds.partial, ds.pend_split, ds.pend_bias, s));
+    ds.pend_split = 0;
     g.X = ds.hn;
     g.x_bf16 = 1;
     g.prologue = 0;
@@ -289,13 +291,23 @@ int Engine::decode_step_launch(hipStream_t s) {
   // ds.h already holds mel_emb[tok] + mel_pos[...] of this step (written by the previous step's sampler)
   const bool fast = adt == BF16 && B <= 4;  // bf16 activations between the decode kernels (ctx, act)
   const bool skinny = adt == BF16 && B > 4 && D % 32 == 0 && D <= 2048;  // weights once, batch on MFMA
+  ds.pend_split = 0;
   auto run = [&](GemvArgs& g, int dt) -> int {
     if (skinny) {
-      if (g.prologue == 1) {  // LayerNorm as a row kernel; its affine lives in the projection
-        ITTS_TRY(ln_rows_bf16(ds.hn, g.X, g.ln_gamma, g.ln_beta, B, g.K, g.ln_eps, 1, s));
+      if (g.prologue == 1) {  // LayerNorm as a row kernel (its affine lives in the projection); it also absorbs the
+                              // split-K partial sums of the projection that fed the residual stream
+        ITTS_TRY(ln_rows_bf16(ds.hn, ds.h, g.ln_gamma, g.ln_beta, B, g.K, g.ln_eps, 1, ds.partial, ds.pend_split, ds.pend_bias, s));
+        ds.pend_split = 0;
         g.X = ds.hn;
         g.x_bf16 = 1;
         g.prologue = 0;
+      } else if (g.accumulate && g.Y == ds.h && g.N == D) {
+        // residual projections have few 16-feature tiles (D/16 = 80 on 256 CUs): split K over workgroups, reduced by
+        // the LayerNorm that follows
+        g.ksplit = g.K >= 4 * D ? 4 : 2;
+        g.partial = ds.partial;
+        ds.pend_split = g.ksplit;
+        ds.pend_bias = g.bias;
       }
       return skinny_mfma(g, s);
     }

@@ -247,7 +247,7 @@ def test_skinny_gemm(lib, case):
     xd, wd, bd = x.to(DEV), w.to(DEV), bias.to(DEV)
     y = y0.to(DEV).clone() if not ybf else torch.empty(B, N, dtype=torch.bfloat16, device=DEV)
     L.check(lib.itts_skinny_gemm(y.data_ptr(), ybf, xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), B, N, K,
-                                 L.ACT_GELU_NEW if gelu else L.ACT_NONE, acc, stream()))
+                                 L.ACT_GELU_NEW if gelu else L.ACT_NONE, acc, 1, None, stream()))
     torch.cuda.synchronize()
     assert relerr(y.float(), ref.float()) < (1e-2 if ybf else 2e-5)
     # rows do not depend on the rest of the batch (same row alone gives the same bits)
@@ -255,7 +255,7 @@ def test_skinny_gemm(lib, case):
         y1 = torch.empty(1, N, dtype=y.dtype, device=DEV)
         r = B // 2
         L.check(lib.itts_skinny_gemm(y1.data_ptr(), ybf, xd[r:r + 1].contiguous().data_ptr(), wd.data_ptr(), bd.data_ptr(), 1, N,
-                                     K, L.ACT_GELU_NEW if gelu else L.ACT_NONE, 0, stream()))
+                                     K, L.ACT_GELU_NEW if gelu else L.ACT_NONE, 0, 1, None, stream()))
         torch.cuda.synchronize()
         assert torch.equal(y1[0], y[r])
 
@@ -271,6 +271,39 @@ def test_ln_rows_bf16(lib, passes):
         ref = torch.nn.functional.layer_norm(ref, (D,), None, None, 1e-5)
     xd, gd, bd = x.to(DEV), g.to(DEV), b.to(DEV)
     y = torch.empty(rows, D, dtype=torch.bfloat16, device=DEV)
-    L.check(lib.itts_ln_rows_bf16(y.data_ptr(), xd.data_ptr(), gd.data_ptr(), bd.data_ptr(), rows, D, 1e-5, passes, stream()))
+    L.check(lib.itts_ln_rows_bf16(y.data_ptr(), xd.data_ptr(), gd.data_ptr(), bd.data_ptr(), rows, D, 1e-5, passes, None, 0,
+                                  None, stream()))
     torch.cuda.synchronize()
     assert relerr(y.float(), ref.float()) < 6e-3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", [(64, 1280, 5120, 4), (64, 1280, 1280, 2), (9, 128, 512, 4), (20, 1280, 1280, 3)])
+def test_skinny_splitk_absorbed_by_layernorm(lib, case):
+    """residual projection split over K: partial sums + bias are absorbed by the following LayerNorm kernel, which also
+    writes the updated fp32 residual stream (two-stage deterministic reduction)."""
+    B, N, K, S = case
+    x = (rnd("ss.x", (B, K)) * 1.5).to(torch.bfloat16)
+    w = (rnd("ss.w", (N, K)) * 0.05).to(torch.bfloat16)
+    bias = rnd("ss.b", (N,))
+    h0 = rnd("ss.h", (B, N)) * 2
+    h_ref = h0.double() + x.double() @ w.double().T + bias.double()
+    y_ref = torch.nn.functional.layer_norm(h_ref, (N,), None, None, 1e-5)
+    xd, wd, bd, hd = x.to(DEV), w.to(DEV), bias.to(DEV), h0.to(DEV).clone()
+    part = torch.full((S, B, N), float("nan"), device=DEV)
+    L.check(lib.itts_skinny_gemm(None, 0, xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), B, N, K, L.ACT_NONE, 1, S,
+                                 part.data_ptr(), stream()))
+    y = torch.empty(B, N, dtype=torch.bfloat16, device=DEV)
+    L.check(lib.itts_ln_rows_bf16(y.data_ptr(), hd.data_ptr(), None, None, B, N, 1e-5, 1, part.data_ptr(), S, bd.data_ptr(),
+                                  stream()))
+    torch.cuda.synchronize()
+    assert relerr(hd, h_ref.float()) < 2e-5
+    assert relerr(y.float(), y_ref.float()) < 6e-3
+    # run-to-run determinism
+    hd2 = h0.to(DEV).clone()
+    L.check(lib.itts_skinny_gemm(None, 0, xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), B, N, K, L.ACT_NONE, 1, S,
+                                 part.data_ptr(), stream()))
+    L.check(lib.itts_ln_rows_bf16(y.data_ptr(), hd2.data_ptr(), None, None, B, N, 1e-5, 1, part.data_ptr(), S, bd.data_ptr(),
+                                  stream()))
+    torch.cuda.synchronize()
+    assert torch.equal(hd, hd2)
