@@ -69,14 +69,16 @@ int itts_gemv(float* Y, const float* X, const void* W, const float* bias, int B,
 /* Decode-step projections at batch > 4 (same Conv1D call sites): X bf16 [B, K], W bf16 [N, K], weights streamed once,
  * batch on MFMA; Y fp32 [B, N] (store, or += when accumulate) or bf16 when y_bf16.  K % 32 == 0, B <= 128.
  * ksplit > 1 splits K over workgroups: raw sums go to partial[ksplit][B][N] (no bias / act / Y), to be absorbed by
- * itts_ln_rows_bf16 (deterministic two-stage reduction, no atomics). */
+ * itts_ln_rows_bf16 (deterministic two-stage reduction, no atomics).
+ * layout bit 0: X is MFMA-fragment tiled, bit 1: bf16 Y is written tiled - element (b, k) at
+ * ((k/32) * ceil(B/16) + b/16) * 512 + ((k%32)/8 * 16 + b%16) * 8 + k%8 (csrc/itts_decode.h tile_off). */
 int itts_skinny_gemm(void* Y, int y_bf16, const void* X, const void* W, const float* bias, int B, int N, int K, int act,
-                     int accumulate, int ksplit, float* partial, itts_stream stream);
+                     int accumulate, int ksplit, float* partial, int layout, itts_stream stream);
 
 /* y (bf16) = LayerNorm(x fp32) [passes == 2: LayerNorm again without affine], GPT-2 ln_1 / ln_2 / ln_f o final_norm.
  * nsplit > 0: first x += partial_bias + sum_s partial[s] (the residual add of a split-K projection), written back. */
 int itts_ln_rows_bf16(void* y, float* x, const float* gamma, const float* beta, int rows, int D, float eps, int passes,
-                      const float* partial, int nsplit, const float* partial_bias, itts_stream stream);
+                      const float* partial, int nsplit, const float* partial_bias, int y_tiled, itts_stream stream);
 
 int itts_transpose(void* y, const void* x, int B, int R, int C, int dtype, itts_stream stream);
 

@@ -77,22 +77,23 @@ int itts_gemv(float* Y, const float* X, const void* W, const float* bias, int B,
 }
 
 int itts_skinny_gemm(void* Y, int y_bf16, const void* X, const void* W, const float* bias, int B, int N, int K, int act,
-                     int accumulate, int ksplit, float* partial, itts_stream stream) {
+                     int accumulate, int ksplit, float* partial, int layout, itts_stream stream) {
   (void)hipGetLastError();
   GemvArgs g;
   g.X = (const float*)X; g.x_bf16 = 1; g.W = W; g.Y = (float*)Y; g.y_bf16 = y_bf16; g.bias = bias; g.B = B; g.N = N; g.K = K;
   g.ldy = N; g.act = act; g.accumulate = accumulate; g.ksplit = ksplit; g.partial = partial;
+  g.x_tiled = layout & 1; g.y_tiled = (layout >> 1) & 1;
   return skinny_mfma(g, (hipStream_t)stream);
 }
 
 int itts_ln_rows_bf16(void* y, float* x, const float* gamma, const float* beta, int rows, int D, float eps, int passes,
-                      const float* partial, int nsplit, const float* partial_bias, itts_stream stream) {
+                      const float* partial, int nsplit, const float* partial_bias, int y_tiled, itts_stream stream) {
   (void)hipGetLastError();
   if (!y || !x || rows <= 0) {
     set_error("itts_ln_rows_bf16: bad arguments");
     return E_INVALID;
   }
-  return ln_rows_bf16(y, x, gamma, beta, rows, D, eps, passes, partial, nsplit, partial_bias, (hipStream_t)stream);
+  return ln_rows_bf16(y, x, gamma, beta, rows, D, eps, passes, partial, nsplit, partial_bias, y_tiled, (hipStream_t)stream);
 }
 
 int itts_transpose(void* y, const void* x, int B, int R, int C, int dtype, itts_stream stream) {

@@ -442,12 +442,17 @@ template <> struct CacheVec<float> {
 // NIT = key pairs per slot held in registers (NIT * 2 * SLOTS keys: 768 with bf16 at NIT = 3).  The first pair is
 // requested before any device scalar is read, the rest as soon as the sequence length is known, all before the first
 // use: the whole cache read costs two overlapped memory latencies instead of one per iteration.
-template <typename TC, typename TO, int NIT>
-__global__ __launch_bounds__(1024) void decode_attn2_kernel(TO* __restrict__ ctx, const float* __restrict__ qkv,
-                                                            TC* __restrict__ kc, TC* __restrict__ vc,
-                                                            const int* __restrict__ len, const int* __restrict__ kv_start,
-                                                            const int* __restrict__ prefix, int H, int Smax, float scale) {
-  constexpr int DH = 64, VEC = CacheVec<TC>::VEC, LPK = CacheVec<TC>::LPK, NT = 1024, NW = NT / 64, SLOTS = NT / LPK;
+// NT = threads per (row, head): 1024 for the latency-bound small batches (one workgroup per CU), 256 once there are
+// enough (row, head) pairs to fill the CUs several times over - 5 workgroups per CU overlap their load / softmax /
+// merge phases, where the 86-VGPR 1024-thread form runs its 5 rounds per CU back to back.
+template <typename TC, typename TO, int NIT, int NT>
+__global__ __launch_bounds__(NT) void decode_attn2_kernel(TO* __restrict__ ctx, const float* __restrict__ qkv,
+                                                          TC* __restrict__ kc, TC* __restrict__ vc,
+                                                          const int* __restrict__ len, const int* __restrict__ kv_start,
+                                                          const int* __restrict__ prefix, int H, int Smax, float scale,
+                                                          int ctx_bt) {
+  constexpr int DH = 64, VEC = CacheVec<TC>::VEC, LPK = CacheVec<TC>::LPK, NW = NT / 64, SLOTS = NT / LPK;
+  constexpr int SD = NT >= 1024 ? 2 : 4;  // rows per slot in flight beyond the register window
   __shared__ float sq[DH];
   __shared__ float sm[NW], sl[NW];
   __shared__ float so[NW][DH];
@@ -523,16 +528,16 @@ __global__ __launch_bounds__(1024) void decode_attn2_kernel(TO* __restrict__ ctx
   for (int u = 0; u < 2 * NIT; ++u)
     if (u * SLOTS < S) consume(kr[u], vr[u], u * SLOTS + slot);  // block-uniform condition
   // sequences longer than the register-resident window: stream the rest two rows at a time
-  for (int jb = 2 * NIT * SLOTS; jb < S; jb += 2 * SLOTS) {
-    CacheVec<TC> k2[2], v2[2];
+  for (int jb = 2 * NIT * SLOTS; jb < S; jb += SD * SLOTS) {
+    CacheVec<TC> k2[SD], v2[SD];
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+    for (int u = 0; u < SD; ++u) {
       const int j = min(jb + u * SLOTS + slot, Smax - 1);
       k2[u].load(kb + (size_t)j * DH + sub * VEC);
       v2[u].load(vb + (size_t)j * DH + sub * VEC);
     }
 #pragma unroll
-    for (int u = 0; u < 2; ++u) consume(k2[u], v2[u], jb + u * SLOTS + slot);
+    for (int u = 0; u < SD; ++u) consume(k2[u], v2[u], jb + u * SLOTS + slot);
   }
   // merge the 64/LPK key slots of this wave (lanes with equal `sub`)
   float M = m;
@@ -567,7 +572,7 @@ __global__ __launch_bounds__(1024) void decode_attn2_kernel(TO* __restrict__ ctx
       o = fmaf(e, so[i][tid], o);
       L = fmaf(e, sl[i], L);
     }
-    stf(ctx + (size_t)b * D + h * DH + tid, o / L);
+    stf(ctx + (ctx_bt ? tile_off(b, h * DH + tid, ctx_bt) : (size_t)b * D + h * DH + tid), o / L);
   }
 }
 
@@ -743,20 +748,31 @@ int gemv_bf16(const GemvArgs& g, hipStream_t s) {
 }
 
 int decode_attn2(void* ctx, int to, const float* qkv, void* kc, void* vc, const int* len, const int* kv_start,
-                 const int* prefix_dev, int B, int H, int dh, int Smax, int tc, hipStream_t s) {
+                 const int* prefix_dev, int B, int H, int dh, int Smax, int tc, hipStream_t s, int ctx_tiled) {
   ITTS_REQUIRE(dh == 64, "decode_attn2: head dim must be 64");
+  ITTS_REQUIRE(!ctx_tiled || to == BF16, "decode_attn2: tiled ctx is bf16 only");
   const float scale = 1.f / sqrtf((float)dh);
   dim3 grid(H, B);
-  if (tc == F32 && to == F32)
-    hipLaunchKernelGGL((decode_attn2_kernel<float, float, 3>), grid, dim3(1024), 0, s, (float*)ctx, qkv, (float*)kc, (float*)vc, len, kv_start, prefix_dev, H, Smax, scale);
-  else if (tc == BF16 && to == BF16)
-    hipLaunchKernelGGL((decode_attn2_kernel<bf16_t, bf16_t, 3>), grid, dim3(1024), 0, s, (bf16_t*)ctx, qkv, (bf16_t*)kc, (bf16_t*)vc, len, kv_start, prefix_dev, H, Smax, scale);
-  else if (tc == BF16 && to == F32)
-    hipLaunchKernelGGL((decode_attn2_kernel<bf16_t, float, 3>), grid, dim3(1024), 0, s, (float*)ctx, qkv, (bf16_t*)kc, (bf16_t*)vc, len, kv_start, prefix_dev, H, Smax, scale);
-  else {
+  const int bt = ctx_tiled ? (B + 15) / 16 : 0;
+  const bool many = (long)B * H >= 512;
+#define LAUNCH(TCT, TOT)                                                                                                  \
+  if (many)                                                                                                               \
+    hipLaunchKernelGGL((decode_attn2_kernel<TCT, TOT, 3, 256>), grid, dim3(256), 0, s, (TOT*)ctx, qkv, (TCT*)kc, (TCT*)vc, len, \
+                       kv_start, prefix_dev, H, Smax, scale, bt);                                                         \
+  else                                                                                                                    \
+    hipLaunchKernelGGL((decode_attn2_kernel<TCT, TOT, 3, 1024>), grid, dim3(1024), 0, s, (TOT*)ctx, qkv, (TCT*)kc, (TCT*)vc,    \
+                       len, kv_start, prefix_dev, H, Smax, scale, bt);
+  if (tc == F32 && to == F32) {
+    LAUNCH(float, float)
+  } else if (tc == BF16 && to == BF16) {
+    LAUNCH(bf16_t, bf16_t)
+  } else if (tc == BF16 && to == F32) {
+    LAUNCH(bf16_t, float)
+  } else {
     set_error("decode_attn2: dtype combination");
     return E_INVALID;
   }
+#undef LAUNCH
   ITTS_HIP_CHECK(hipGetLastError());
   return OK;
 }

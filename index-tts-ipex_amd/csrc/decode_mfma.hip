@@ -17,6 +17,7 @@ typedef float f32x4v __attribute__((ext_vector_type(4)));
 
 constexpr int SW = 8;  // waves per workgroup (K split inside the workgroup)
 
+
 // NT = 16-feature tiles per workgroup (each wave multiplies the same X fragments into NT weight tiles: X is the larger
 // L2->CU stream at B = 64, so two tiles per workgroup halve it per output); gridDim.y = K split across workgroups
 // (ksplit > 1: raw partial sums go to g.partial[split][b][n]; bias / residual are applied by ln_rows_bf16).
@@ -35,9 +36,14 @@ __global__ __launch_bounds__(512) void skinny_mfma_kernel(GemvArgs g) {
   const bf16_t* wp[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t) wp[t] = W + (size_t)min(n0 + t * 16 + fr, g.N - 1) * K + fg * 8 + (size_t)ks0 * 32;
+  // X either row-major [B][K] or fragment-tiled [K/32][BT][64 lanes][8] (tile_off): one MFMA operand = 1 KiB contiguous
+  const int btr = (g.B + 15) >> 4;  // batch tiles that exist (the template rounds up to 1 / 2 / 4 / 8)
+  const int xstep = g.x_tiled ? btr * 512 : 32;
   const bf16_t* xp[BT];
 #pragma unroll
-  for (int bt = 0; bt < BT; ++bt) xp[bt] = X + (size_t)min(bt * 16 + fr, g.B - 1) * K + fg * 8 + (size_t)ks0 * 32;
+  for (int bt = 0; bt < BT; ++bt)
+    xp[bt] = g.x_tiled ? X + ((size_t)ks0 * btr + min(bt, btr - 1)) * 512 + lane * 8
+                       : X + (size_t)min(bt * 16 + fr, g.B - 1) * K + fg * 8 + (size_t)ks0 * 32;
   f32x4v acc[NT][BT];
 #pragma unroll
   for (int t = 0; t < NT; ++t)
@@ -55,7 +61,7 @@ __global__ __launch_bounds__(512) void skinny_mfma_kernel(GemvArgs g) {
     for (int u = 0; u < SU; ++u) {
       const int ks = min(k0 + u * SW, nks - 1);
 #pragma unroll
-      for (int bt = 0; bt < BT; ++bt) xf[u][bt] = *reinterpret_cast<const bf16x8*>(xp[bt] + (size_t)ks * 32);
+      for (int bt = 0; bt < BT; ++bt) xf[u][bt] = *reinterpret_cast<const bf16x8*>(xp[bt] + (size_t)ks * xstep);
     }
 #pragma unroll
     for (int u = 0; u < SU; ++u) {
@@ -90,7 +96,7 @@ __global__ __launch_bounds__(512) void skinny_mfma_kernel(GemvArgs g) {
     if (g.bias) v += g.bias[n];
     v = act_apply(g.act, v);
     if (g.y_bf16)
-      reinterpret_cast<bf16_t*>(g.Y)[o] = (bf16_t)v;
+      reinterpret_cast<bf16_t*>(g.Y)[g.y_tiled ? tile_off(b, n, btr) : o] = (bf16_t)v;
     else if (g.accumulate)
       g.Y[o] += v;
     else
@@ -103,7 +109,7 @@ __global__ __launch_bounds__(512) void skinny_mfma_kernel(GemvArgs g) {
 __global__ __launch_bounds__(256) void ln_rows_bf16_kernel(bf16_t* __restrict__ y, float* __restrict__ x,
                                                            const float* __restrict__ g1, const float* __restrict__ b1,
                                                            int D, float eps, int passes, const float* __restrict__ partial,
-                                                           int nsplit, const float* __restrict__ pbias, int rows) {
+                                                           int nsplit, const float* __restrict__ pbias, int rows, int y_tiled) {
   __shared__ float red[2][2][4];
   const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   constexpr int MAXE = 8;  // D <= 2048
@@ -153,7 +159,10 @@ __global__ __launch_bounds__(256) void ln_rows_bf16_kernel(bf16_t* __restrict__ 
   }
 #pragma unroll
   for (int i = 0; i < MAXE; ++i)
-    if (tid + i * 256 < D) y[(size_t)row * D + tid + i * 256] = (bf16_t)v[i];
+    if (tid + i * 256 < D) {
+      const int c = tid + i * 256;
+      y[y_tiled ? tile_off(row, c, (rows + 15) >> 4) : (size_t)row * D + c] = (bf16_t)v[i];
+    }
 }
 
 }  // namespace
@@ -189,11 +198,12 @@ int skinny_mfma(const GemvArgs& g, hipStream_t s) {
 }
 
 int ln_rows_bf16(void* y, float* x, const float* g1, const float* b1, int rows, int D, float eps, int passes,
-                 const float* partial, int nsplit, const float* pbias, hipStream_t s) {
+                 const float* partial, int nsplit, const float* pbias, int y_tiled, hipStream_t s) {
   ITTS_REQUIRE(D <= 2048 && passes >= 1 && passes <= 2, "ln_rows_bf16: D > 2048 or bad pass count");
   ITTS_REQUIRE(nsplit == 0 || partial, "ln_rows_bf16: partial sums missing");
+  ITTS_REQUIRE(!y_tiled || D % 32 == 0, "ln_rows_bf16: tiled output needs D % 32 == 0");
   hipLaunchKernelGGL(ln_rows_bf16_kernel, dim3(rows), dim3(256), 0, s, (bf16_t*)y, x, g1, b1, D, eps, passes, partial, nsplit,
-                     pbias, rows);
+                     pbias, rows, y_tiled);
   ITTS_HIP_CHECK(hipGetLastError());
   return OK;
 }

@@ -22,7 +22,15 @@ struct GemvArgs {
   float ln_eps = 1e-5f;
   int ksplit = 1;            // skinny_mfma: K split across workgroups; > 1 writes raw sums to partial[split][B][ldy]
   float* partial = nullptr;
+  int x_tiled = 0, y_tiled = 0;  // skinny_mfma: bf16 X / Y in MFMA-fragment tiles (tile_off) instead of row-major
 };
+
+// bf16 activations of the batched decode step live in the operand order of v_mfma_f32_16x16x32_bf16: element (b, k) of a
+// [B, K] matrix at ((k/32) * BT + b/16) * 512 + ((k%32)/8 * 16 + b%16) * 8 + k%8, BT = ceil(B/16) - every (k-step, batch
+// tile) fragment is one contiguous KiB, which the L2 -> CU path streams ~2.4x faster than 16 rows x 64 B.
+__host__ __device__ inline size_t tile_off(int b, int k, int BT) {
+  return ((size_t)(k >> 5) * BT + (b >> 4)) * 512 + ((((k & 31) >> 3) << 4) + (b & 15)) * 8 + (k & 7);
+}
 
 struct SamplerArgs {
   const float* logits = nullptr;  // [B, V]
@@ -49,7 +57,7 @@ int kv_scatter(void* kc, void* vc, const void* qkv, int B, int S, int H, int dh,
 bool gemv2_supported(const GemvArgs& g);
 int gemv2(const GemvArgs& g, int tw, hipStream_t s);
 int decode_attn2(void* ctx, int to, const float* qkv, void* kc, void* vc, const int* len, const int* kv_start,
-                 const int* prefix_dev, int B, int H, int dh, int Smax, int tc, hipStream_t s);
+                 const int* prefix_dev, int B, int H, int dh, int Smax, int tc, hipStream_t s, int ctx_tiled = 0);
 bool gemv_bf16_supported(const GemvArgs& g);
 int gemv_bf16(const GemvArgs& g, hipStream_t s);
 int sampler2_step(const SamplerArgs& a, int B, hipStream_t s);
@@ -60,6 +68,6 @@ int decode_embed2(float* h, const void* emb, const void* pos, const int* tok, co
 bool skinny_mfma_supported(const GemvArgs& g);
 int skinny_mfma(const GemvArgs& g, hipStream_t s);
 int ln_rows_bf16(void* y, float* x, const float* g1, const float* b1, int rows, int D, float eps, int passes,
-                 const float* partial, int nsplit, const float* pbias, hipStream_t s);
+                 const float* partial, int nsplit, const float* pbias, int y_tiled, hipStream_t s);
 
 }  // namespace itts

@@ -123,7 +123,8 @@ int Engine::ensure_decode_state(int B, int Smax, int max_gen, hipStream_t s) {
     d.cache_bytes = need;
   }
   if (regrow) {
-    const int cb = std::max(B, d.cap_B), cg = std::max(max_gen, d.cap_gen);
+    // rows rounded up to 16: the batched decode keeps its bf16 activations in 16-row MFMA tiles
+    const int cb = (std::max(B, d.cap_B) + 15) / 16 * 16, cg = std::max(max_gen, d.cap_gen);
     ITTS_TRY(dev_alloc((void**)&d.h, (size_t)cb * D * 4));
     ITTS_TRY(dev_alloc((void**)&d.qkv, (size_t)cb * 3 * D * 4));
     ITTS_TRY(dev_alloc((void**)&d.ctx, (size_t)cb * D * 4));
@@ -244,10 +245,11 @@ int Engine::head_and_sample(hipStream_t s) {
   g.ln2_beta = nullptr;
   if (adt == BF16 && B > 4 && D % 32 == 0 && D <= 2048) {
     // batched decode: ln_f -> final_norm as a row kernel (bf16), head on the matrix cores
-    ITTS_TRY(ln_rows_bf16(ds.hn, ds.h, gpt.ln_f.g, gpt.ln_f.b, B, D, 1e-5f, 2, ds.partial, ds.pend_split, ds.pend_bias, s));
+    ITTS_TRY(ln_rows_bf16(ds.hn, ds.h, gpt.ln_f.g, gpt.ln_f.b, B, D, 1e-5f, 2, ds.partial, ds.pend_split, ds.pend_bias, 1, s));
     ds.pend_split = 0;
     g.X = ds.hn;
     g.x_bf16 = 1;
+    g.x_tiled = 1;
     g.prologue = 0;
     ITTS_TRY(skinny_mfma(g, s));
   } else if (adt == BF16 && gemv_bf16_supported(g)) {
@@ -296,7 +298,7 @@ int Engine::decode_step_launch(hipStream_t s) {
     if (skinny) {
       if (g.prologue == 1) {  // LayerNorm as a row kernel (its affine lives in the projection); it also absorbs the
                               // split-K partial sums of the projection that fed the residual stream
-        ITTS_TRY(ln_rows_bf16(ds.hn, ds.h, g.ln_gamma, g.ln_beta, B, g.K, g.ln_eps, 1, ds.partial, ds.pend_split, ds.pend_bias, s));
+        ITTS_TRY(ln_rows_bf16(ds.hn, ds.h, g.ln_gamma, g.ln_beta, B, g.K, g.ln_eps, 1, ds.partial, ds.pend_split, ds.pend_bias, 1, s));
         ds.pend_split = 0;
         g.X = ds.hn;
         g.x_bf16 = 1;
@@ -309,6 +311,8 @@ int Engine::decode_step_launch(hipStream_t s) {
         ds.pend_split = g.ksplit;
         ds.pend_bias = g.bias;
       }
+      g.x_tiled = 1;           // every bf16 activation of this path (hn, ctx, act) is fragment-tiled
+      g.y_tiled = g.y_bf16;
       return skinny_mfma(g, s);
     }
     if (fast && gemv_bf16_supported(g)) return gemv_bf16(g, s);
@@ -340,7 +344,7 @@ int Engine::decode_step_launch(hipStream_t s) {
     ITTS_TRY(run(g, L.attn.dt));
     const size_t lo = (size_t)l * B * H * ds.Smax * dh * es;
     ITTS_TRY(decode_attn2(ds.ctx, bf_ctx ? BF16 : F32, ds.qkv, (char*)ds.kc + lo, (char*)ds.vc + lo, ds.len, ds.kv_start,
-                          ds.prefix_dev, B, H, dh, ds.Smax, adt, s));
+                          ds.prefix_dev, B, H, dh, ds.Smax, adt, s, skinny ? 1 : 0));
     GemvArgs p;  // h += ctx Wproj + b
     p.B = B;
     p.X = ds.ctx;

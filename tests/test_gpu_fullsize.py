@@ -59,15 +59,24 @@ def test_full_conditioning_and_greedy_fp32(eng32, mel, gold):
 
 
 def test_full_greedy_bf16_divergence_report(eng16, mel, gold):
-    """bf16 cannot be bit-exact against fp32; report the first divergence step and the reference margin there."""
+    """bf16 cannot be bit-exact against fp32 (with PRNG weights the first-step logits move by ~1 on a scale of 11 while
+    the reference top-1/top-2 margin is 0.097): report the first divergence step, and bound the first-step logits error
+    on the reference's top-8 entries: rel-RMS < 0.15, bf16 argmax inside the reference top-8."""
     g = gold("full_decode_b1")
     cond = eng16.conditioning(mel)
+    eng16.prefill(cond, g["text"], 48)
+    _, lg = eng16.fetch(logits=True)
+    eng16._exit()
+    idx, val = g["top_idx"][0], g["top_val"][0]
+    err = rms_rel(lg[0, idx], val)
     codes = eng16.generate(cond, g["text"], 48)
     same = codes[0] == g["codes"][0, : codes.shape[1]]
     first = int(np.argmin(same)) if not same.all() else codes.shape[1]
     margin = float(g["top_val"][min(first, 47), 0] - g["top_val"][min(first, 47), 1])
-    print(f"bf16 full-size greedy: first divergence at step {first}/48 (reference top1-top2 raw margin there {margin:.4f})")
-    assert first >= 1
+    print(f"bf16 full-size greedy: first divergence at step {first}/48 (reference top1-top2 raw margin there {margin:.4f}); "
+          f"first-step top-8 logits rel-RMS {err:.4f}")
+    assert err < 0.15
+    assert int(lg[0].argmax()) in set(int(i) for i in idx)
 
 
 def test_full_padding_batch_invariance_fp32(eng32, mel, gold):
@@ -110,3 +119,38 @@ def test_full_roundtrip_properties_bf16(eng16, mel):
     lat = eng16.latent(cond, text, a[0])
     wav = eng16.bigvgan(lat, eng16.ecapa(mel.transpose(1, 2)))
     assert wav.shape == (1, 1, 64 * 1024) and float(wav.abs().max()) <= 1.0 and torch.isfinite(wav).all()
+
+
+def test_full_batched_decode_matches_small_batch_bf16(eng16, mel, gold):
+    """Batched decode (B = 32 rows: LayerNorm row kernel, MFMA projections with tiled activations, split-K residual
+    projections, 256-thread cache attention) against the B = 2 GEMV path on the same two sentences: replicated rows
+    are bit-identical, logits agree within bf16 tolerance while the greedy ids agree."""
+    g = gold("full_decode_b1")
+    cond = eng16.conditioning(mel)
+    t2 = np.stack([g["text"][0], synth.text_ids(g["text"].shape[1], 77, CFG.gpt.number_text_tokens)]).astype(np.int32)
+    t32 = np.concatenate([t2] * 16, 0)
+    n = 12
+    eng16.prefill(cond, t2, n, 10.0, True)
+    small = []
+    for k in range(n):
+        small.append(eng16.fetch(logits=True))
+        if k + 1 < n:
+            eng16.decode(1)
+    eng16._exit()
+    eng16.prefill(cond, t32, n, 10.0, True)
+    worst, compared = 0.0, 0
+    alive = [True, True]
+    for k in range(n):
+        codes, lg = eng16.fetch(logits=True)
+        for r in range(2, 32):
+            assert np.array_equal(lg[r], lg[r % 2]), (k, r)
+        for r in range(2):
+            if alive[r]:
+                worst = max(worst, rms_rel(lg[r], small[k][1][r]))
+                compared += 1
+                alive[r] = codes[r, k] == small[k][0][r, k]
+        if k + 1 < n:
+            eng16.decode(1)
+    eng16._exit()
+    print(f"batched vs small-batch decode: {compared} row-steps compared, worst logits rel-RMS {worst:.4f}")
+    assert compared >= 2 and worst < 3e-2  # ids of the two paths part early with PRNG weights (bf16 noise vs tiny margins)

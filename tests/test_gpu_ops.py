@@ -229,12 +229,30 @@ def test_attention_mfma_vs_simple(lib, case):
         assert relerr(got[b][valid[b]], ref[b][valid[b]].float()) < 1.5e-2
 
 
+def to_tiles(x, BT):
+    """row-major [B, K] -> MFMA-fragment tiles (csrc/itts_decode.h tile_off), padded rows poisoned with NaN"""
+    B, K = x.shape
+    xp = torch.full((BT * 16, K), float("nan"), dtype=x.dtype)
+    xp[:B] = x
+    return xp.view(BT, 16, K // 32, 4, 8).permute(2, 0, 3, 1, 4).contiguous().view(-1)
+
+
+def from_tiles(t, B, K):
+    BT = (B + 15) // 16
+    return t.view(K // 32, BT, 4, 16, 8).permute(1, 3, 0, 2, 4).reshape(BT * 16, K)[:B]
+
+
 @pytest.mark.gpu
+@pytest.mark.parametrize("tiled", [0, 1])
 @pytest.mark.parametrize("case", [(64, 3840, 1280, 0, 0, 0), (8, 1280, 5120, 0, 1, 0), (33, 5120, 1280, 1, 0, 1),
                                   (128, 8194, 1280, 0, 0, 0), (5, 66, 128, 0, 0, 0), (17, 40, 96, 0, 1, 0)])
-def test_skinny_gemm(lib, case):
-    """decode projections at batch > 4: weights streamed once, batch on MFMA; vs fp64 math on the same bf16 inputs."""
+def test_skinny_gemm(lib, case, tiled):
+    """decode projections at batch > 4: weights streamed once, batch on MFMA; vs fp64 math on the same bf16 inputs.
+    tiled: bf16 X (and bf16 Y) in MFMA-fragment order, as the decode step keeps them."""
     B, N, K, gelu, acc, ybf = case
+    if tiled and N % 32 and ybf:
+        pytest.skip("tiled output needs N % 32 == 0")
+    BT = (B + 15) // 16
     x = (rnd("sk.x", (B, K)) * 1.5).to(torch.bfloat16)
     w = (rnd("sk.w", (N, K)) * 0.05).to(torch.bfloat16)
     bias = rnd("sk.b", (N,))
@@ -244,20 +262,27 @@ def test_skinny_gemm(lib, case):
         ref = 0.5 * ref * (1 + torch.tanh(0.7978845608028654 * (ref + 0.044715 * ref ** 3)))
     if acc:
         ref = ref + y0.double()
-    xd, wd, bd = x.to(DEV), w.to(DEV), bias.to(DEV)
-    y = y0.to(DEV).clone() if not ybf else torch.empty(B, N, dtype=torch.bfloat16, device=DEV)
-    L.check(lib.itts_skinny_gemm(y.data_ptr(), ybf, xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), B, N, K,
-                                 L.ACT_GELU_NEW if gelu else L.ACT_NONE, acc, 1, None, stream()))
+    xd, wd, bd = (to_tiles(x, BT) if tiled else x).to(DEV), w.to(DEV), bias.to(DEV)
+    layout = 3 if tiled else 0
+    y = y0.to(DEV).clone() if not ybf else torch.empty(BT * 16 * N, dtype=torch.bfloat16, device=DEV)
+    act = L.ACT_GELU_NEW if gelu else L.ACT_NONE
+    L.check(lib.itts_skinny_gemm(y.data_ptr(), ybf, xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), B, N, K, act, acc, 1, None,
+                                 layout, stream()))
     torch.cuda.synchronize()
-    assert relerr(y.float(), ref.float()) < (1e-2 if ybf else 2e-5)
-    # rows do not depend on the rest of the batch (same row alone gives the same bits)
+    if ybf:
+        got = from_tiles(y.cpu(), B, N) if tiled else y.cpu()[:B * N].view(B, N)
+    else:
+        got = y.cpu()
+    assert relerr(got.float(), ref.float()) < (1e-2 if ybf else 2e-5)
+    # rows do not depend on the rest of the batch, nor on the layout (same row alone, row-major, gives the same bits)
     if not acc:
-        y1 = torch.empty(1, N, dtype=y.dtype, device=DEV)
+        y1 = torch.empty(16 * N if ybf else N, dtype=y.dtype, device=DEV)
         r = B // 2
-        L.check(lib.itts_skinny_gemm(y1.data_ptr(), ybf, xd[r:r + 1].contiguous().data_ptr(), wd.data_ptr(), bd.data_ptr(), 1, N,
-                                     K, L.ACT_GELU_NEW if gelu else L.ACT_NONE, 0, 1, None, stream()))
+        x1 = x[r:r + 1].contiguous().to(DEV)
+        L.check(lib.itts_skinny_gemm(y1.data_ptr(), ybf, x1.data_ptr(), wd.data_ptr(), bd.data_ptr(), 1, N, K, act, 0, 1, None, 0,
+                                     stream()))
         torch.cuda.synchronize()
-        assert torch.equal(y1[0], y[r])
+        assert torch.equal(y1.cpu()[:N], got[r])
 
 
 @pytest.mark.gpu
@@ -272,9 +297,13 @@ def test_ln_rows_bf16(lib, passes):
     xd, gd, bd = x.to(DEV), g.to(DEV), b.to(DEV)
     y = torch.empty(rows, D, dtype=torch.bfloat16, device=DEV)
     L.check(lib.itts_ln_rows_bf16(y.data_ptr(), xd.data_ptr(), gd.data_ptr(), bd.data_ptr(), rows, D, 1e-5, passes, None, 0,
-                                  None, stream()))
+                                  None, 0, stream()))
+    yt = torch.empty(((rows + 15) // 16) * 16 * D, dtype=torch.bfloat16, device=DEV)
+    L.check(lib.itts_ln_rows_bf16(yt.data_ptr(), xd.data_ptr(), gd.data_ptr(), bd.data_ptr(), rows, D, 1e-5, passes, None, 0,
+                                  None, 1, stream()))
     torch.cuda.synchronize()
     assert relerr(y.float(), ref.float()) < 6e-3
+    assert torch.equal(from_tiles(yt.cpu(), rows, D), y.cpu())
 
 
 @pytest.mark.gpu
@@ -292,18 +321,18 @@ def test_skinny_splitk_absorbed_by_layernorm(lib, case):
     xd, wd, bd, hd = x.to(DEV), w.to(DEV), bias.to(DEV), h0.to(DEV).clone()
     part = torch.full((S, B, N), float("nan"), device=DEV)
     L.check(lib.itts_skinny_gemm(None, 0, xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), B, N, K, L.ACT_NONE, 1, S,
-                                 part.data_ptr(), stream()))
+                                 part.data_ptr(), 0, stream()))
     y = torch.empty(B, N, dtype=torch.bfloat16, device=DEV)
     L.check(lib.itts_ln_rows_bf16(y.data_ptr(), hd.data_ptr(), None, None, B, N, 1e-5, 1, part.data_ptr(), S, bd.data_ptr(),
-                                  stream()))
+                                  0, stream()))
     torch.cuda.synchronize()
     assert relerr(hd, h_ref.float()) < 2e-5
     assert relerr(y.float(), y_ref.float()) < 6e-3
     # run-to-run determinism
     hd2 = h0.to(DEV).clone()
     L.check(lib.itts_skinny_gemm(None, 0, xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), B, N, K, L.ACT_NONE, 1, S,
-                                 part.data_ptr(), stream()))
+                                 part.data_ptr(), 0, stream()))
     L.check(lib.itts_ln_rows_bf16(y.data_ptr(), hd2.data_ptr(), None, None, B, N, 1e-5, 1, part.data_ptr(), S, bd.data_ptr(),
-                                  stream()))
+                                  0, stream()))
     torch.cuda.synchronize()
     assert torch.equal(hd, hd2)
