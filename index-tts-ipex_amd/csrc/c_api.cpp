@@ -1,4 +1,5 @@
 // extern "C" boundary of libitts_hip (declared in include/itts_hip.h).
+#include <cstdlib>
 #include <cstring>
 #include <new>
 
@@ -12,6 +13,8 @@ struct itts_engine {
 
 namespace itts {
 int gemm(const GemmArgs& g, int ta, int tw, int tc, hipStream_t s) {
+  static const bool no_conv_lds = getenv("ITTS_NO_CONV_LDS") != nullptr;
+  if (!no_conv_lds && conv_lds_supported(g, ta, tw, tc)) return conv_lds(g, s);
   if (gemm_mfma_supported(g, ta, tw, tc)) return gemm_mfma(g, ta, tw, tc, s);
   return gemm_simple(g, ta, tw, tc, s);
 }

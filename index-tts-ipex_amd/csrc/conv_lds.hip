@@ -1,0 +1,211 @@
+// LDS-tiled 1-D convolution on the matrix cores for the narrow BigVGAN stages (AMPBlock1 convs with C = 24 / 48 / 96
+// channels, k = 3 / 7 / 11, dilation 1 / 3 / 5; indextts/BigVGAN/models.py:20-81).
+//
+// The generic shift-GEMM (gemm_mfma.hip) re-fetches the activation rows once per tap; with K = k*C this small the
+// kernel is bound by that global->LDS traffic, not by MFMA.  Here one workgroup owns a time tile of one batch item:
+// the BM + (k-1)*dil input rows it needs (halo included, zero padded) are brought into LDS ONCE with contiguous
+// 16-byte loads (channels-last rows are adjacent in memory), every tap then reads its MFMA A-fragments from that
+// resident tile at a row offset.  Only the small weight slab streams (32-channel chunks, register-staged pairs).
+// The epilogue goes back through LDS so residual / accumulate reads and the output store are 16-byte row-contiguous
+// (C = 24 rows are 48 bytes: per-lane scalar stores would waste most of every HBM burst).
+// v_mfma_f32_16x16x32_bf16; fp32 accumulation; bf16 in / out.
+#include "itts_kernels.h"
+
+namespace itts {
+namespace {
+
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int WROW = 40;  // bf16 per staged weight row (80 bytes, conflict-free ds_read_b128)
+
+// MT x NT 16x16 tiles per wave, WAVES_M x WAVES_N waves (= 4)
+template <int MT, int NT, int WAVES_M, int WAVES_N>
+__global__ __launch_bounds__(256) void conv_lds_kernel(GemmArgs g, int tiles_per_item, int HR, int CP) {
+  constexpr int BM = WAVES_M * MT * 16, NP = WAVES_N * NT * 16;
+  constexpr int WROWS = (NP + 63) / 64;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  bf16_t* sA = reinterpret_cast<bf16_t*>(smem);                              // [HR][CP]
+  bf16_t* sW = reinterpret_cast<bf16_t*>(smem + (size_t)HR * CP * 2);        // [2][NP][WROW]
+  float* sC = reinterpret_cast<float*>(smem);                                // epilogue: [BM][NP + 4]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+  const int b = blockIdx.x / tiles_per_item, t0 = (blockIdx.x - b * tiles_per_item) * BM;
+  const int T = g.T, C = g.Cin, K = g.taps * C;
+  const bf16_t* __restrict__ A = (const bf16_t*)g.A + (size_t)b * T * g.lda;
+  const bf16_t* __restrict__ W = (const bf16_t*)g.W;
+
+  // ---- resident input tile: rows t0 - pad_left + i, zero outside [0, T); pad columns zero ----
+  {
+    const int vpr = CP >> 3, cv = C >> 3, nvec = HR * vpr;
+    for (int v = tid; v < nvec; v += 256) {
+      const int i = v / vpr, q = v - i * vpr;
+      const int ts = t0 - g.pad_left + i;
+      u32x4 val = u32x4{0u, 0u, 0u, 0u};
+      if (q < cv && ts >= 0 && ts < T) val = *reinterpret_cast<const u32x4*>(A + (size_t)ts * g.lda + q * 8);
+      *reinterpret_cast<u32x4*>(sA + (size_t)i * CP + q * 8) = val;
+    }
+  }
+  const int cpt = (C + 31) >> 5, nchunk = g.taps * cpt, npair = (nchunk + 1) >> 1;
+  const int lr = tid >> 2, lq = tid & 3;
+  const bf16_t* w_row[WROWS];
+#pragma unroll
+  for (int p = 0; p < WROWS; ++p) w_row[p] = W + (size_t)min(lr + 64 * p, g.N - 1) * K;
+  u32x4 rw[2][WROWS];
+  auto load_w = [&](int pr) {
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const int ch = 2 * pr + c;
+      const bool live = ch < nchunk;
+      const int chc = live ? ch : 0;
+      const int tap = chc / cpt, c0 = (chc - tap * cpt) << 5;
+      const bool cok = live && lq * 8 < C - c0;
+      const int cq = cok ? lq * 8 : 0;
+#pragma unroll
+      for (int p = 0; p < WROWS; ++p) {
+        const u32x4 v = *reinterpret_cast<const u32x4*>(w_row[p] + (size_t)tap * C + c0 + cq);
+        rw[c][p] = (cok && lr + 64 * p < g.N) ? v : u32x4{0u, 0u, 0u, 0u};  // rows >= N and channels >= C multiply as zero
+      }
+    }
+  };
+  auto store_w = [&]() {
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int p = 0; p < WROWS; ++p)
+        if (lr + 64 * p < NP) *reinterpret_cast<u32x4*>(sW + ((size_t)c * NP + lr + 64 * p) * WROW + lq * 8) = rw[c][p];
+  };
+  f32x4v acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = f32x4v{0.f, 0.f, 0.f, 0.f};
+  load_w(0);
+  store_w();
+  __syncthreads();
+  const int fr = lane & 15, fk = (lane >> 4) * 8;
+  const bf16_t* a_lane = sA + (size_t)(wm * MT * 16 + fr) * CP + fk;
+  const bf16_t* w_lane = sW + (size_t)(wn * NT * 16 + fr) * WROW + fk;
+  for (int pr = 0; pr < npair; ++pr) {
+    if (pr + 1 < npair) load_w(pr + 1);
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const int ch = 2 * pr + c;
+      if (ch < nchunk) {  // block-uniform
+        const int tap = ch / cpt, c0 = (ch - tap * cpt) << 5;
+        const bool cok = fk < C - c0;  // lanes past the last channel of a partial chunk read zero
+        const bf16_t* ap = a_lane + (size_t)tap * g.dil * CP + c0;
+        bf16x8 af[MT], wf[NT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+          const bf16x8 v = *reinterpret_cast<const bf16x8*>(ap + (size_t)i * 16 * CP);
+          af[i] = cok ? v : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+        }
+#pragma unroll
+        for (int j = 0; j < NT; ++j) wf[j] = *reinterpret_cast<const bf16x8*>(w_lane + ((size_t)c * NP + j * 16) * WROW);
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], wf[j], acc[i][j], 0, 0, 0);
+      }
+    }
+    __syncthreads();  // every wave is done with this weight pair (and, on the last pass, with the input tile)
+    if (pr + 1 < npair) {
+      store_w();
+      __syncthreads();
+    }
+  }
+  // ---- epilogue through LDS: fp32 tile [BM][NP + 4], then row-contiguous 16-byte traffic ----
+  constexpr int CS = NP + 4;
+  const int cr = (lane >> 4) * 4, cc = lane & 15;
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) sC[(size_t)(wm * MT * 16 + i * 16 + cr + r) * CS + wn * NT * 16 + j * 16 + cc] = acc[i][j][r];
+  __syncthreads();
+  const int nv = g.N >> 3;  // 8-column vectors per row
+  bf16_t* __restrict__ Cc = (bf16_t*)g.C + (size_t)b * T * g.ldc;
+  const bf16_t* __restrict__ R = g.R ? (const bf16_t*)g.R + (size_t)b * T * g.ldr : nullptr;
+  const bf16_t* __restrict__ ADD = g.ADD ? (const bf16_t*)g.ADD + (size_t)b * T * g.ldadd : nullptr;
+  const float* bias = g.bias ? g.bias + (size_t)b * g.bias_bstride : nullptr;
+  for (int v = tid; v < BM * nv; v += 256) {
+    const int m = v / nv, q = v - m * nv, t = t0 + m;
+    if (t >= T) continue;
+    const int n = q * 8;
+    float o[8];
+    const float4 s0 = *reinterpret_cast<const float4*>(sC + (size_t)m * CS + n);
+    const float4 s1 = *reinterpret_cast<const float4*>(sC + (size_t)m * CS + n + 4);
+    o[0] = s0.x; o[1] = s0.y; o[2] = s0.z; o[3] = s0.w; o[4] = s1.x; o[5] = s1.y; o[6] = s1.z; o[7] = s1.w;
+    u32x4 rv = u32x4{0u, 0u, 0u, 0u}, av = u32x4{0u, 0u, 0u, 0u};
+    if (R) rv = *reinterpret_cast<const u32x4*>(R + (size_t)t * g.ldr + n);
+    if (ADD) av = *reinterpret_cast<const u32x4*>(ADD + (size_t)t * g.ldadd + n);
+    const bf16_t* rb = reinterpret_cast<const bf16_t*>(&rv);
+    const bf16_t* ab = reinterpret_cast<const bf16_t*>(&av);
+    u32x4 ov;
+    bf16_t* ob = reinterpret_cast<bf16_t*>(&ov);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float x = o[e];
+      if (bias) x += bias[n + e];
+      x = act_apply(g.act, x);
+      x = x * (g.scale ? g.scale[n + e] : 1.f) + (g.shift ? g.shift[n + e] : 0.f);
+      x = act_apply(g.act2, x);
+      if (R) x += (float)rb[e];
+      x *= g.alpha;
+      if (ADD) x += g.beta * (float)ab[e];
+      ob[e] = (bf16_t)x;
+    }
+    *reinterpret_cast<u32x4*>(Cc + (size_t)t * g.ldc + n) = ov;
+  }
+}
+
+struct Plan {
+  int bm, np, hr, cp;
+  size_t lds;
+};
+
+template <int MT, int NT, int WAVES_M, int WAVES_N>
+int launch(const GemmArgs& g, hipStream_t s) {
+  constexpr int BM = WAVES_M * MT * 16, NP = WAVES_N * NT * 16;
+  const int HR = BM + (g.taps - 1) * g.dil, CP = g.Cin + 8;
+  const size_t lds_main = (size_t)HR * CP * 2 + (size_t)2 * NP * WROW * 2;
+  const size_t lds_epi = (size_t)BM * (NP + 4) * 4;
+  const size_t lds = lds_main > lds_epi ? lds_main : lds_epi;
+  const int B = g.M / g.T, tiles = (g.T + BM - 1) / BM;
+  static bool attr_done = false;
+  if (!attr_done) {
+    ITTS_HIP_CHECK(hipFuncSetAttribute((const void*)conv_lds_kernel<MT, NT, WAVES_M, WAVES_N>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((conv_lds_kernel<MT, NT, WAVES_M, WAVES_N>), dim3(B * tiles), dim3(256), lds, s, g, tiles, HR, CP);
+  ITTS_HIP_CHECK(hipGetLastError());
+  return OK;
+}
+
+}  // namespace
+
+bool conv_lds_supported(const GemmArgs& g, int ta, int tw, int tc) {
+  if (ta != BF16 || tw != BF16 || tc != BF16) return false;
+  if (g.nphase != 1 || g.in_up != 1 || g.pad_mode != PAD_ZERO || g.taps < 3) return false;
+  if (g.Cin % 8 != 0 || g.Cin > 96 || g.Cin < 16 || g.N % 8 != 0 || g.N > 96) return false;
+  if (((g.Cin + 8) / 2) % 8 != 4) return false;  // LDS row stride must be an odd multiple of 16 bytes
+  if (g.T <= 0 || g.M % g.T != 0 || g.T < 256) return false;
+  if (g.lda % 8 || g.ldc % 8 || (g.R && g.ldr % 8) || (g.ADD && g.ldadd % 8)) return false;
+  if (((uintptr_t)g.A | (uintptr_t)g.W | (uintptr_t)g.C | (uintptr_t)g.R | (uintptr_t)g.ADD) & 15) return false;
+  if ((g.taps - 1) * g.dil > 64) return false;
+  return true;
+}
+
+int conv_lds(const GemmArgs& g, hipStream_t s) {
+  ITTS_REQUIRE(g.A && g.W && g.C, "conv_lds: null pointer");
+  ITTS_REQUIRE(conv_lds_supported(g, BF16, BF16, BF16), "conv_lds: unsupported shape");
+  if (g.N <= 32) return launch<4, 2, 4, 1>(g, s);
+  if (g.N <= 48) return launch<4, 3, 4, 1>(g, s);
+  return launch<4, 3, 2, 2>(g, s);
+}
+
+}  // namespace itts

@@ -106,24 +106,34 @@ __global__ __launch_bounds__(512) void skinny_mfma_kernel(GemvArgs g) {
 
 // y(bf16) = LN(x) [-> LN again for the head]; optional affine on the first pass.  With nsplit > 0 the row first absorbs a
 // split-K projection: x += bias + sum_s partial[s] (fixed order), written back to the fp32 residual stream.
+template <int MAXE>
 __global__ __launch_bounds__(256) void ln_rows_bf16_kernel(bf16_t* __restrict__ y, float* __restrict__ x,
                                                            const float* __restrict__ g1, const float* __restrict__ b1,
                                                            int D, float eps, int passes, const float* __restrict__ partial,
                                                            int nsplit, const float* __restrict__ pbias, int rows, int y_tiled) {
   __shared__ float red[2][2][4];
   const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  constexpr int MAXE = 8;  // D <= 2048
   float v[MAXE];
   float* xr = x + (size_t)row * D;
 #pragma unroll
   for (int i = 0; i < MAXE; ++i) v[i] = tid + i * 256 < D ? xr[tid + i * 256] : 0.f;
   if (nsplit > 0) {
+    // all partial loads of a thread are issued together (up to 4 splits x MAXE elements), then summed in split order
+    float pv[4][MAXE], bv[MAXE];
+#pragma unroll
+    for (int i = 0; i < MAXE; ++i) {
+      const int c = min(tid + i * 256, D - 1);
+      bv[i] = pbias ? pbias[c] : 0.f;
+#pragma unroll
+      for (int sp = 0; sp < 4; ++sp) pv[sp][i] = sp < nsplit ? partial[((size_t)sp * rows + row) * D + c] : 0.f;
+    }
 #pragma unroll
     for (int i = 0; i < MAXE; ++i) {
       const int c = tid + i * 256;
       if (c < D) {
-        float a = pbias ? pbias[c] : 0.f;
-        for (int sp = 0; sp < nsplit; ++sp) a += partial[((size_t)sp * rows + row) * D + c];
+        float a = bv[i];
+#pragma unroll
+        for (int sp = 0; sp < 4; ++sp) a += pv[sp][i];
         v[i] += a;
         xr[c] = v[i];
       }
@@ -200,10 +210,14 @@ int skinny_mfma(const GemvArgs& g, hipStream_t s) {
 int ln_rows_bf16(void* y, float* x, const float* g1, const float* b1, int rows, int D, float eps, int passes,
                  const float* partial, int nsplit, const float* pbias, int y_tiled, hipStream_t s) {
   ITTS_REQUIRE(D <= 2048 && passes >= 1 && passes <= 2, "ln_rows_bf16: D > 2048 or bad pass count");
-  ITTS_REQUIRE(nsplit == 0 || partial, "ln_rows_bf16: partial sums missing");
+  ITTS_REQUIRE(nsplit == 0 || (partial && nsplit <= 4), "ln_rows_bf16: partial sums missing or more than 4 splits");
   ITTS_REQUIRE(!y_tiled || D % 32 == 0, "ln_rows_bf16: tiled output needs D % 32 == 0");
-  hipLaunchKernelGGL(ln_rows_bf16_kernel, dim3(rows), dim3(256), 0, s, (bf16_t*)y, x, g1, b1, D, eps, passes, partial, nsplit,
-                     pbias, rows, y_tiled);
+  if (D <= 1280)
+    hipLaunchKernelGGL(ln_rows_bf16_kernel<5>, dim3(rows), dim3(256), 0, s, (bf16_t*)y, x, g1, b1, D, eps, passes, partial,
+                       nsplit, pbias, rows, y_tiled);
+  else
+    hipLaunchKernelGGL(ln_rows_bf16_kernel<8>, dim3(rows), dim3(256), 0, s, (bf16_t*)y, x, g1, b1, D, eps, passes, partial,
+                       nsplit, pbias, rows, y_tiled);
   ITTS_HIP_CHECK(hipGetLastError());
   return OK;
 }

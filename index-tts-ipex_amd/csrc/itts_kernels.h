@@ -10,6 +10,8 @@ namespace itts {
 int gemm_simple(const GemmArgs& g, int ta, int tw, int tc, hipStream_t s);
 bool gemm_mfma_supported(const GemmArgs& g, int ta, int tw, int tc);
 int gemm_mfma(const GemmArgs& g, int ta, int tw, int tc, hipStream_t s);
+bool conv_lds_supported(const GemmArgs& g, int ta, int tw, int tc);
+int conv_lds(const GemmArgs& g, hipStream_t s);
 int gemm(const GemmArgs& g, int ta, int tw, int tc, hipStream_t s);  // dispatcher
 
 // ---- anti-aliased SnakeBeta (snake.hip); x,y [B,T,C] ----

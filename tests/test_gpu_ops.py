@@ -336,3 +336,37 @@ def test_skinny_splitk_absorbed_by_layernorm(lib, case):
                                   0, stream()))
     torch.cuda.synchronize()
     assert torch.equal(hd, hd2)
+
+
+AMP_CASES = [
+    # B, T, C, k, dil   (AMPBlock1 convs of the narrow BigVGAN stages; T not a multiple of the time tile)
+    (2, 700, 24, 3, 1), (1, 1000, 24, 11, 5), (2, 515, 48, 7, 3), (1, 769, 48, 11, 1), (2, 300, 96, 3, 5), (1, 641, 96, 11, 5),
+    (1, 256, 96, 7, 1), (3, 257, 24, 7, 5),
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", AMP_CASES)
+def test_conv_lds_amp_shapes(lib, case):
+    """LDS-resident conv kernel (conv_lds.hip) vs fp64 torch conv1d on the same bf16 inputs, with the full AMP epilogue:
+    per-batch bias, residual, alpha scaling and beta * running-sum accumulate; also bit-compared per row against the
+    generic shift-GEMM path within bf16 rounding."""
+    B, T, Cc, k, dil = case
+    x = rnd(f"al.x{case}", (B, Cc, T)).to(torch.bfloat16)
+    w = rnd(f"al.w{case}", (Cc, Cc, k), 1.0 / np.sqrt(Cc * k)).to(torch.bfloat16)
+    bias = rnd(f"al.b{case}", (B, Cc), 0.1)
+    res = rnd(f"al.r{case}", (B, Cc, T)).to(torch.bfloat16)
+    run = rnd(f"al.s{case}", (B, Cc, T)).to(torch.bfloat16)
+    pad = dil * (k - 1) // 2
+    ref = F.conv1d(F.pad(x.double(), (pad, pad)), w.double(), None, dilation=dil) + bias.double()[:, :, None]
+    ref = (ref + res.double()) * (1.0 / 3.0) + 1.0 * run.double()
+    A = x.transpose(1, 2).contiguous().to(DEV)
+    W = torch.from_numpy(pack.conv_w(w.float().numpy())).to(torch.bfloat16).to(DEV)
+    R = res.transpose(1, 2).contiguous().to(DEV)
+    S = run.transpose(1, 2).contiguous().to(DEV)
+    kw = dict(M=B * T, N=Cc, Cin=Cc, taps=k, lda=Cc, ldc=Cc, T=T, dil=dil, pad_left=pad, pad_mode=0, bias=bias.to(DEV),
+              bias_bstride=Cc, R=R, ldr=Cc, alpha=1.0 / 3.0, ADD=S, ldadd=Cc, beta=1.0)
+    out = run_gemm(lib, A, W, (B, T, Cc), L.BF16, L.BF16, L.BF16, 0, **kw)
+    assert relerr(out.float().transpose(1, 2), ref.float()) < 1.5e-2
+    gen = run_gemm(lib, A, W, (B, T, Cc), L.BF16, L.BF16, L.BF16, 1, **kw)  # vector kernel, fp32 accumulate
+    assert relerr(out.float(), gen.float()) < 1.5e-2
