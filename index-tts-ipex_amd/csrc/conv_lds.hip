@@ -162,15 +162,13 @@ __global__ __launch_bounds__(256) void conv_lds_kernel(GemmArgs g, int tiles_per
   }
 }
 
-struct Plan {
-  int bm, np, hr, cp;
-  size_t lds;
-};
+// LDS row pitch (bf16 elements): channels + pad such that pitch/2 dwords is an odd multiple of 4 (conflict-free b128 reads)
+inline int row_pitch(int C) { return ((C + 8) / 2) % 8 == 4 ? C + 8 : C + 16; }
 
 template <int MT, int NT, int WAVES_M, int WAVES_N>
 int launch(const GemmArgs& g, hipStream_t s) {
   constexpr int BM = WAVES_M * MT * 16, NP = WAVES_N * NT * 16;
-  const int HR = BM + (g.taps - 1) * g.dil, CP = g.Cin + 8;
+  const int HR = BM + (g.taps - 1) * g.dil, CP = row_pitch(g.Cin);
   const size_t lds_main = (size_t)HR * CP * 2 + (size_t)2 * NP * WROW * 2;
   const size_t lds_epi = (size_t)BM * (NP + 4) * 4;
   const size_t lds = lds_main > lds_epi ? lds_main : lds_epi;
@@ -192,7 +190,7 @@ bool conv_lds_supported(const GemmArgs& g, int ta, int tw, int tc) {
   if (ta != BF16 || tw != BF16 || tc != BF16) return false;
   if (g.nphase != 1 || g.in_up != 1 || g.pad_mode != PAD_ZERO || g.taps < 3) return false;
   if (g.Cin % 8 != 0 || g.Cin > 96 || g.Cin < 16 || g.N % 8 != 0 || g.N > 96) return false;
-  if (((g.Cin + 8) / 2) % 8 != 4) return false;  // LDS row stride must be an odd multiple of 16 bytes
+  if ((row_pitch(g.Cin) / 2) % 8 != 4) return false;  // LDS row stride must be an odd multiple of 16 bytes
   if (g.T <= 0 || g.M % g.T != 0 || g.T < 256) return false;
   if (g.lda % 8 || g.ldc % 8 || (g.R && g.ldr % 8) || (g.ADD && g.ldadd % 8)) return false;
   if (((uintptr_t)g.A | (uintptr_t)g.W | (uintptr_t)g.C | (uintptr_t)g.R | (uintptr_t)g.ADD) & 15) return false;

@@ -12,6 +12,8 @@
 // and the 6-sample input window in registers: per output it does 2 new up-FIR phases (12 FMA), 2
 // SnakeBeta evaluations and the 12-tap down-FIR (no 2x intermediate ever reaches HBM).  fp32 math,
 // I/O in fp32 or bf16.
+#include <cstdlib>
+
 #include "itts_kernels.h"
 
 namespace itts {
@@ -111,6 +113,132 @@ __global__ __launch_bounds__(256) void snake_aa_kernel(T* __restrict__ y, const 
 }
 
 
+// ---- channels-last, LDS-tiled: the form used for every C % 8 == 0 ----------------------------------------------------
+// One workgroup owns TT = (256 / CT) * RUN time steps x CT channels (CT = C for the narrow stages, a 64-channel slab
+// otherwise).  The TT + 12 input rows arrive with 16-byte loads issued back to back (rows of a narrow stage are
+// adjacent in memory, so the tile is one contiguous span), each lane then slides down its channel reading LDS, and the
+// outputs leave through LDS as 16-byte row-contiguous stores.  The register-window kernel above pays one dependent
+// global load per time step and 48-byte rows at C = 24; this one pays one memory latency per tile.
+// FAST: v_sin_f32 (__sinf) as the reference's fast-math CUDA build does (bf16 I/O); fp32 I/O keeps sinf for parity.
+template <typename T, bool FAST>
+__global__ __launch_bounds__(256) void snake_aa_lds_kernel(T* __restrict__ y, const T* __restrict__ x,
+                                                           const float* __restrict__ la, const float* __restrict__ lb,
+                                                           const float* __restrict__ up12, const float* __restrict__ dn12,
+                                                           int Tn, int C, int CT, int tiles_t, int slabs) {
+  constexpr int VEC = 16 / (int)sizeof(T);
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_snake[];
+  const int runs = 256 / CT, TT = runs * RUN;
+  T* sx = reinterpret_cast<T*>(smem_snake);                       // [(TT + 12)][CT]
+  T* so = sx + (size_t)(TT + 12) * CT;                            // [TT][CT]
+  int bid = blockIdx.x;
+  const int slab = bid % slabs;
+  bid /= slabs;
+  const int tile = bid % tiles_t, b = bid / tiles_t;
+  const int t0 = tile * TT, c0 = slab * CT;
+  const T* __restrict__ xb = x + (size_t)b * Tn * C + c0;
+  T* __restrict__ yb = y + (size_t)b * Tn * C + c0;
+  const int tid = threadIdx.x;
+  {
+    const int vpr = CT / VEC, nvec = (TT + 12) * vpr;
+    for (int v = tid; v < nvec; v += 256) {
+      const int i = v / vpr, q = v - i * vpr;
+      int t = t0 - 6 + i;
+      t = t < 0 ? 0 : (t >= Tn ? Tn - 1 : t);  // replicate padding resolved at load time
+      *reinterpret_cast<uint4*>(sx + (size_t)i * CT + q * VEC) = *reinterpret_cast<const uint4*>(xb + (size_t)t * C + q * VEC);
+    }
+  }
+  __syncthreads();
+  const int c = tid % CT, run = tid / CT;
+  if (run < runs) {
+    const float ea = expf(la[c0 + c]);
+    const float inv_b = 1.f / (expf(lb[c0 + c]) + 1e-9f);
+    float fu[12], fd[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {
+      fu[i] = up12[i];
+      fd[i] = dn12[i];
+    }
+    auto act = [&](float u) {
+      const float sn = FAST ? __sinf(u * ea) : sinf(u * ea);
+      return u + inv_b * sn * sn;
+    };
+    const T* col = sx + c;
+    auto xin = [&](int t) {  // x[clamp(t)] of this channel; t within [t0 - 6, t0 + TT + 6)
+      t = t < 0 ? 0 : (t >= Tn ? Tn - 1 : t);
+      return ldf(col + (size_t)(t - (t0 - 6)) * CT);
+    };
+    const int mlast = 2 * Tn - 1;
+    auto v_at = [&](int m) {
+      m = m < 0 ? 0 : (m > mlast ? mlast : m);
+      const int q = m >> 1;
+      float u = 0.f;
+      if (m & 1) {
+#pragma unroll
+        for (int r = 0; r < 6; ++r) u = fmaf(fu[2 * r], xin(q + 3 - r), u);
+      } else {
+#pragma unroll
+        for (int r = 0; r < 6; ++r) u = fmaf(fu[2 * r + 1], xin(q + 2 - r), u);
+      }
+      return act(2.f * u);
+    };
+    const int ts = t0 + run * RUN;
+    const int te = min(ts + RUN, Tn);
+    if (ts < Tn) {
+      float v[12], xs[6];
+#pragma unroll
+      for (int j = 0; j < 10; ++j) v[j] = v_at(2 * ts - 5 + j);
+#pragma unroll
+      for (int i = 0; i < 6; ++i) xs[i] = xin(ts + i);
+      for (int t = ts; t < te; ++t) {
+        float uo = 0.f, ue = 0.f;
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
+          uo = fmaf(fu[2 * r], xs[5 - r], uo);
+          ue = fmaf(fu[2 * r + 1], xs[5 - r], ue);
+        }
+        const float vprev = v[9];
+        v[10] = (2 * t + 5 <= mlast) ? act(2.f * uo) : vprev;
+        v[11] = (2 * t + 6 <= mlast) ? act(2.f * ue) : v[10];
+        float o = 0.f;
+#pragma unroll
+        for (int j = 0; j < 12; ++j) o = fmaf(fd[j], v[j], o);
+        stf(so + (size_t)(t - t0) * CT + c, o);
+#pragma unroll
+        for (int j = 0; j < 10; ++j) v[j] = v[j + 2];
+#pragma unroll
+        for (int i = 0; i < 5; ++i) xs[i] = xs[i + 1];
+        xs[5] = xin(t + 6);
+      }
+    }
+  }
+  __syncthreads();
+  {
+    const int vpr = CT / VEC, rows = min(TT, Tn - t0), nvec = rows * vpr;
+    for (int v = tid; v < nvec; v += 256) {
+      const int i = v / vpr, q = v - i * vpr;
+      *reinterpret_cast<uint4*>(yb + (size_t)(t0 + i) * C + q * VEC) = *reinterpret_cast<const uint4*>(so + (size_t)i * CT + q * VEC);
+    }
+  }
+}
+
+template <typename T, bool FAST>
+static int launch_snake_lds(void* y, const void* x, const float* la, const float* lb, const float* up12, const float* dn12,
+                            int B, int Tn, int C, hipStream_t s) {
+  int CT = C;
+  if (C > 64) {
+    CT = 64;
+    while (C % CT) CT -= 8;
+  }
+  const int runs = 256 / CT, TT = runs * RUN;
+  const int tiles_t = (Tn + TT - 1) / TT, slabs = C / CT;
+  const size_t lds = ((size_t)(TT + 12) * CT + (size_t)TT * CT) * sizeof(T);
+  hipLaunchKernelGGL((snake_aa_lds_kernel<T, FAST>), dim3((unsigned)((long)B * tiles_t * slabs)), dim3(256), lds, s, (T*)y,
+                     (const T*)x, la, lb, up12, dn12, Tn, C, CT, tiles_t, slabs);
+  ITTS_HIP_CHECK(hipGetLastError());
+  return OK;
+}
+
+
 // ---- [B,C,T] layout (the reference's native-op contract): one (b,c) row per blockIdx.y/z, LDS-staged tile ----
 constexpr int BCT_TILE = 1024;
 
@@ -192,6 +320,11 @@ int snake_aa(void* y, const void* x, const float* log_alpha, const float* log_be
              const float* down12, int B, int T, int C, int dt, hipStream_t s) {
   ITTS_REQUIRE(y && x && log_alpha && log_beta && up12 && down12, "snake_aa: null pointer");
   ITTS_REQUIRE(B > 0 && T > 0 && C > 0, "snake_aa: bad dims");
+  static const bool no_lds = getenv("ITTS_SNAKE_REG") != nullptr;
+  if (!no_lds && C % 8 == 0 && C >= 8 && (dt == F32 || dt == BF16) && !(((uintptr_t)x | (uintptr_t)y) & 15)) {
+    if (dt == F32) return launch_snake_lds<float, false>(y, x, log_alpha, log_beta, up12, down12, B, T, C, s);
+    return launch_snake_lds<bf16_t, true>(y, x, log_alpha, log_beta, up12, down12, B, T, C, s);
+  }
   const int nchunk = (T + RUN - 1) / RUN;
   const long total = (long)B * nchunk * C;
   const int blocks = (int)((total + 255) / 256);

@@ -49,7 +49,8 @@ def test_snake_golden(lib, gold, tag, layout):
     assert relerr(out, torch.from_numpy(g["y"])) < 2e-5
 
 
-@pytest.mark.parametrize("shape", [(2, 768, 100), (1, 24, 4099), (3, 5, 33)])
+@pytest.mark.parametrize("shape", [(2, 768, 100), (1, 24, 4099), (3, 5, 33), (2, 48, 1000), (1, 96, 700), (2, 192, 333),
+                                   (1, 1536, 50), (2, 24, 7), (1, 40, 321)])
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
 def test_snake_vs_oracle(lib, shape, dt):
     B, Cc, T = shape
