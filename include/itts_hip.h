@@ -114,6 +114,15 @@ int itts_conditioning(itts_engine* e, const void* mel_bfc, int F, float* cond_ou
 /* V6  ECAPA_TDNN.forward (BigVGAN/ECAPA_TDNN.py:545-581): mel [B, F, num_mels] -> spk fp32 [B, spk_dim] */
 int itts_ecapa(itts_engine* e, const void* mel_bfc, int B, int F, float* spk_out, itts_stream stream);
 
+/* Sampling mode of the next itts_gpt_prefill / itts_gpt_decode calls: HF 4.36.2 GenerationMixin.sample as
+ * indextts/infer.py:116-124 + gpt/model.py:690-703 configure it with num_beams = 1 (RepetitionPenaltyLogitsProcessor ->
+ * TemperatureLogitsWarper -> TopKLogitsWarper -> TopPLogitsWarper -> softmax -> one draw).  The draw is the inverse CDF
+ * of uniforms_host[k * B + b] (step k, row b; host array of n_uniforms >= max_gen * B floats in [0, 1)) over the kept
+ * tokens in descending-score order, so a caller-side RNG fixes the sequence.  do_sample = 0 returns to greedy.
+ * 1 <= top_k <= 64, 0 < top_p <= 1, temperature > 0. */
+int itts_gpt_set_sampling(itts_engine* e, int do_sample, int top_k, float top_p, float temperature, const float* uniforms_host,
+                          int64_t n_uniforms);
+
 /* G1/G3/G4 step 0: prepare_gpt_inputs (model.py:591-654) + prefill + first greedy token.
  * cond fp32 [latents, D]; text ids host int32 [B, L] (may hold start/stop padding ids, stripped per row).
  * Synchronises the stream once (uploads the row descriptors). */

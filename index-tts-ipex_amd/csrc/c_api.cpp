@@ -175,6 +175,11 @@ int itts_gpt_prefill(itts_engine* e, const float* cond, const int32_t* text_ids_
   ENG(e);
   return e->e.gpt_prefill(cond, text_ids_host, B, L, max_gen, repetition_penalty, suppress_stop, (hipStream_t)s);
 }
+int itts_gpt_set_sampling(itts_engine* e, int do_sample, int top_k, float top_p, float temperature, const float* uniforms_host,
+                          int64_t n_uniforms) {
+  ENG(e);
+  return e->e.gpt_set_sampling(do_sample, top_k, top_p, temperature, uniforms_host, (long)n_uniforms);
+}
 int itts_gpt_decode(itts_engine* e, int nsteps, itts_stream s) {
   ENG(e);
   return e->e.gpt_decode(nsteps, (hipStream_t)s);

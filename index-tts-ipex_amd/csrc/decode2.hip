@@ -576,6 +576,38 @@ __global__ __launch_bounds__(NT) void decode_attn2_kernel(TO* __restrict__ ctx, 
   }
 }
 
+// bookkeeping shared by the greedy and the sampling kernels (thread 0 of the row's block)
+__device__ __forceinline__ void sampler_commit(const SamplerArgs& a, int b, int choice, int* si) {
+  const int k = a.step[b];
+  si[1] = -1;
+  if (k < a.max_gen) {  // graph replays past the end are no-ops
+    const int unf = a.unfinished[b];
+    const int tok = unf ? choice : a.stop;
+    a.ids[(size_t)b * a.max_gen + k] = tok;
+    a.cur_tok[b] = tok;
+    a.seen[(size_t)b * a.V + tok] = 1;
+    a.unfinished[b] = unf && tok != a.stop;
+    a.step[b] = k + 1;
+    si[0] = tok;
+    si[1] = k + 2;  // position of the token fed at the next step: 0, 2, 3, ... (model.py:153-155)
+  }
+}
+
+// next step's input row h[b] = mel_emb[tok] + mel_pos[k + 2], fused here (one launch less per token)
+__device__ __forceinline__ void sampler_next_embedding(const SamplerArgs& a, int b, const int* si, int tid) {
+  if (a.h_next && si[1] > 0) {
+    const int tok = si[0], p = min(si[1], a.pos_rows - 1);
+    for (int i = tid; i < a.D; i += 1024) {
+      float v;
+      if (a.emb_bf16)
+        v = (float)((const bf16_t*)a.emb)[(size_t)tok * a.D + i] + (float)((const bf16_t*)a.pos)[(size_t)p * a.D + i];
+      else
+        v = ((const float*)a.emb)[(size_t)tok * a.D + i] + ((const float*)a.pos)[(size_t)p * a.D + i];
+      a.h_next[(size_t)b * a.D + i] = v;
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // sampler2: repetition penalty + argmax + bookkeeping, one 1024-thread block per row; the per-row length
 // counter is advanced by the row's own block (no cross-block step counter, no extra launch).
@@ -618,33 +650,163 @@ __global__ __launch_bounds__(1024) void sampler2_kernel(SamplerArgs a) {
         best = sv[w];
         bi = si[w];
       }
-    const int k = a.step[b];
-    si[1] = -1;
-    if (k < a.max_gen) {  // graph replays past the end are no-ops
-      const int unf = a.unfinished[b];
-      const int tok = unf ? bi : a.stop;
-      a.ids[(size_t)b * a.max_gen + k] = tok;
-      a.cur_tok[b] = tok;
-      seen[tok] = 1;
-      a.unfinished[b] = unf && tok != a.stop;
-      a.step[b] = k + 1;
-      si[0] = tok;
-      si[1] = k + 2;  // position of the token fed at the next step: 0, 2, 3, ... (model.py:153-155)
-    }
+    sampler_commit(a, b, bi, si);
   }
-  // next step's input row h[b] = mel_emb[tok] + mel_pos[k + 2], fused here (one launch less per token)
   __syncthreads();
-  if (a.h_next && si[1] > 0) {
-    const int tok = si[0], p = min(si[1], a.pos_rows - 1);
-    for (int i = tid; i < a.D; i += 1024) {
-      float v;
-      if (a.emb_bf16)
-        v = (float)((const bf16_t*)a.emb)[(size_t)tok * a.D + i] + (float)((const bf16_t*)a.pos)[(size_t)p * a.D + i];
-      else
-        v = ((const float*)a.emb)[(size_t)tok * a.D + i] + ((const float*)a.pos)[(size_t)p * a.D + i];
-      a.h_next[(size_t)b * a.D + i] = v;
+  sampler_next_embedding(a, b, si, tid);
+}
+
+// ---------------------------------------------------------------------------------------------
+// sampler_sample: the do_sample=True path of HF 4.36.2 GenerationMixin.sample as infer.py:116-124 configures it
+// (RepetitionPenaltyLogitsProcessor -> TemperatureLogitsWarper -> TopKLogitsWarper -> TopPLogitsWarper -> softmax ->
+// multinomial), one 1024-thread block per row.  Scores live in LDS; the k-th largest score is found by a 4-pass
+// radix select on order-preserving keys (no sort of the vocabulary), the <= 64 survivors are bitonic-sorted by one
+// wave, top-p and the draw run serially over them in the order torch.cumsum uses.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned order_key(float v) {
+  const unsigned u = __float_as_uint(v);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+__global__ __launch_bounds__(1024) void sampler_sample_kernel(SamplerArgs a) {
+  extern __shared__ float ssc[];  // [V] processed scores
+  __shared__ unsigned hist[256];
+  __shared__ int s_bin, s_k, s_cnt;
+  __shared__ float cval[64];
+  __shared__ int cidx[64];
+  __shared__ int si[2];
+  __shared__ float ce[64];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+  const float* __restrict__ lg = a.logits + (size_t)b * a.V;
+  const uint8_t* seen = a.seen + (size_t)b * a.V;
+  for (int i = tid; i < a.V; i += 1024) {
+    float v = lg[i];
+    if (a.penalty != 1.f && seen[i]) v = v < 0.f ? v * a.penalty : v / a.penalty;
+    if (a.suppress_stop && i == a.stop) v = -INFINITY;
+    if (a.temperature != 1.f) v = v / a.temperature;  // TemperatureLogitsWarper: scores / temperature
+    ssc[i] = v;
+  }
+  // ---- radix select: key of the top_k-th largest score ----
+  unsigned prefix = 0;
+  int kk = min(a.top_k, a.V);
+  for (int pass = 3; pass >= 0; --pass) {
+    const int shift = pass * 8;
+    if (tid < 256) hist[tid] = 0;
+    __syncthreads();
+    for (int i = tid; i < a.V; i += 1024) {
+      const unsigned key = order_key(ssc[i]);
+      if (pass == 3 || (key >> (shift + 8)) == (prefix >> (shift + 8))) atomicAdd(&hist[(key >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    if (tid < 64) {
+      const unsigned h0 = hist[4 * lane], h1 = hist[4 * lane + 1], h2 = hist[4 * lane + 2], h3 = hist[4 * lane + 3];
+      const unsigned own = h0 + h1 + h2 + h3;
+      unsigned x = own;  // inclusive suffix sum over lanes (higher lanes = larger keys)
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const unsigned t = __shfl_down(x, off, 64);
+        if (lane + off < 64) x += t;
+      }
+      const unsigned above = x - own;
+      if (above < (unsigned)kk && (unsigned)kk <= x) {  // exactly one lane
+        unsigned acc = above;
+        int bin = 4 * lane + 3;
+        const unsigned hb[4] = {h0, h1, h2, h3};
+#pragma unroll
+        for (int j = 3; j >= 0; --j) {
+          if (acc + hb[j] >= (unsigned)kk) {
+            bin = 4 * lane + j;
+            break;
+          }
+          acc += hb[j];
+        }
+        s_bin = bin;
+        s_k = kk - (int)acc;
+      }
+    }
+    __syncthreads();
+    prefix |= (unsigned)s_bin << shift;
+    kk = s_k;
+  }
+  // ---- gather the survivors (score >= k-th largest; ties kept as HF's `scores < kth` mask keeps them, up to 64) ----
+  if (tid == 0) s_cnt = 0;
+  __syncthreads();
+  for (int i = tid; i < a.V; i += 1024) {
+    const float v = ssc[i];
+    if (order_key(v) >= prefix) {
+      const int pos = atomicAdd(&s_cnt, 1);
+      if (pos < 64) {
+        cval[pos] = v;
+        cidx[pos] = i;
+      }
     }
   }
+  __syncthreads();
+  if (tid < 64) {
+    const int n = min(s_cnt, 64);
+    float v = lane < n ? cval[lane] : -INFINITY;
+    int ix = lane < n ? cidx[lane] : 0x7fffffff;
+    // bitonic sort across the wave: descending score, ascending index on ties
+#pragma unroll
+    for (int k = 2; k <= 64; k <<= 1) {
+#pragma unroll
+      for (int j = k >> 1; j > 0; j >>= 1) {
+        const float ov = __shfl_xor(v, j, 64);
+        const int oi = __shfl_xor(ix, j, 64);
+        const bool up = (lane & k) == 0;          // this k-block sorts "first is better"
+        const bool lower = (lane & j) == 0;       // this lane keeps the better of the pair when `up`
+        const bool other_better = ov > v || (ov == v && oi < ix);
+        const bool take = (lower == up) ? other_better : !other_better;
+        if (take) {
+          v = ov;
+          ix = oi;
+        }
+      }
+    }
+    cval[lane] = v;
+    cidx[lane] = ix;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    const int n = min(s_cnt, 64);
+    const float m = cval[0];
+    float* e = ce;
+    float Z = 0.f;
+    for (int r = 0; r < n; ++r) {
+      e[r] = expf(cval[r] - m);
+      Z += e[r];
+    }
+    int R = n;
+    if (a.top_p < 1.f) {
+      // TopPLogitsWarper: ascending cumulative probability <= 1 - top_p is removed; the best token always stays
+      float tail = 0.f;
+      R = 1;
+      for (int r = n - 1; r >= 1; --r) {
+        tail += e[r] / Z;
+        if (!(tail <= 1.f - a.top_p)) {
+          R = r + 1;
+          break;
+        }
+      }
+    }
+    float total = 0.f;
+    for (int r = 0; r < R; ++r) total += e[r];
+    const int k = a.step[b];
+    const float u = a.uniforms[(size_t)min(k, a.max_gen - 1) * a.B + b];
+    const float target = u * total;
+    int pick = R - 1;
+    float c = 0.f;
+    for (int r = 0; r < R; ++r) {
+      c += e[r];
+      if (c >= target) {
+        pick = r;
+        break;
+      }
+    }
+    sampler_commit(a, b, cidx[pick], si);
+  }
+  __syncthreads();
+  sampler_next_embedding(a, b, si, tid);
 }
 
 template <typename TW>
@@ -778,6 +940,14 @@ int decode_attn2(void* ctx, int to, const float* qkv, void* kc, void* vc, const 
 }
 
 int sampler2_step(const SamplerArgs& a, int B, hipStream_t s) {
+  if (a.do_sample) {
+    ITTS_REQUIRE(a.uniforms && a.top_k >= 1 && a.top_k <= 64 && a.temperature > 0.f && a.top_p > 0.f && a.B == B,
+                 "sampler: sampling needs uniforms, 1 <= top_k <= 64, temperature > 0, top_p > 0");
+    ITTS_REQUIRE((size_t)a.V * 4 <= 60 * 1024, "sampler: vocabulary too large for the LDS-resident sampler");
+    hipLaunchKernelGGL(sampler_sample_kernel, dim3(B), dim3(1024), (size_t)a.V * 4, s, a);
+    ITTS_HIP_CHECK(hipGetLastError());
+    return OK;
+  }
   hipLaunchKernelGGL(sampler2_kernel, dim3(B), dim3(1024), 0, s, a);
   ITTS_HIP_CHECK(hipGetLastError());
   return OK;

@@ -119,6 +119,11 @@ struct DecodeState {
   int suppress_stop = 0;
   hipGraphExec_t graph = nullptr;
   int graph_B = 0, graph_Smax = 0, graph_suppress = 0;
+  // multinomial sampling (itts_gpt_set_sampling): parameters baked into the captured step, uniforms [max_gen][B]
+  int do_sample = 0, top_k = 0, graph_sample = 0, graph_top_k = 0;
+  float top_p = 1.f, temperature = 1.f, graph_top_p = 1.f, graph_temperature = 1.f;
+  float* uniforms = nullptr;
+  size_t uniforms_cap = 0;
   float graph_penalty = 0.f;
   bool active = false;
 };
@@ -171,6 +176,8 @@ struct Engine {
   int gpt_prefill(const float* cond, const int32_t* text_ids, int B, int L, int max_gen, float penalty, int suppress,
                   hipStream_t s);
   int gpt_decode(int nsteps, hipStream_t s);
+  int gpt_set_sampling(int do_sample, int top_k, float top_p, float temperature, const float* uniforms_host, long n);
+  std::vector<float> sample_uniforms;  // host copy, uploaded by the next prefill
   int gpt_status(int* steps, int* n_unf, hipStream_t s);
   int gpt_fetch(int32_t* codes, float* logits, hipStream_t s);
   int gpt_latent(const float* cond, const int32_t* text_ids, int L, const int32_t* codes, int T, void* latent_out,

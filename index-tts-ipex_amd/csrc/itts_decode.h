@@ -46,6 +46,11 @@ struct SamplerArgs {
   const void* emb = nullptr;
   const void* pos = nullptr;
   int D = 0, pos_rows = 0, emb_bf16 = 0;
+  // multinomial sampling (HF GenerationMixin.sample: processors -> Temperature -> TopK -> TopP -> softmax -> draw);
+  // the draw is an inverse-CDF lookup of uniforms[k * B + b] over the kept tokens in descending-score order
+  int do_sample = 0, top_k = 0, B = 0;
+  float top_p = 1.f, temperature = 1.f;
+  const float* uniforms = nullptr;  // [max_gen][B]
 };
 
 int gemv(const GemvArgs& g, int tw, hipStream_t s);

@@ -168,6 +168,21 @@ int Engine::gpt_prefill(const float* cond_dev, const int32_t* text_ids, int B, i
   ds.prefix = sp;
   ds.penalty = penalty;
   ds.suppress_stop = suppress;
+  if (ds.do_sample) {
+    const size_t need_u = (size_t)max_gen * B;
+    ITTS_REQUIRE(sample_uniforms.size() >= need_u, "gpt_prefill: sampling enabled but fewer than max_gen * B uniforms were supplied");
+    if (need_u > ds.uniforms_cap) {
+      ITTS_HIP_CHECK(hipStreamSynchronize(s));
+      if (ds.graph) {  // the captured sampler holds the old pointer
+        (void)hipGraphExecDestroy(ds.graph);
+        ds.graph = nullptr;
+      }
+      ITTS_TRY(dev_alloc((void**)&ds.uniforms, need_u * 4));
+      ds.uniforms_cap = need_u;
+    }
+    ITTS_HIP_CHECK(hipMemcpyAsync(ds.uniforms, sample_uniforms.data(), need_u * 4, hipMemcpyHostToDevice, s));
+    ITTS_HIP_CHECK(hipStreamSynchronize(s));
+  }
   // host: row descriptors (prepare_gpt_inputs, model.py:615-639)
   std::vector<RowDesc> rd((size_t)B * S0);
   std::vector<int> kvs(B);
@@ -281,6 +296,12 @@ int Engine::head_and_sample(hipStream_t s) {
   sa.D = D;
   sa.pos_rows = c.max_mel_tokens + 3;
   sa.emb_bf16 = adt == BF16;
+  sa.do_sample = ds.do_sample;
+  sa.top_k = ds.top_k;
+  sa.top_p = ds.top_p;
+  sa.temperature = ds.temperature;
+  sa.uniforms = ds.uniforms;
+  sa.B = B;
   return sampler2_step(sa, B, s);
 }
 
@@ -388,6 +409,25 @@ int Engine::decode_step_launch(hipStream_t s) {
   return head_and_sample(s);
 }
 
+// HF GenerationMixin.sample configuration of infer.py:116-124 (do_sample, top_k, top_p, temperature); the random
+// draws are supplied by the caller as uniforms in [0, 1), one per (step, row): row-major [max_gen][B]
+int Engine::gpt_set_sampling(int do_sample, int top_k, float top_p, float temperature, const float* uniforms_host, long n) {
+  if (!do_sample) {
+    ds.do_sample = 0;
+    sample_uniforms.clear();
+    return OK;
+  }
+  ITTS_REQUIRE(top_k >= 1 && top_k <= 64, "gpt_set_sampling: top_k must be in [1, 64]");
+  ITTS_REQUIRE(top_p > 0.f && top_p <= 1.f && temperature > 0.f, "gpt_set_sampling: need 0 < top_p <= 1 and temperature > 0");
+  ITTS_REQUIRE(uniforms_host && n > 0, "gpt_set_sampling: uniforms missing");
+  ds.do_sample = 1;
+  ds.top_k = top_k;
+  ds.top_p = top_p;
+  ds.temperature = temperature;
+  sample_uniforms.assign(uniforms_host, uniforms_host + n);
+  return OK;
+}
+
 int Engine::gpt_decode(int nsteps, hipStream_t s) {
   if (!ds.active) {
     set_error("gpt_decode: call itts_gpt_prefill first");
@@ -397,7 +437,8 @@ int Engine::gpt_decode(int nsteps, hipStream_t s) {
   if (use_graph && s != nullptr) {
     DecodeState& d = ds;
     const bool stale = !d.graph || d.graph_B != d.B || d.graph_Smax != d.Smax || d.graph_penalty != d.penalty ||
-                       d.graph_suppress != d.suppress_stop;
+                       d.graph_suppress != d.suppress_stop || d.graph_sample != d.do_sample || d.graph_top_k != d.top_k ||
+                       d.graph_top_p != d.top_p || d.graph_temperature != d.temperature;
     if (stale && nsteps > 0) {
       if (d.graph) {
         (void)hipGraphExecDestroy(d.graph);
@@ -418,6 +459,10 @@ int Engine::gpt_decode(int nsteps, hipStream_t s) {
       d.graph_Smax = d.Smax;
       d.graph_penalty = d.penalty;
       d.graph_suppress = d.suppress_stop;
+      d.graph_sample = d.do_sample;
+      d.graph_top_k = d.top_k;
+      d.graph_top_p = d.top_p;
+      d.graph_temperature = d.temperature;
     }
     for (int i = 0; i < nsteps; ++i) ITTS_HIP_CHECK(hipGraphLaunch(d.graph, s));
     return OK;

@@ -180,6 +180,17 @@ class Engine:
                                           float(repetition_penalty), int(suppress_stop), self._s()), "gpt_prefill")
         self._gen = (B, max_gen)
 
+    def set_sampling(self, do_sample: bool, top_k: int = 30, top_p: float = 0.8, temperature: float = 1.0,
+                     uniforms: Optional[np.ndarray] = None):
+        """HF GenerationMixin.sample configuration (infer.py:116-124) for the following prefill/decode calls;
+        uniforms [max_gen, B] float32 in [0, 1) are the draws (step k, row b)."""
+        if not do_sample:
+            L.check(self.lib.itts_gpt_set_sampling(self.h, 0, 0, 1.0, 1.0, None, 0), "gpt_set_sampling")
+            return
+        u = np.ascontiguousarray(uniforms, dtype=np.float32)
+        L.check(self.lib.itts_gpt_set_sampling(self.h, 1, int(top_k), float(top_p), float(temperature),
+                                               u.ctypes.data_as(C.c_void_p), u.size), "gpt_set_sampling")
+
     def decode(self, nsteps: int):
         L.check(self.lib.itts_gpt_decode(self.h, nsteps, self._s()), "gpt_decode")
 
@@ -197,23 +208,35 @@ class Engine:
         return (codes, lg) if logits else codes
 
     def generate(self, cond: torch.Tensor, text_ids: np.ndarray, max_gen: int, repetition_penalty: float = 10.0,
-                 suppress_stop: bool = False, check_every: int = 16) -> np.ndarray:
-        """Greedy decode (do_sample=False, num_beams=1 of tests/padding_test.py:35-46).  Returns int64 codes
-        [B, n] with n <= max_gen: HF stops when every row has emitted stop or at max length."""
-        self.prefill(cond, text_ids, max_gen, repetition_penalty, suppress_stop)
-        done = 1
-        while done < max_gen:
-            if not suppress_stop:
-                step, unf = self.status()
-                done = step
-                if unf == 0:
-                    break
-            n = min(check_every, max_gen - done)
-            self.decode(n)
-            done += n
-        step, unf = self.status()
-        codes = self.fetch()[:, :step].astype(np.int64)
-        self._exit()
+                 suppress_stop: bool = False, check_every: int = 16, do_sample: bool = False, top_k: int = 30,
+                 top_p: float = 0.8, temperature: float = 1.0, seed: Optional[int] = None,
+                 uniforms: Optional[np.ndarray] = None) -> np.ndarray:
+        """Greedy decode (do_sample=False, num_beams=1 of tests/padding_test.py:35-46) or, with do_sample, HF
+        GenerationMixin.sample (top-k / top-p / temperature, num_beams=1; draws from `uniforms` or a numpy Generator
+        seeded with `seed`).  Returns int64 codes [B, n] with n <= max_gen: HF stops when every row has emitted stop
+        or at max length."""
+        if do_sample:
+            if uniforms is None:
+                uniforms = np.random.default_rng(seed).random((max_gen, np.asarray(text_ids).shape[0]), dtype=np.float32)
+            self.set_sampling(True, top_k, top_p, temperature, uniforms)
+        try:
+            self.prefill(cond, text_ids, max_gen, repetition_penalty, suppress_stop)
+            done = 1
+            while done < max_gen:
+                if not suppress_stop:
+                    step, unf = self.status()
+                    done = step
+                    if unf == 0:
+                        break
+                n = min(check_every, max_gen - done)
+                self.decode(n)
+                done += n
+            step, unf = self.status()
+            codes = self.fetch()[:, :step].astype(np.int64)
+            self._exit()
+        finally:
+            if do_sample:
+                self.set_sampling(False)
         # HF stops right after the step in which the last running row emitted stop: trim the look-ahead steps
         stop = self.ccfg.stop_mel_token
         n = 0

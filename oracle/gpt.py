@@ -226,15 +226,69 @@ def repetition_penalty_(scores, ids, penalty: float):
     return scores.scatter(1, ids, sc)
 
 
+def sample_distribution(scores, top_k: int, top_p: float, temperature: float):
+    """HF 4.36.2 logits warpers as GenerationMixin.sample applies them for infer.py:116-124 (TemperatureLogitsWarper ->
+    TopKLogitsWarper(min_tokens_to_keep=1) -> TopPLogitsWarper(min_tokens_to_keep=1) -> softmax), restated on one fp32 row
+    in the arithmetic order the HIP sampler uses.  Returns (token ids in descending-score order, un-normalised weights
+    e_r = exp(s_r - s_0) of the kept tokens)."""
+    import numpy as np
+
+    s = np.asarray(scores, dtype=np.float32).copy()
+    V = s.shape[0]
+    if temperature != 1.0:
+        s = (s / np.float32(temperature)).astype(np.float32)
+    k = min(int(top_k), V)
+    kth = np.partition(s, V - k)[V - k]  # TopK: keeps everything >= the k-th largest (ties stay)
+    idx = np.nonzero(s >= kth)[0]
+    order = np.lexsort((idx, -s[idx].astype(np.float64)))
+    idx = idx[order][:64]
+    v = s[idx]
+    e = np.exp((v - v[0]).astype(np.float32)).astype(np.float32)
+    Z = np.float32(0)
+    for x in e:
+        Z = np.float32(Z + x)
+    R = len(idx)
+    if top_p < 1.0:
+        # TopP: ascending cumulative probability <= 1 - top_p is removed, the best token always stays
+        tail, R = np.float32(0), 1
+        lim = np.float32(1.0) - np.float32(top_p)
+        for r in range(len(idx) - 1, 0, -1):
+            tail = np.float32(tail + np.float32(e[r] / Z))
+            if not tail <= lim:
+                R = r + 1
+                break
+    return idx[:R], e[:R]
+
+
+def sample_pick(scores, top_k: int, top_p: float, temperature: float, u: float) -> int:
+    """One multinomial draw as an inverse-CDF lookup of the uniform u over the kept tokens (descending-score order)."""
+    import numpy as np
+
+    idx, e = sample_distribution(scores, top_k, top_p, temperature)
+    total = np.float32(0)
+    for x in e:
+        total = np.float32(total + x)
+    target = np.float32(np.float32(u) * total)
+    c = np.float32(0)
+    for r, x in enumerate(e):
+        c = np.float32(c + x)
+        if c >= target:
+            return int(idx[r])
+    return int(idx[-1])
+
+
 def greedy_generate(cond, text_inputs, w: W, cfg_gpt, max_generate_length: int, repetition_penalty: float = 10.0,
-                    suppress_eos: bool = False, trace: Optional[dict] = None):
+                    suppress_eos: bool = False, trace: Optional[dict] = None, sampling: Optional[dict] = None):
     """UnifiedVoice.inference_speech (model.py:655-708) with HF 4.36.2 `generate` greedy_search semantics
     (do_sample False, num_beams 1; eos=pad=stop_mel_token; MaxLengthCriteria): hand-rolled because the
     installed transformers 5.x `generate` skips the prefill (SURVEY 8c 'Critical caveat').
 
     Step 0 feeds cat(prefix, mel_emb(start)+mel_pos[0]) (model.py:139-150); step k>=1 feeds
     mel_emb(tok)+mel_pos[mask_len - s] -> positions 0,2,3,4,... (model.py:151-155).
-    Returns codes [b, <=max_generate_length] (prefix stripped, model.py:704-705)."""
+    Returns codes [b, <=max_generate_length] (prefix stripped, model.py:704-705).
+
+    sampling = {"top_k", "top_p", "temperature", "uniforms" [max_gen, b]} switches the pick to GenerationMixin.sample
+    (do_sample=True, num_beams=1) with the draws supplied as uniforms (sample_pick)."""
     stop = cfg_gpt["stop_mel_token"]
     fake, prefix, mask = prepare_gpt_inputs(cond, text_inputs, w, cfg_gpt)
     b, s, _ = prefix.shape
@@ -252,7 +306,12 @@ def greedy_generate(cond, text_inputs, w: W, cfg_gpt, max_generate_length: int, 
         scores = repetition_penalty_(logits.clone(), ids, repetition_penalty) if repetition_penalty != 1.0 else logits
         if suppress_eos:
             scores[:, stop] = -float("inf")
-        nxt = torch.argmax(scores, dim=-1)
+        if sampling is not None:
+            k_step = ids.shape[1] - (s + 1)
+            nxt = torch.tensor([sample_pick(scores[r].numpy(), sampling["top_k"], sampling["top_p"], sampling["temperature"],
+                                            float(sampling["uniforms"][k_step, r])) for r in range(b)], dtype=torch.long)
+        else:
+            nxt = torch.argmax(scores, dim=-1)
         nxt = nxt * unfinished + stop * (1 - unfinished)
         ids = torch.cat([ids, nxt[:, None]], dim=1)
         mask = torch.cat([mask, torch.ones(b, 1, dtype=torch.long)], dim=1)

@@ -218,3 +218,25 @@ def test_decode_batched_mfma_path(eng16, gold):
     eng16._exit()
     print(f"bf16 batched decode: {k + 1} steps compared, worst logits rel-RMS {worst:.4f}")
     assert k >= 3 and worst < 5e-2
+
+
+@pytest.mark.parametrize("name,max_gen", [("micro_decode_b1", 24), ("micro_decode_b5", 24)])
+@pytest.mark.parametrize("cfgs", [(30, 0.8, 1.0), (8, 0.6, 0.7)])
+def test_sampling_ids_match_oracle_fp32(eng32, gold, name, max_gen, cfgs):
+    """do_sample=True (HF GenerationMixin.sample, num_beams=1: repetition penalty -> temperature -> top-k -> top-p ->
+    draw): with the same uniforms the HIP sampler and the oracle emit identical ids (fp32 engine, micro config)."""
+    top_k, top_p, temp = cfgs
+    c, g = gold("micro_conditioning"), gold(name)
+    cond = torch.from_numpy(c["cond"])
+    B = g["text"].shape[0]
+    u = np.random.default_rng(11).random((max_gen, B), dtype=np.float32)
+    got = eng32.generate(cond, g["text"], max_gen, do_sample=True, top_k=top_k, top_p=top_p, temperature=temp, uniforms=u)
+    w = ogpt.to_torch(synth.gpt_state_dict(CFG, 1234))
+    ref = ogpt.greedy_generate(cond, torch.from_numpy(g["text"]), w, CFG.gpt, max_gen,
+                               sampling=dict(top_k=top_k, top_p=top_p, temperature=temp, uniforms=u)).numpy()
+    assert got.shape == ref.shape, (got.shape, ref.shape)
+    assert np.array_equal(got, ref)
+    assert not np.array_equal(got, g["codes"][:, : got.shape[1]]) or top_k == 1  # it really sampled
+    # greedy still works afterwards (sampling state is reset)
+    again = eng32.generate(cond, g["text"], max_gen)
+    assert np.array_equal(again, g["codes"])

@@ -154,3 +154,35 @@ def test_full_batched_decode_matches_small_batch_bf16(eng16, mel, gold):
     eng16._exit()
     print(f"batched vs small-batch decode: {compared} row-steps compared, worst logits rel-RMS {worst:.4f}")
     assert compared >= 2 and worst < 3e-2  # ids of the two paths part early with PRNG weights (bf16 noise vs tiny margins)
+
+
+def test_full_sampling_steps_match_oracle_pick(eng32, mel, gold):
+    """Full-size vocabulary (V = 8194: 4-pass radix select, tie handling, top-p) - every sampled id equals the oracle's
+    pick from the engine's own fp32 logits of that step, with the repetition-penalty set rebuilt from the ids so far."""
+    from oracle import gpt as ogpt
+
+    g = gold("full_decode_b1")
+    cond = eng32.conditioning(mel)
+    text = np.concatenate([g["text"], g["text"]], 0)
+    n, B = 16, 2
+    u = np.random.default_rng(5).random((n, B), dtype=np.float32)
+    u[3, 0], u[4, 1] = 0.0, 0.99999994
+    eng32.set_sampling(True, 30, 0.8, 0.9, u)
+    try:
+        eng32.prefill(cond, text, n, 10.0, False)
+        for k in range(n):
+            codes, lg = eng32.fetch(logits=True)
+            for b in range(B):
+                if k > 0 and (codes[b, :k] == CFG.gpt.stop_mel_token).any():
+                    continue
+                sc = torch.from_numpy(lg[b:b + 1].copy())
+                seen = torch.from_numpy(np.concatenate([[1, CFG.gpt.start_mel_token], codes[b, :k]]).astype(np.int64))[None]  # fake ids are 1 (model.py:645)
+                sc = ogpt.repetition_penalty_(sc, seen, 10.0)
+                want = ogpt.sample_pick(sc[0].numpy(), 30, 0.8, 0.9, float(u[k, b]))
+                assert codes[b, k] == want, (k, b)
+            if k + 1 < n:
+                eng32.decode(1)
+        eng32._exit()
+    finally:
+        eng32.set_sampling(False)
+    assert (codes[0, :n] != codes[1, :n]).any()  # two rows, same text, different draws
