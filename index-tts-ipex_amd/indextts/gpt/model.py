@@ -9,6 +9,8 @@ import warnings
 import numpy as np
 import torch
 
+from itts_hip import infer_core
+
 
 class UnifiedVoice:
     def __init__(self, engine, gpt_cfg):
@@ -51,20 +53,24 @@ class UnifiedVoice:
     def inference_speech(self, speech_conditioning_mel, text_inputs, cond_mel_lengths=None, input_tokens=None,
                          num_return_sequences=1, max_generate_length=None, typical_sampling=False, typical_mass=.9,
                          **hf_generate_kwargs):
-        """Greedy decode of mel codes [b, <= max_generate_length] (model.py:655-708).  HF `generate` kwargs are
-        accepted; anything but greedy search (do_sample=False, num_beams=1) is not implemented yet and falls back
-        to greedy with a warning."""
+        """Mel codes [b, <= max_generate_length] (model.py:655-708).  HF `generate` kwargs are accepted: greedy search
+        (do_sample=False) and multinomial sampling (do_sample=True with top_k <= 64, top_p, temperature,
+        repetition_penalty) run on the device; num_beams > 1 and typical_sampling are not implemented and fall back to
+        num_beams = 1 / plain warpers with a RuntimeWarning."""
         if input_tokens is not None or num_return_sequences != 1:
             raise NotImplementedError("input_tokens / num_return_sequences > 1")
-        if hf_generate_kwargs.get("do_sample", False) or hf_generate_kwargs.get("num_beams", 1) != 1 or typical_sampling:
-            warnings.warn("itts_hip: sampling / beam search are not implemented; decoding greedily", RuntimeWarning)
+        if typical_sampling:
+            warnings.warn("itts_hip: typical sampling is not implemented; using top-k / top-p", RuntimeWarning)
+        sample_kw = infer_core.sampling_kwargs(hf_generate_kwargs.get("do_sample", False), hf_generate_kwargs.get("num_beams", 1),
+                                               hf_generate_kwargs.get("top_k", 50), hf_generate_kwargs.get("top_p", 1.0),
+                                               hf_generate_kwargs.get("temperature", 1.0))
         cond = self.get_conditioning(speech_conditioning_mel, cond_mel_lengths)
         ids = text_inputs.detach().cpu().numpy() if isinstance(text_inputs, torch.Tensor) else np.asarray(text_inputs)
         if ids.ndim == 1:
             ids = ids[None]
         max_gen = self.max_mel_tokens - 1 if max_generate_length is None else int(max_generate_length)
         rep = float(hf_generate_kwargs.get("repetition_penalty", 1.0) or 1.0)
-        codes = self._eng.generate(cond, ids, max_gen, repetition_penalty=rep)
+        codes = self._eng.generate(cond, ids, max_gen, repetition_penalty=rep, **sample_kw)
         return torch.from_numpy(codes).to(self._eng.device)
 
     @torch.no_grad()

@@ -7,7 +7,10 @@ Same constructor and methods (`extract_features`, `infer`, `infer_fast`, `set_gr
     reference's own cli.py:70 and tests call the latter, which this fork's signature rejects);
   * conditioning latents and the ECAPA speaker vector are computed once per prompt and reused across sentences;
   * all sentences of a text are decoded as one batch (what `infer_fast` does per bucket);
-  * only greedy decoding is implemented (SURVEY.md 8f row 1): other sampling settings warn and decode greedily;
+  * greedy search and multinomial sampling (do_sample with top_k <= 64 / top_p / temperature / repetition_penalty,
+    HF GenerationMixin.sample semantics) run on the device; beam search (num_beams > 1, the reference default of 3) is
+    not implemented and decodes with num_beams = 1 after a RuntimeWarning.  Draws come from a numpy Generator seeded from
+    torch's global RNG, so `torch.manual_seed` makes a run reproducible (the reference draws with torch.multinomial);
   * `is_fp16=True` selects the bf16 throughput engine, `False` the fp32 parity engine; `use_cuda_kernel` is accepted
     and ignored (the fused HIP activation is always used).
 There is no CPU fallback: without a GPU / libitts_hip.so construction raises."""
@@ -108,12 +111,11 @@ class IndexTTS:
         start = time.perf_counter()
         do_sample = kw.pop("do_sample", True)
         num_beams = kw.pop("num_beams", 3)
-        for k in ("top_p", "top_k", "temperature", "length_penalty"):
-            kw.pop(k, None)
+        top_p, top_k, temperature = kw.pop("top_p", 0.8), kw.pop("top_k", 30), kw.pop("temperature", 1.0)
+        kw.pop("length_penalty", None)
         rep = kw.pop("repetition_penalty", 10.0)
         max_mel_tokens = kw.pop("max_mel_tokens", 600)
-        if do_sample or num_beams != 1:
-            warnings.warn("itts_hip: sampling / beam search are not implemented; decoding greedily", RuntimeWarning)
+        sample_kw = infer_core.sampling_kwargs(do_sample, num_beams, top_k, top_p, temperature)
         sents = self._sentences_to_ids(text, max_text_tokens_per_sentence)
         self._set_gr_progress(0.1, "text processing...")
         cond = self.gpt.get_conditioning(prompt_mel)
@@ -124,7 +126,7 @@ class IndexTTS:
         for bi, bk in enumerate(buckets):
             t0 = time.perf_counter()
             ids = infer_core.pad_tokens_cat([x["sent"] for x in bk], self.cfg.gpt.stop_text_token)
-            codes = self.engine.generate(cond, ids, max_mel_tokens, repetition_penalty=rep)
+            codes = self.engine.generate(cond, ids, max_mel_tokens, repetition_penalty=rep, **sample_kw)
             t_gen += time.perf_counter() - t0
             if (codes[:, -1] != self.stop_mel_token).any():
                 warnings.warn(f"WARN: generation stopped due to exceeding `max_mel_tokens` ({max_mel_tokens}).", RuntimeWarning)

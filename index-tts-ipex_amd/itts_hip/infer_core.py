@@ -71,3 +71,25 @@ def pad_tokens_cat(tokens: Sequence[np.ndarray], stop_text_token: int) -> np.nda
     for i, r in enumerate(rows):
         out[i, : r.shape[0]] = r
     return out
+
+
+def sampling_kwargs(do_sample, num_beams, top_k, top_p, temperature) -> dict:
+    """HF `generate` kwargs (infer.py:116-124) -> Engine.generate keywords.  Beam search is not implemented: num_beams > 1
+    warns and decodes with one beam.  top_k outside [1, 64] (HF: 0 / None disable the warper) is clamped to 64 with a
+    warning - the device sampler keeps at most 64 candidates.  The seed is drawn from torch's global RNG so that
+    torch.manual_seed governs the run as it does for the reference's torch.multinomial."""
+    import warnings
+
+    import torch
+
+    if num_beams is not None and int(num_beams) != 1:
+        warnings.warn("itts_hip: beam search is not implemented; decoding with num_beams=1", RuntimeWarning)
+    if not do_sample:
+        return {}
+    k = int(top_k) if top_k else 0
+    if k < 1 or k > 64:
+        warnings.warn(f"itts_hip: top_k={top_k} is outside [1, 64]; using 64", RuntimeWarning)
+        k = 64
+    p = 1.0 if top_p is None else float(top_p)
+    return dict(do_sample=True, top_k=k, top_p=min(max(p, 1e-6), 1.0), temperature=float(temperature or 1.0),
+                seed=int(torch.randint(0, 2 ** 31 - 1, (1,)).item()))

@@ -58,8 +58,11 @@ def test_indextts_infer_matches_oracle(tts):
     mel = torch.from_numpy(synth.prompt_mel(61, seed=7))
     sents = [synth.text_ids(11, 11, CFG.gpt.number_text_tokens).astype(np.int32),
              synth.text_ids(7, 12, CFG.gpt.number_text_tokens).astype(np.int32)]
-    with pytest.warns(RuntimeWarning):  # default kwargs ask for beam-sample: decoded greedily with a warning
-        sr, wav = tts.infer(prompt_mel=mel, text=sents, output_path=None, max_mel_tokens=24)
+    import warnings
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", RuntimeWarning)  # "generation stopped due to exceeding max_mel_tokens"
+        sr, wav = tts.infer(prompt_mel=mel, text=sents, output_path=None, max_mel_tokens=24, do_sample=False, num_beams=1)
     assert sr == 24000 and wav.dtype == np.int16 and wav.ndim == 2 and wav.shape[1] == 1
     wg = ogpt.to_torch(synth.gpt_state_dict(CFG, 1234))
     wb = ogpt.to_torch(synth.bigvgan_state_dict(CFG, 1234))
@@ -71,6 +74,29 @@ def test_indextts_infer_matches_oracle(tts):
     assert ref.shape == wav.shape, (ref.shape, wav.shape)
     err = np.sqrt(((wav.astype(np.float64) - ref) ** 2).mean()) / np.sqrt((ref.astype(np.float64) ** 2).mean())
     assert err < 2e-3, err  # int16 quantisation + fp32 tolerance
+
+
+def test_indextts_default_kwargs_sample_reproducibly(tts):
+    """infer()'s defaults are do_sample=True, num_beams=3, top_k=30, top_p=0.8 (infer.py:116-124): beams warn and fall
+    back to one beam, the sampler runs on the device and torch.manual_seed fixes the draws."""
+    mel = torch.from_numpy(synth.prompt_mel(61, seed=7))
+    sents = [synth.text_ids(11, 11, CFG.gpt.number_text_tokens).astype(np.int32)]
+    outs = []
+    for seed in (3, 3, 4):
+        torch.manual_seed(seed)
+        with pytest.warns(RuntimeWarning, match="beam search"):
+            _, wav = tts.infer(prompt_mel=mel, text=sents, output_path=None, max_mel_tokens=24)
+        outs.append(wav)
+    assert outs[0].shape == outs[1].shape and np.array_equal(outs[0], outs[1])
+    assert outs[0].shape != outs[2].shape or not np.array_equal(outs[0], outs[2])
+    # UnifiedVoice.inference_speech with HF kwargs
+    torch.manual_seed(5)
+    a = tts.gpt.inference_speech(mel, torch.from_numpy(sents[0])[None], do_sample=True, top_k=30, top_p=0.8, temperature=1.0,
+                                 num_beams=1, repetition_penalty=10.0, max_generate_length=16)
+    torch.manual_seed(5)
+    b = tts.gpt.inference_speech(mel, torch.from_numpy(sents[0])[None], do_sample=True, top_k=30, top_p=0.8, temperature=1.0,
+                                 num_beams=1, repetition_penalty=10.0, max_generate_length=16)
+    assert torch.equal(a, b)
 
 
 def test_padding_test_through_dropin(tts, gold):
