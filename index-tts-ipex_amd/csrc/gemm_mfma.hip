@@ -31,7 +31,11 @@ __device__ __forceinline__ int reflect_idx(int t, int T) {
   return t;
 }
 
-template <int BM, int BN, typename TC, int NBUF>
+// DEPTH = chunk pairs in flight per thread (register ring).  The K loop of one workgroup costs one memory latency per
+// refill; with DEPTH pairs requested ahead the refill rate is DEPTH x higher, which is what the few-tile / long-K shapes
+// (GPT latent pass: 1242 rows, K up to 5120; BigVGAN stage 1-3 convs) need - they run 1-2 workgroups per CU, so no
+// other wave hides the latency.
+template <int BM, int BN, typename TC, int NBUF, int DEPTH>
 __global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmArgs g) {
   constexpr int WM = BM / 2, WN = BN / 2;      // wave tile
   constexpr int MT = WM / 16, NT = WN / 16;    // 16x16 MFMA tiles per wave
@@ -73,14 +77,24 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmArgs g) {
 #pragma unroll
   for (int p = 0; p < WROWS; ++p) w_row[p] = W + (size_t)min(n0 + lr + 64 * p, g.N - 1) * K;
 
-  u32x4 ra[2][AROWS], rw[2][WROWS];
-  auto load_pair = [&](int pr) {
+  struct Stage {
+    u32x4 a[2][AROWS], w[2][WROWS];
+    unsigned ok;  // validity bits (A: bit c*8+p, W: bit 16+c), applied when the stage is written to LDS - a select
+                  // next to the load would make the wave wait for the data right where it was requested
+  };
+  Stage st[DEPTH];
+  // every load is unconditional (clamped, in-bounds addresses; dead lanes are zeroed by a select afterwards): vmcnt is
+  // in-order and hipcc's wait accounting turns conservative across predicated loads
+  // loads are requested in increasing chunk order, so (tap, channel offset) of the next chunk is a running counter -
+  // no integer division in the K loop
+  int nx_ch = 0, nx_tap = 0, nx_c0 = 0;
+  const bool up1 = g.in_up == 1;
+  auto load_pair = [&](Stage& r) {
+    unsigned okbits = 0;
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
-      const int ch = 2 * pr + c;
-      const bool live = ch < nchunk;
-      const int chc = live ? ch : 0;
-      const int tap = chc / cpt, c0 = (chc - tap * cpt) * CK;
+      const bool live = nx_ch < nchunk;
+      const int tap = live ? nx_tap : 0, c0 = live ? nx_c0 : 0;
       const bool cok = lq * 8 < g.Cin - c0;   // this lane's 8 channels exist in the tap
       const int cq = cok ? lq * 8 : 0;        // clamped (in-bounds) column for masked lanes
       const int off = g.phase_shift[phase] + tap * g.dil - g.pad_left;
@@ -89,26 +103,36 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmArgs g) {
         int ts = a_t[p] + off;
         if (g.pad_mode == PAD_REFLECT && a_t[p] >= 0) ts = reflect_idx(ts, T);
         const bool ok = live && cok && ts >= 0 && ts < T;
-        const long r = a_base[p] + (ok ? ts / g.in_up : 0);
-        const u32x4 v = *reinterpret_cast<const u32x4*>(A + r * g.lda + c0 + cq);
-        ra[c][p] = ok ? v : u32x4{0u, 0u, 0u, 0u};
+        const int tsc = ok ? ts : 0;
+        const long rr = a_base[p] + (up1 ? tsc : tsc / g.in_up);
+        r.a[c][p] = *reinterpret_cast<const u32x4*>(A + rr * g.lda + c0 + cq);
+        okbits |= (ok ? 1u : 0u) << (c * 8 + p);
       }
 #pragma unroll
       for (int p = 0; p < WROWS; ++p) {
         // masked lanes multiply zeros from A: their W fragment only has to be finite and in bounds
-        const u32x4 v = *reinterpret_cast<const u32x4*>(w_row[p] + (size_t)tap * g.Cin + c0 + cq);
-        rw[c][p] = (live && cok) ? v : u32x4{0u, 0u, 0u, 0u};
+        r.w[c][p] = *reinterpret_cast<const u32x4*>(w_row[p] + (size_t)tap * g.Cin + c0 + cq);
+      }
+      okbits |= ((live && cok) ? 1u : 0u) << (16 + c);
+      ++nx_ch;
+      nx_c0 += CK;
+      if (nx_c0 >= g.Cin) {
+        nx_c0 = 0;
+        ++nx_tap;
       }
     }
+    r.ok = okbits;
   };
-  auto store_pair = [&](int buf) {
+  auto store_pair = [&](int buf, const Stage& r) {
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
 #pragma unroll
-      for (int p = 0; p < AROWS; ++p) *reinterpret_cast<u32x4*>(&sA[buf][c][lr + 64 * p][lq * 8]) = ra[c][p];
+      for (int p = 0; p < AROWS; ++p)
+        *reinterpret_cast<u32x4*>(&sA[buf][c][lr + 64 * p][lq * 8]) = ((r.ok >> (c * 8 + p)) & 1u) ? r.a[c][p] : u32x4{0u, 0u, 0u, 0u};
 #pragma unroll
       for (int p = 0; p < WROWS; ++p)
-        if (lr + 64 * p < BN) *reinterpret_cast<u32x4*>(&sW[buf][c][lr + 64 * p][lq * 8]) = rw[c][p];
+        if (lr + 64 * p < BN)
+          *reinterpret_cast<u32x4*>(&sW[buf][c][lr + 64 * p][lq * 8]) = ((r.ok >> (16 + c)) & 1u) ? r.w[c][p] : u32x4{0u, 0u, 0u, 0u};
     }
   };
 
@@ -118,28 +142,37 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmArgs g) {
 #pragma unroll
     for (int j = 0; j < NT; ++j) acc[i][j] = f32x4v{0.f, 0.f, 0.f, 0.f};
 
-  load_pair(0);
-  store_pair(0);
+#pragma unroll
+  for (int d = 0; d < DEPTH; ++d) load_pair(st[d]);  // pairs past the end load clamped addresses and are never stored
+  store_pair(0, st[0]);
   __syncthreads();
   const int fr = lane & 15, fk = (lane >> 4) * 8;
-  for (int pr = 0; pr < npair; ++pr) {
-    const int buf = NBUF == 2 ? (pr & 1) : 0;
-    if (pr + 1 < npair) load_pair(pr + 1);
+  // the trip count is rounded up to a multiple of DEPTH: pairs past the end were loaded from clamped addresses with all
+  // validity bits clear, so they reach LDS as zeros and add nothing - and the loop body stays branch-free, which keeps
+  // the ring slots in fixed registers
+  const int npair_pad = (npair + DEPTH - 1) / DEPTH * DEPTH;
+  for (int p0 = 0; p0 < npair_pad; p0 += DEPTH) {
 #pragma unroll
-    for (int c = 0; c < 2; ++c) {
-      bf16x8 af[MT], bfr[NT];
+    for (int d = 0; d < DEPTH; ++d) {
+      const int pr = p0 + d;
+      const int buf = NBUF == 2 ? (pr & 1) : 0;
+      load_pair(st[d]);  // slot d went to LDS one step ago; refill it with the pair DEPTH ahead
 #pragma unroll
-      for (int i = 0; i < MT; ++i) af[i] = *reinterpret_cast<const bf16x8*>(&sA[buf][c][wm * WM + i * 16 + fr][fk]);
+      for (int c = 0; c < 2; ++c) {
+        bf16x8 af[MT], bfr[NT];
 #pragma unroll
-      for (int j = 0; j < NT; ++j) bfr[j] = *reinterpret_cast<const bf16x8*>(&sW[buf][c][wn * WN + j * 16 + fr][fk]);
+        for (int i = 0; i < MT; ++i) af[i] = *reinterpret_cast<const bf16x8*>(&sA[buf][c][wm * WM + i * 16 + fr][fk]);
 #pragma unroll
-      for (int i = 0; i < MT; ++i)
+        for (int j = 0; j < NT; ++j) bfr[j] = *reinterpret_cast<const bf16x8*>(&sW[buf][c][wn * WN + j * 16 + fr][fk]);
 #pragma unroll
-        for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+      }
+      if (NBUF == 1) __syncthreads();  // every wave has consumed the buffer before it is overwritten
+      store_pair(NBUF == 2 ? (buf ^ 1) : 0, st[(d + 1) % DEPTH]);
+      __syncthreads();
     }
-    if (NBUF == 1) __syncthreads();  // every wave has consumed the buffer before it is overwritten
-    if (pr + 1 < npair) store_pair(NBUF == 2 ? (buf ^ 1) : 0);
-    __syncthreads();
   }
 
   // epilogue: lane holds rows (lane>>4)*4 + r, column lane&15 of each 16x16 tile
@@ -176,25 +209,41 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmArgs g) {
 
 static int g_nbuf = 1;  // 1 = single LDS buffer (more workgroups per CU; measured faster end to end), ITTS_GEMM_NBUF=2 to A/B
 
-template <int BM, int BN, typename TC>
-int launch(const GemmArgs& g, hipStream_t s) {
+static int g_depth = 0;  // 0 = per-tile default; ITTS_GEMM_DEPTH=1/2/4 to A/B
+
+template <int BM, int BN, typename TC, int DEPTH>
+int launch_d(const GemmArgs& g, hipStream_t s) {
   dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, g.nphase);
-  if (g_nbuf == 1) hipLaunchKernelGGL((gemm_mfma_kernel<BM, BN, TC, 1>), grid, dim3(256), 0, s, g);
-  else hipLaunchKernelGGL((gemm_mfma_kernel<BM, BN, TC, 2>), grid, dim3(256), 0, s, g);
+  if (g_nbuf == 1) hipLaunchKernelGGL((gemm_mfma_kernel<BM, BN, TC, 1, DEPTH>), grid, dim3(256), 0, s, g);
+  else hipLaunchKernelGGL((gemm_mfma_kernel<BM, BN, TC, 2, DEPTH>), grid, dim3(256), 0, s, g);
   ITTS_HIP_CHECK(hipGetLastError());
   return OK;
 }
 
+template <int BM, int BN, typename TC, int DDEF>
+int launch(const GemmArgs& g, hipStream_t s) {
+  const int d = g_depth ? g_depth : DDEF;
+  if (d <= 1) return launch_d<BM, BN, TC, 1>(g, s);
+  if (d == 2) return launch_d<BM, BN, TC, 2>(g, s);
+  return launch_d<BM, BN, TC, 4>(g, s);
+}
+
 template <typename TC>
 int dispatch(const GemmArgs& g, hipStream_t s) {
-  // tile choice: the K loop of one workgroup is latency-bound (register-staged, one chunk pair ahead), so what matters
-  // first is having several workgroups per CU (256 CUs); among shapes that do, prefer the larger tile (fewer LDS
-  // bytes per MFMA).
+  // tile choice: the K loop of one workgroup is latency-bound (register-staged), so what matters first is having several
+  // workgroups per CU (256 CUs); among shapes that do, prefer the larger tile (fewer LDS bytes per MFMA).  Small tiles
+  // carry a deeper register ring (their stages are cheap: 16 VGPRs per pair at 64x64).
   auto tiles = [&](int bm, int bn) { return (long)((g.M + bm - 1) / bm) * ((g.N + bn - 1) / bn) * g.nphase; };
-  if (g.N <= 32) return launch<128, 32, TC>(g, s);
-  if (g.N >= 128 && tiles(128, 128) >= 768) return launch<128, 128, TC>(g, s);
-  if (tiles(128, 64) >= 512 || g.M <= 64) return g.M <= 64 ? launch<64, 64, TC>(g, s) : launch<128, 64, TC>(g, s);
-  return launch<64, 64, TC>(g, s);
+  // ring depth: deep where a CU holds 1-2 workgroups (nothing else hides the refill latency), 1 where there are many
+  // tiles per CU (the extra registers would cost more occupancy than the ring buys)
+  if (g.N <= 32) return launch<128, 32, TC, 1>(g, s);
+  if (g.N >= 128 && tiles(128, 128) >= 768)
+    return tiles(128, 128) >= 1536 ? launch<128, 128, TC, 1>(g, s) : launch<128, 128, TC, 2>(g, s);
+  if (tiles(128, 64) >= 512 || g.M <= 64) {
+    if (g.M <= 64) return launch<64, 64, TC, 4>(g, s);
+    return tiles(128, 64) >= 768 ? launch<128, 64, TC, 1>(g, s) : launch<128, 64, TC, 2>(g, s);
+  }
+  return launch<64, 64, TC, 4>(g, s);
 }
 
 }  // namespace
@@ -211,6 +260,8 @@ int gemm_mfma(const GemmArgs& g, int ta, int tw, int tc, hipStream_t s) {
   static const bool once = [] {
     const char* e = getenv("ITTS_GEMM_NBUF");
     if (e) g_nbuf = atoi(e) == 2 ? 2 : 1;
+    const char* dd = getenv("ITTS_GEMM_DEPTH");
+    if (dd) g_depth = atoi(dd);
     return true;
   }();
   (void)once;
