@@ -53,19 +53,26 @@ __global__ __launch_bounds__(256) void conv_lds_kernel(GemmArgs g, int tiles_per
 #pragma unroll
   for (int p = 0; p < WROWS; ++p) w_row[p] = W + (size_t)min(lr + 64 * p, g.N - 1) * K;
   u32x4 rw[2][WROWS];
-  auto load_w = [&](int pr) {
+  unsigned wok = 0;
+  int nx_ch = 0, nx_tap = 0, nx_c0 = 0;  // weight chunks are requested in order: running (tap, channel) counters, no division
+  auto load_w = [&]() {
+    wok = 0;
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
-      const int ch = 2 * pr + c;
-      const bool live = ch < nchunk;
-      const int chc = live ? ch : 0;
-      const int tap = chc / cpt, c0 = (chc - tap * cpt) << 5;
+      const bool live = nx_ch < nchunk;
+      const int tap = live ? nx_tap : 0, c0 = live ? nx_c0 : 0;
       const bool cok = live && lq * 8 < C - c0;
       const int cq = cok ? lq * 8 : 0;
 #pragma unroll
       for (int p = 0; p < WROWS; ++p) {
-        const u32x4 v = *reinterpret_cast<const u32x4*>(w_row[p] + (size_t)tap * C + c0 + cq);
-        rw[c][p] = (cok && lr + 64 * p < g.N) ? v : u32x4{0u, 0u, 0u, 0u};  // rows >= N and channels >= C multiply as zero
+        rw[c][p] = *reinterpret_cast<const u32x4*>(w_row[p] + (size_t)tap * C + c0 + cq);
+        wok |= ((cok && lr + 64 * p < g.N) ? 1u : 0u) << (c * 8 + p);  // rows >= N and channels >= C multiply as zero
+      }
+      ++nx_ch;
+      nx_c0 += 32;
+      if (nx_c0 >= C) {
+        nx_c0 = 0;
+        ++nx_tap;
       }
     }
   };
@@ -74,26 +81,27 @@ __global__ __launch_bounds__(256) void conv_lds_kernel(GemmArgs g, int tiles_per
     for (int c = 0; c < 2; ++c)
 #pragma unroll
       for (int p = 0; p < WROWS; ++p)
-        if (lr + 64 * p < NP) *reinterpret_cast<u32x4*>(sW + ((size_t)c * NP + lr + 64 * p) * WROW + lq * 8) = rw[c][p];
+        if (lr + 64 * p < NP)
+          *reinterpret_cast<u32x4*>(sW + ((size_t)c * NP + lr + 64 * p) * WROW + lq * 8) =
+              ((wok >> (c * 8 + p)) & 1u) ? rw[c][p] : u32x4{0u, 0u, 0u, 0u};
   };
   f32x4v acc[MT][NT];
 #pragma unroll
   for (int i = 0; i < MT; ++i)
 #pragma unroll
     for (int j = 0; j < NT; ++j) acc[i][j] = f32x4v{0.f, 0.f, 0.f, 0.f};
-  load_w(0);
+  load_w();
   store_w();
   __syncthreads();
   const int fr = lane & 15, fk = (lane >> 4) * 8;
   const bf16_t* a_lane = sA + (size_t)(wm * MT * 16 + fr) * CP + fk;
   const bf16_t* w_lane = sW + (size_t)(wn * NT * 16 + fr) * WROW + fk;
+  int tap = 0, c0 = 0;  // chunk consumed by the MFMAs, same running-counter scheme
   for (int pr = 0; pr < npair; ++pr) {
-    if (pr + 1 < npair) load_w(pr + 1);
+    load_w();  // pair pr + 1 (past the end: clamped addresses, stored as zeros and never read)
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
-      const int ch = 2 * pr + c;
-      if (ch < nchunk) {  // block-uniform
-        const int tap = ch / cpt, c0 = (ch - tap * cpt) << 5;
+      if (2 * pr + c < nchunk) {  // block-uniform
         const bool cok = fk < C - c0;  // lanes past the last channel of a partial chunk read zero
         const bf16_t* ap = a_lane + (size_t)tap * g.dil * CP + c0;
         bf16x8 af[MT], wf[NT];
@@ -108,6 +116,11 @@ __global__ __launch_bounds__(256) void conv_lds_kernel(GemmArgs g, int tiles_per
         for (int i = 0; i < MT; ++i)
 #pragma unroll
           for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], wf[j], acc[i][j], 0, 0, 0);
+        c0 += 32;
+        if (c0 >= C) {
+          c0 = 0;
+          ++tap;
+        }
       }
     }
     __syncthreads();  // every wave is done with this weight pair (and, on the last pass, with the input tile)
