@@ -185,10 +185,19 @@ __global__ __launch_bounds__(256) void snake_aa_lds_kernel(T* __restrict__ y, co
     const int te = min(ts + RUN, Tn);
     if (ts < Tn) {
       float v[12], xs[6];
+#if defined(SNAKE_EXPERIMENT) && SNAKE_EXPERIMENT == 2
+#pragma unroll
+      for (int j = 0; j < 10; ++j) v[j] = xin(ts + j - 5);
+#else
 #pragma unroll
       for (int j = 0; j < 10; ++j) v[j] = v_at(2 * ts - 5 + j);
+#endif
 #pragma unroll
       for (int i = 0; i < 6; ++i) xs[i] = xin(ts + i);
+#if defined(SNAKE_EXPERIMENT) && SNAKE_EXPERIMENT == 1
+      for (int t = ts; t < te; ++t) stf(so + (size_t)(t - t0) * CT + c, xin(t) + v[0]);
+      if (false)
+#endif
       for (int t = ts; t < te; ++t) {
         float uo = 0.f, ue = 0.f;
 #pragma unroll
@@ -197,8 +206,13 @@ __global__ __launch_bounds__(256) void snake_aa_lds_kernel(T* __restrict__ y, co
           ue = fmaf(fu[2 * r + 1], xs[5 - r], ue);
         }
         const float vprev = v[9];
+#if defined(SNAKE_EXPERIMENT) && SNAKE_EXPERIMENT == 3
+        v[10] = (2 * t + 5 <= mlast) ? 2.f * uo : vprev;
+        v[11] = (2 * t + 6 <= mlast) ? 2.f * ue : v[10];
+#else
         v[10] = (2 * t + 5 <= mlast) ? act(2.f * uo) : vprev;
         v[11] = (2 * t + 6 <= mlast) ? act(2.f * ue) : v[10];
+#endif
         float o = 0.f;
 #pragma unroll
         for (int j = 0; j < 12; ++j) o = fmaf(fd[j], v[j], o);
