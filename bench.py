@@ -259,7 +259,9 @@ def main():
     try:
         pm = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_decode.json"))
         if pm:
-            traffic = int(json.load(open(os.path.join(ROOT, "profiles", pm[-1])))["traffic_over_algorithmic"] * step_bytes)
+            pj = json.load(open(os.path.join(ROOT, "profiles", pm[-1])))
+            if int(pj.get("decode_rows", -1)) == B and a.dtype == "bf16" and not a.micro:  # same kernels as the PMC run only
+                traffic = int(pj["traffic_over_algorithmic"] * step_bytes)
     except Exception:
         traffic = None
     out = {
@@ -270,7 +272,8 @@ def main():
         "config": {"workload": ("IndexTTS-1.5, %d utterance(s)/GPU x %d sentences x (L=%d text tokens, T=%d mel codes), "
                                 "prompt %d frames, greedy fixed-length decode, rep_penalty 10" % (BU, NS, L, T, a.prompt_frames)),
                    "utterances_per_gpu": BU, "decode_batch": B, "audio_sec_per_step_per_gpu": round(audio_s / a.steps / world, 3)},
-        "roofline": {"bound": "hbm", "kernel": "gpt decode step (hipGraph: 97 gemv + 24 cache-attention + sampler)",
+        "roofline": {"bound": "hbm", "kernel": ("gpt decode step (hipGraph: 97 gemv + 24 cache-attention + sampler)" if B <= 4 else
+                                                "gpt decode step (hipGraph: 97 skinny MFMA gemm + 49 layernorm + 24 cache-attention + sampler)"),
                      "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                      "algorithmic_bytes_per_launch": int(step_bytes), "avg_launch_ms": round(ms_step, 4),

@@ -34,3 +34,12 @@ json.dump({"mel_tokens": T, "decode_rows": B, "fetch_kib_raw_per_step": f["per_s
           open("$out/pmc_decode.json", "w"), indent=1)
 print(open("$out/pmc_decode.json").read())
 PY
+# BASELINE config 3 (32 utterances per GPU = 64 decode rows): bench line + kernel summary
+python3 $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --batch 32 --no-cpu-baseline > $out/bench_b32.json 2> $out/bench_b32.err
+tail -1 $out/bench_b32.json | cut -c1-300
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats32 -- python3 $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --batch 32 --no-cpu-baseline > $out/bench_b32_profiled.json 2> $out/prof32.err
+t=$(find $out/stats32 -name "*kernel_trace.csv" | head -1)
+python3 $GRAFT_REPO_ROOT/tools/trace_summary.py "$t" > $out/kernel_summary_b32.txt
+cp $(find $out/stats32 -name "*kernel_stats.csv" | head -1) $out/kernel_stats_b32.csv
+rm -rf $out/stats32
+head -8 $out/kernel_summary_b32.txt | cut -c1-200
