@@ -297,6 +297,19 @@ __global__ __launch_bounds__(256) void gemv_bf16_kernel(GemvArgs g) {
     for (int r = 0; r < RPW; ++r)
       w[r][c] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(W + (size_t)min(n0 + r, g.N - 1) * K + k));
   }
+  // bias and the residual-stream value this row accumulates into: requested now (youngest loads, wave-uniform
+  // addresses, unconditional), so the epilogue has no dependent memory latency of its own
+  float bpre[RPW], ypre[RPW][NB];
+  {
+    const float* bp = g.bias ? g.bias : reinterpret_cast<const float*>(g.W);  // any readable address when there is no bias
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+      const int n = min(n0 + r, g.N - 1);
+      bpre[r] = bp[n];
+#pragma unroll
+      for (int b = 0; b < NB; ++b) ypre[r][b] = YBF ? 0.f : g.Y[(size_t)min(b, g.B - 1) * g.ldy + n];
+    }
+  }
   // ---- 2. LayerNorm(s) in registers (one barrier each), bf16 pairs to LDS ----
   if (!XBF) {
     float xv[NB][KCH][4];
@@ -400,13 +413,12 @@ __global__ __launch_bounds__(256) void gemv_bf16_kernel(GemvArgs g) {
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
           if (b < g.B) {
-            float v = acc[r][b] + (g.bias ? g.bias[n] : 0.f);
+            float v = acc[r][b] + (g.bias ? bpre[r] : 0.f);
             v = act_apply(g.act, v);
             if (YBF) {
               ((bf16_t*)g.Y)[(size_t)b * g.ldy + n] = (bf16_t)v;
             } else {
-              float* y = g.Y + (size_t)b * g.ldy + n;
-              *y = g.accumulate ? (*y + v) : v;
+              g.Y[(size_t)b * g.ldy + n] = g.accumulate ? (ypre[r][b] + v) : v;
             }
           }
         }
