@@ -465,7 +465,6 @@ __global__ __launch_bounds__(NT) void decode_attn2_kernel(TO* __restrict__ ctx, 
                                                           int ctx_bt) {
   constexpr int DH = 64, VEC = CacheVec<TC>::VEC, LPK = CacheVec<TC>::LPK, NW = NT / 64, SLOTS = NT / LPK;
   constexpr int SD = NT >= 1024 ? 2 : 4;  // rows per slot in flight beyond the register window
-  __shared__ float sq[DH];
   __shared__ float sm[NW], sl[NW];
   __shared__ float so[NW][DH];
   const int h = blockIdx.x, b = blockIdx.y;
@@ -483,23 +482,33 @@ __global__ __launch_bounds__(NT) void decode_attn2_kernel(TO* __restrict__ ctx, 
     kr[u].load(kb + (size_t)j * DH + sub * VEC);
     vr[u].load(vb + (size_t)j * DH + sub * VEC);
   }
-  // (b) per-row scalars, the query, and the K/V append of this step
+  // (a') this thread's slice of the step's q / k / v (addresses depend on no device scalar either): straight to
+  //      registers - no LDS round trip, no barrier between the query and the cache reads
+  const float* qv = qkv + (size_t)b * 3 * D + h * DH + sub * VEC;
+  float4 qraw[VEC / 4], kraw[VEC / 4], vraw[VEC / 4];
+#pragma unroll
+  for (int i = 0; i < VEC / 4; ++i) {
+    qraw[i] = *reinterpret_cast<const float4*>(qv + 4 * i);
+    kraw[i] = *reinterpret_cast<const float4*>(qv + D + 4 * i);
+    vraw[i] = *reinterpret_cast<const float4*>(qv + 2 * D + 4 * i);
+  }
+  // (b) per-row scalars and the K/V append of this step
   const int pos = prefix[0] + len[b];
   const int S = pos + 1;
   const int ks = kv_start[b];
-  const float* qv = qkv + (size_t)b * 3 * D + h * DH;
-  if (tid < DH) {
-    sq[tid] = qv[tid] * scale;
-    stf(kb + (size_t)pos * DH + tid, qv[D + tid]);
-    stf(vb + (size_t)pos * DH + tid, qv[2 * D + tid]);
-  }
-  __syncthreads();
   float qr[VEC], kown[VEC], vown[VEC];  // the appended row with the cache's rounding, never read back from HBM
 #pragma unroll
   for (int i = 0; i < VEC; ++i) {
-    qr[i] = sq[sub * VEC + i];
-    kown[i] = (float)(TC)qv[D + sub * VEC + i];
-    vown[i] = (float)(TC)qv[2 * D + sub * VEC + i];
+    qr[i] = (&qraw[i >> 2].x)[i & 3] * scale;
+    kown[i] = (float)(TC)(&kraw[i >> 2].x)[i & 3];
+    vown[i] = (float)(TC)(&vraw[i >> 2].x)[i & 3];
+  }
+  if (tid < LPK) {  // slot 0: its LPK lanes cover the 64 dims
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      stf(kb + (size_t)pos * DH + sub * VEC + i, kown[i]);
+      stf(vb + (size_t)pos * DH + sub * VEC + i, vown[i]);
+    }
   }
   // (c) now that S is known: request every remaining row of the sequence at once (one more memory latency in total)
 #pragma unroll
@@ -589,11 +598,9 @@ __global__ __launch_bounds__(NT) void decode_attn2_kernel(TO* __restrict__ ctx, 
 }
 
 // bookkeeping shared by the greedy and the sampling kernels (thread 0 of the row's block)
-__device__ __forceinline__ void sampler_commit(const SamplerArgs& a, int b, int choice, int* si) {
-  const int k = a.step[b];
+__device__ __forceinline__ void sampler_commit(const SamplerArgs& a, int b, int choice, int* si, int k, int unf) {
   si[1] = -1;
   if (k < a.max_gen) {  // graph replays past the end are no-ops
-    const int unf = a.unfinished[b];
     const int tok = unf ? choice : a.stop;
     a.ids[(size_t)b * a.max_gen + k] = tok;
     a.cur_tok[b] = tok;
@@ -630,6 +637,7 @@ __global__ __launch_bounds__(1024) void sampler2_kernel(SamplerArgs a) {
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float* __restrict__ lg = a.logits + (size_t)b * a.V;
   uint8_t* seen = a.seen + (size_t)b * a.V;
+  const int k_pre = a.step[b], unf_pre = a.unfinished[b];  // requested with the logits: nothing to wait for after the argmax
   float best = -INFINITY;
   int bi = 0x7fffffff;
 #pragma unroll 4
@@ -662,7 +670,7 @@ __global__ __launch_bounds__(1024) void sampler2_kernel(SamplerArgs a) {
         best = sv[w];
         bi = si[w];
       }
-    sampler_commit(a, b, bi, si);
+    sampler_commit(a, b, bi, si, k_pre, unf_pre);
   }
   __syncthreads();
   sampler_next_embedding(a, b, si, tid);
@@ -691,6 +699,7 @@ __global__ __launch_bounds__(1024) void sampler_sample_kernel(SamplerArgs a) {
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
   const float* __restrict__ lg = a.logits + (size_t)b * a.V;
   const uint8_t* seen = a.seen + (size_t)b * a.V;
+  const int k_pre = a.step[b], unf_pre = a.unfinished[b];
   for (int i = tid; i < a.V; i += 1024) {
     float v = lg[i];
     if (a.penalty != 1.f && seen[i]) v = v < 0.f ? v * a.penalty : v / a.penalty;
@@ -803,7 +812,7 @@ __global__ __launch_bounds__(1024) void sampler_sample_kernel(SamplerArgs a) {
     }
     float total = 0.f;
     for (int r = 0; r < R; ++r) total += e[r];
-    const int k = a.step[b];
+    const int k = k_pre;
     const float u = a.uniforms[(size_t)min(k, a.max_gen - 1) * a.B + b];
     const float target = u * total;
     int pick = R - 1;
@@ -815,7 +824,7 @@ __global__ __launch_bounds__(1024) void sampler_sample_kernel(SamplerArgs a) {
         break;
       }
     }
-    sampler_commit(a, b, cidx[pick], si);
+    sampler_commit(a, b, cidx[pick], si, k_pre, unf_pre);
   }
   __syncthreads();
   sampler_next_embedding(a, b, si, tid);
