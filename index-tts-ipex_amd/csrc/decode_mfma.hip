@@ -49,6 +49,18 @@ __global__ __launch_bounds__(512) void skinny_mfma_kernel(GemvArgs g) {
   for (int t = 0; t < NT; ++t)
 #pragma unroll
     for (int bt = 0; bt < BT; ++bt) acc[t][bt] = f32x4v{0.f, 0.f, 0.f, 0.f};
+  // epilogue operands (bias of the outputs this thread will finish) requested up front: the tail then has no
+  // dependent memory latency
+  constexpr int EPT = (NT * BT * 256 + 511) / 512;
+  float bpre[EPT];
+  {
+    const float* bp = g.bias ? g.bias : reinterpret_cast<const float*>(g.W);
+#pragma unroll
+    for (int it = 0; it < EPT; ++it) {
+      const int idx = tid + it * 512, tb = idx >> 8, t = tb / BT;
+      bpre[it] = bp[min(n0 + t * 16 + (idx & 15), g.N - 1)];
+    }
+  }
   for (int k0 = wave; k0 < nks; k0 += SW * SU) {
     bf16x8 wf[SU][NT], xf[SU][BT];
 #pragma unroll
@@ -81,7 +93,10 @@ __global__ __launch_bounds__(512) void skinny_mfma_kernel(GemvArgs g) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) red[wave][t * BT + bt][r * 64 + lane] = acc[t][bt][r];
   __syncthreads();
-  for (int idx = tid; idx < NT * BT * 256; idx += 512) {
+#pragma unroll
+  for (int it = 0; it < EPT; ++it) {
+    const int idx = tid + it * 512;
+    if (idx >= NT * BT * 256) break;
     const int tb = idx >> 8, t = tb / BT, bt = tb - t * BT, e = idx & 255, r = e >> 6, l = e & 63;
     const int b = bt * 16 + (l >> 4) * 4 + r, n = n0 + t * 16 + (l & 15);
     if (b >= g.B || n >= g.N) continue;
@@ -93,7 +108,7 @@ __global__ __launch_bounds__(512) void skinny_mfma_kernel(GemvArgs g) {
       g.partial[((size_t)split * g.B + b) * g.ldy + n] = v;
       continue;
     }
-    if (g.bias) v += g.bias[n];
+    if (g.bias) v += bpre[it];
     v = act_apply(g.act, v);
     if (g.y_bf16)
       reinterpret_cast<bf16_t*>(g.Y)[g.y_tiled ? tile_off(b, n, btr) : o] = (bf16_t)v;
