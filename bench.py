@@ -183,9 +183,17 @@ def main():
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
     dec_ms, dec_steps = [0.0], [0]
 
+    # per-phase device time (conditioning+ECAPA / prefill+AR decode / latent pass / vocoder), as infer.py:218-220 prints
+    pev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
+    phase_ms = {"conditioning": 0.0, "ar_decode": 0.0, "latent": 0.0, "vocoder": 0.0}
+
     def step(timed: bool):
+        if timed:
+            pev[0].record(eng.stream)
         cond = eng.conditioning(mel)
         spk = eng.ecapa(mel.transpose(1, 2))
+        if timed:
+            pev[1].record(eng.stream)
         eng.prefill(cond, texts, T, 10.0, True)
         if timed:
             ev[0].record(eng.stream)
@@ -197,11 +205,14 @@ def main():
         if timed:
             dec_ms[0] += ev[0].elapsed_time(ev[1])
             dec_steps[0] += T - 1
+            pev[2].record(eng.stream)
         clean = []
         for i in range(B):
             c, n = remove_long_silence(codes[i:i + 1].astype(np.int64), g["stop_mel_token"])
             clean.append(c[0, :int(n[0])])
         lats = eng.latent_batch(cond, [texts[i] for i in range(B)], clean)
+        if timed:
+            pev[3].record(eng.stream)
         nsamp = 0
         outs = []
         if all(l.shape[1] == lats[0].shape[1] for l in lats):
@@ -213,6 +224,11 @@ def main():
         host = [torch.clamp(32767 * w, -32767.0, 32767.0).to(torch.int16).cpu() for w in outs]
         for w in host:
             nsamp += w.numel()
+        if timed:
+            pev[4].record(eng.stream)
+            pev[4].synchronize()
+            for name, i in (("conditioning", 0), ("ar_decode", 1), ("latent", 2), ("vocoder", 3)):
+                phase_ms[name] += pev[i].elapsed_time(pev[i + 1])
         return nsamp
 
     def sync_all():
@@ -269,6 +285,7 @@ def main():
         "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 2), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
         "rtf": round(dt / audio_s, 5),
+        "phases_ms_per_step": {k: round(v / a.steps, 2) for k, v in phase_ms.items()},
         "config": {"workload": ("IndexTTS-1.5, %d utterance(s)/GPU x %d sentences x (L=%d text tokens, T=%d mel codes), "
                                 "prompt %d frames, greedy fixed-length decode, rep_penalty 10" % (BU, NS, L, T, a.prompt_frames)),
                    "utterances_per_gpu": BU, "decode_batch": B, "audio_sec_per_step_per_gpu": round(audio_s / a.steps / world, 3)},
