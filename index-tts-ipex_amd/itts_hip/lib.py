@@ -98,6 +98,11 @@ def load():
         raise RuntimeError(
             f"libitts_hip.so not found at {LIB_PATH}: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             f"or `make -C {CSRC}` (there is no CPU fallback)")
+    # torch ships its own libamdhip64; the process must run ONE HIP runtime, and device pointers / streams come from
+    # torch, so torch's copy has to be the one already loaded when this library resolves its HIP symbols (loading
+    # libitts_hip first pulls in /opt/rocm's runtime and the engine then sees no device)
+    import torch  # noqa: F401
+
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in _PROTOS.items():
         fn = getattr(lib, name)
