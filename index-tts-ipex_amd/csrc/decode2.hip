@@ -496,6 +496,17 @@ __global__ __launch_bounds__(NT) void decode_attn2_kernel(TO* __restrict__ ctx, 
   const int pos = prefix[0] + len[b];
   const int S = pos + 1;
   const int ks = kv_start[b];
+  // (c) now that S is known: request every remaining row of the sequence at once (one more memory latency in total).
+  //     This comes BEFORE anything that consumes the q/k/v slice - vmcnt is in-order, and the K/V append below would
+  //     otherwise make the wave sit out the first loads' latency before these are even issued
+#pragma unroll
+  for (int u = 2; u < 2 * NIT; ++u)
+    if (u * SLOTS < S) {  // block-uniform
+      const int j = min(u * SLOTS + slot, Smax - 1);
+      kr[u].load(kb + (size_t)j * DH + sub * VEC);
+      vr[u].load(vb + (size_t)j * DH + sub * VEC);
+    }
+  // (d) the step's own q / k / v: scale, round as the cache does, append
   float qr[VEC], kown[VEC], vown[VEC];  // the appended row with the cache's rounding, never read back from HBM
 #pragma unroll
   for (int i = 0; i < VEC; ++i) {
@@ -510,18 +521,10 @@ __global__ __launch_bounds__(NT) void decode_attn2_kernel(TO* __restrict__ ctx, 
       stf(vb + (size_t)pos * DH + sub * VEC + i, vown[i]);
     }
   }
-  // (c) now that S is known: request every remaining row of the sequence at once (one more memory latency in total)
-#pragma unroll
-  for (int u = 2; u < 2 * NIT; ++u)
-    if (u * SLOTS < S) {  // block-uniform
-      const int j = min(u * SLOTS + slot, Smax - 1);
-      kr[u].load(kb + (size_t)j * DH + sub * VEC);
-      vr[u].load(vb + (size_t)j * DH + sub * VEC);
-    }
   float m = -INFINITY, l = 0.f, acc[VEC];
 #pragma unroll
   for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
-  // (d) online softmax over the slot's keys
+  // (e) online softmax over the slot's keys
   auto consume = [&](const CacheVec<TC>& kk, const CacheVec<TC>& vv, int j) {
     const bool own = j == pos;
     const bool ok = j < S && j >= ks;
