@@ -43,19 +43,25 @@ def parse():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--micro", action="store_true", help="tiny config (plumbing check)")
+    ap.add_argument("--gpt-fp8", action="store_true",
+                    help="BASELINE config 5 storage: GPT projections as fp8 e4m3 + row scales for the decode GEMV (bf16 activations / KV)")
     ap.add_argument("--no-graph", action="store_true", help="eager decode launches (for rocprofv3 --pmc passes)")
     return ap.parse_args()
 
 
-def build_engine_dp(cfg, dtype, device, rank, world):
+def build_engine_dp(cfg, dtype, device, rank, world, gpt_fp8=False):
     """Rank 0 materialises + packs the synthetic checkpoint; other ranks receive the packed arena by an RCCL
     broadcast over xGMI (one-off, outside the timed region)."""
     from itts_hip import engine as ieng
     from itts_hip import pack, synth
 
     eng = ieng.Engine(cfg, dtype, device, max_batch=128)
+    def gpt_packed():
+        p = pack.pack_gpt(synth.gpt_state_dict(cfg, 1234), cfg)
+        return pack.quantize_gpt_fp8(p) if gpt_fp8 else p
+
     if world == 1:
-        eng.load_packed(pack.pack_gpt(synth.gpt_state_dict(cfg, 1234), cfg))
+        eng.load_packed(gpt_packed())
         eng.load_packed(pack.pack_bigvgan(synth.bigvgan_state_dict(cfg, 1234), cfg))
         eng.finalize()
         return eng
@@ -63,7 +69,7 @@ def build_engine_dp(cfg, dtype, device, rank, world):
 
     for part in ("gpt", "bigvgan"):
         if rank == 0:
-            packed = (pack.pack_gpt(synth.gpt_state_dict(cfg, 1234), cfg) if part == "gpt"
+            packed = (gpt_packed() if part == "gpt"
                       else pack.pack_bigvgan(synth.bigvgan_state_dict(cfg, 1234), cfg))
             arena = ieng.WeightArena(packed, eng.dt, eng.device)
             meta = [arena.manifest, arena.nbytes]
@@ -170,7 +176,7 @@ def main():
         a.text_tokens, a.mel_tokens, a.prompt_frames = 11, 24, 61
     g = cfg["gpt"]
     device = f"cuda:{local}"
-    eng = build_engine_dp(cfg, a.dtype, device, rank, world)
+    eng = build_engine_dp(cfg, a.dtype, device, rank, world, a.gpt_fp8)
     from itts_hip.infer_core import remove_long_silence
 
     if a.no_graph:
@@ -266,7 +272,10 @@ def main():
     w_params = NL * (12 * D * D + 13 * D) + 4 * D + D * V + V
     s_bar = (32 + L + 2 + 1) + T / 2.0
     kv_per_pos = 2 * NL * D * esz
-    step_bytes = w_params * esz + B * kv_per_pos * s_bar
+    w_bytes = w_params * esz
+    if a.gpt_fp8 and B <= 4:  # the decode GEMV streams the fp8 copy (+ one fp32 scale per output row); biases stay fp32-sized
+        w_bytes = NL * 12 * D * D + D * V + 4 * (NL * 9 * D + V) + esz * (NL * 13 * D + 4 * D + V)
+    step_bytes = w_bytes + B * kv_per_pos * s_bar
     ms_step = dec_ms[0] / max(dec_steps[0], 1)
     achieved = step_bytes / (ms_step * 1e-3) / 1e9
     # HBM traffic of the decode step from the committed PMC passes (tools/round_profile.sh): measured bytes / algorithmic
@@ -276,14 +285,15 @@ def main():
         pm = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_decode.json"))
         if pm:
             pj = json.load(open(os.path.join(ROOT, "profiles", pm[-1])))
-            if int(pj.get("decode_rows", -1)) == B and a.dtype == "bf16" and not a.micro:  # same kernels as the PMC run only
+            if int(pj.get("decode_rows", -1)) == B and a.dtype == "bf16" and not a.micro and not a.gpt_fp8:  # same kernels as the PMC run only
                 traffic = int(pj["traffic_over_algorithmic"] * step_bytes)
     except Exception:
         traffic = None
     out = {
         "metric": "audio_sec_per_sec", "value": round(audio_s / dt, 3), "unit": "audio-s/s", "n_gpus": world,
         "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 2), "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
+        "scaling": "weak", "vs_baseline": None,
+        "dtype": ("fp8-e4m3 gpt weights (decode), bf16 activations/KV" if a.gpt_fp8 else a.dtype), "data": "synthetic",
         "rtf": round(dt / audio_s, 5),
         "phases_ms_per_step": {k: round(v / a.steps, 2) for k, v in phase_ms.items()},
         "config": {"workload": ("IndexTTS-1.5, %d utterance(s)/GPU x %d sentences x (L=%d text tokens, T=%d mel codes), "

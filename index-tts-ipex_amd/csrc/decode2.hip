@@ -245,6 +245,7 @@ __device__ __forceinline__ uint32_t pack_bf16(float a, float b) {
   bf16x2_t v = {(bf16_t)a, (bf16_t)b};
   return __builtin_bit_cast(uint32_t, v);
 }
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float dot2(uint32_t a, uint32_t b, float c) {
   return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, a), __builtin_bit_cast(bf16x2_t, b), c, false);
 }
@@ -254,7 +255,9 @@ __device__ __forceinline__ float dot2(uint32_t a, uint32_t b, float c) {
 // (A wave-specialised variant - dedicated activation waves - was measured slower: profiles/README.md.)
 // Every batch row uses the SAME thread <-> element mapping, so a row's result does not depend on its position in
 // the batch (the padding/batch invariance the reference's tests/padding_test.py checks).
-template <int NB, int RPW, int NCH, int PRO, bool XBF, bool YBF>
+// W8: weights stored as OCP fp8 e4m3 bytes with one power-of-two scale per output row (BASELINE config 5): half the
+// weight stream; two v_cvt_scalef32_pk_bf16_fp8 per 4 weights feed the same v_dot2c, the row scale multiplies the sum.
+template <int NB, int RPW, int NCH, int PRO, bool XBF, bool YBF, bool W8 = false>
 __global__ __launch_bounds__(256) void gemv_bf16_kernel(GemvArgs g) {
   constexpr int EPC = XBF ? 8 : 4;                                  // elements per 16-byte chunk
   constexpr int KCH = (NCH * 512 + 256 * EPC - 1) / (256 * EPC);    // chunks per row per thread
@@ -287,25 +290,32 @@ __global__ __launch_bounds__(256) void gemv_bf16_kernel(GemvArgs g) {
 #pragma unroll
   for (int b = 0; b < NB; ++b) pivot[b] = PRO >= 1 ? g.X[(size_t)min(b, g.B - 1) * K] : 0.f;
   const bf16_t* __restrict__ W = (const bf16_t*)g.W;
-  u32x4 w[RPW][NCH];
+  const uint8_t* __restrict__ Wq = (const uint8_t*)g.W8;
+  u32x4 w[W8 ? 1 : RPW][W8 ? 1 : NCH];
+  u32x2 w8[W8 ? RPW : 1][W8 ? NCH : 1];  // 8 fp8 weights per lane and chunk
   const int klast = (NCH - 1) * 512 + lane * 8;
   const bool kok = klast < K;
 #pragma unroll
   for (int c = 0; c < NCH; ++c) {
     const int k = c == NCH - 1 ? (kok ? klast : K - 8) : c * 512 + lane * 8;
 #pragma unroll
-    for (int r = 0; r < RPW; ++r)
-      w[r][c] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(W + (size_t)min(n0 + r, g.N - 1) * K + k));
+    for (int r = 0; r < RPW; ++r) {
+      if constexpr (W8)
+        w8[r][c] = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(Wq + (size_t)min(n0 + r, g.N - 1) * K + k));
+      else
+        w[r][c] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(W + (size_t)min(n0 + r, g.N - 1) * K + k));
+    }
   }
   // bias and the residual-stream value this row accumulates into: requested now (youngest loads, wave-uniform
   // addresses, unconditional), so the epilogue has no dependent memory latency of its own
-  float bpre[RPW], ypre[RPW][NB];
+  float bpre[RPW], ypre[RPW][NB], spre[RPW];
   {
-    const float* bp = g.bias ? g.bias : reinterpret_cast<const float*>(g.W);  // any readable address when there is no bias
+    const float* bp = g.bias ? g.bias : reinterpret_cast<const float*>(W8 ? g.W8 : g.W);  // any readable address when there is no bias
 #pragma unroll
     for (int r = 0; r < RPW; ++r) {
       const int n = min(n0 + r, g.N - 1);
       bpre[r] = bp[n];
+      spre[r] = W8 ? g.wscale[n] : 1.f;
 #pragma unroll
       for (int b = 0; b < NB; ++b) ypre[r][b] = YBF ? 0.f : g.Y[(size_t)min(b, g.B - 1) * g.ldy + n];
     }
@@ -396,9 +406,19 @@ __global__ __launch_bounds__(256) void gemv_bf16_kernel(GemvArgs g) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) xq[e] = kok ? xq[e] : 0u;
 #pragma unroll
-      for (int r = 0; r < RPW; ++r)
+      for (int r = 0; r < RPW; ++r) {
+        if constexpr (W8) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) acc[r][b] = dot2(w[r][c][e], xq[e], acc[r][b]);
+          for (int h2 = 0; h2 < 2; ++h2) {
+            const uint32_t q = w8[r][c][h2];  // 4 fp8: bytes 0,1 -> pair 2*h2, bytes 2,3 -> pair 2*h2 + 1
+            acc[r][b] = dot2(__builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(q, 1.0f, false)), xq[2 * h2], acc[r][b]);
+            acc[r][b] = dot2(__builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(q, 1.0f, true)), xq[2 * h2 + 1], acc[r][b]);
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[r][b] = dot2(w[r][c][e], xq[e], acc[r][b]);
+        }
+      }
     }
   }
 #pragma unroll
@@ -413,7 +433,7 @@ __global__ __launch_bounds__(256) void gemv_bf16_kernel(GemvArgs g) {
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
           if (b < g.B) {
-            float v = acc[r][b] + (g.bias ? bpre[r] : 0.f);
+            float v = acc[r][b] * spre[r] + (g.bias ? bpre[r] : 0.f);
             v = act_apply(g.act, v);
             if (YBF) {
               ((bf16_t*)g.Y)[(size_t)b * g.ldy + n] = (bf16_t)v;
@@ -888,7 +908,10 @@ int gemv2(const GemvArgs& g, int tw, hipStream_t s) {
 template <int NB, int RPW, int NCH, int PRO, bool XBF, bool YBF>
 static int launch_gemv_bf16(const GemvArgs& g, hipStream_t s) {
   dim3 grid((g.N + 4 * RPW - 1) / (4 * RPW)), blk(256);
-  hipLaunchKernelGGL((gemv_bf16_kernel<NB, RPW, NCH, PRO, XBF, YBF>), grid, blk, (size_t)NB * g.K * 2, s, g);
+  if (g.W8)
+    hipLaunchKernelGGL((gemv_bf16_kernel<NB, RPW, NCH, PRO, XBF, YBF, true>), grid, blk, (size_t)NB * g.K * 2, s, g);
+  else
+    hipLaunchKernelGGL((gemv_bf16_kernel<NB, RPW, NCH, PRO, XBF, YBF>), grid, blk, (size_t)NB * g.K * 2, s, g);
   ITTS_HIP_CHECK(hipGetLastError());
   return OK;
 }
@@ -925,7 +948,8 @@ bool gemv_bf16_supported(const GemvArgs& g) {
 }
 
 int gemv_bf16(const GemvArgs& g, hipStream_t s) {
-  ITTS_REQUIRE(g.X && g.W && g.Y && g.N > 0, "gemv_bf16: bad args");
+  ITTS_REQUIRE(g.X && (g.W || g.W8) && g.Y && g.N > 0, "gemv_bf16: bad args");
+  ITTS_REQUIRE(!g.W8 || g.wscale, "gemv_bf16: fp8 weights need their row scales");
   ITTS_REQUIRE(gemv_bf16_supported(g), "gemv_bf16: unsupported shape");
   ITTS_REQUIRE(!(g.accumulate && g.y_bf16), "gemv_bf16: accumulate needs an fp32 output");
   if (g.B == 1) return dispatch_gemv_bf16<1>(g, s);

@@ -30,6 +30,8 @@ struct Lin {
   const float* bn_scale = nullptr;
   const float* bn_shift = nullptr;
   int N = 0, Cin = 0, taps = 1, nphase = 1, dt = 0;
+  const void* w8 = nullptr;       // optional fp8 e4m3 copy of w (decode GEMV of the GPT), one scale per output row
+  const float* wscale = nullptr;
 };
 struct Norm {
   const float* g = nullptr;

@@ -229,11 +229,33 @@ int Engine::finalize() {
       L.proj = r.lin(p + "attn.c_proj", wdt, D, D);
       L.fc = r.lin(p + "mlp.c_fc", wdt, 4 * D, D);
       L.proj2 = r.lin(p + "mlp.c_proj", wdt, D, 4 * D);
+      // optional fp8 (e4m3) copies for the decode GEMV: "<name>.weight_fp8" [N, K] bytes + "<name>.weight_scale" [N]
+      auto fp8 = [&](Lin& l, const std::string& n) {
+        if (!r.has(n + ".weight_fp8")) return;
+        const Tensor* q = r.get(n + ".weight_fp8", FP8, {l.N, l.Cin});
+        const float* sc = r.f32(n + ".weight_scale", {l.N});
+        if (q && sc) {
+          l.w8 = q->p;
+          l.wscale = sc;
+        }
+      };
+      fp8(L.attn, p + "attn.c_attn");
+      fp8(L.proj, p + "attn.c_proj");
+      fp8(L.fc, p + "mlp.c_fc");
+      fp8(L.proj2, p + "mlp.c_proj");
       gpt.layers.push_back(L);
     }
     gpt.ln_f = r.norm("gpt.ln_f", D);
     gpt.final_norm = r.norm("gpt.final_norm", D);
     gpt.head = r.lin("gpt.mel_head", wdt, V, D);
+    if (r.has("gpt.mel_head.weight_fp8")) {
+      const Tensor* q = r.get("gpt.mel_head.weight_fp8", FP8, {V, D});
+      const float* sc = r.f32("gpt.mel_head.weight_scale", {V});
+      if (q && sc) {
+        gpt.head.w8 = q->p;
+        gpt.head.wscale = sc;
+      }
+    }
     const Tensor* t;
     if ((t = r.get("gpt.text_embedding", wdt, {c.number_text_tokens + 1, D}))) gpt.text_emb = t->p;
     if ((t = r.get("gpt.mel_embedding", wdt, {V, D}))) gpt.mel_emb = t->p;

@@ -8,11 +8,11 @@ namespace itts {
 
 typedef __bf16 bf16_t;
 
-enum DType : int { F32 = 0, BF16 = 1, I32 = 2, I64 = 3 };
+enum DType : int { F32 = 0, BF16 = 1, I32 = 2, I64 = 3, FP8 = 4 };  // FP8 = OCP e4m3fn bytes (weights only)
 enum Act : int { ACT_NONE = 0, ACT_RELU = 1, ACT_SILU = 2, ACT_GELU_NEW = 3, ACT_GELU_ERF = 4, ACT_TANH = 5, ACT_SIGMOID = 6 };
 enum PadMode : int { PAD_ZERO = 0, PAD_REFLECT = 1 };
 
-inline size_t dtype_size(int dt) { return dt == F32 ? 4 : dt == BF16 ? 2 : dt == I32 ? 4 : 8; }
+inline size_t dtype_size(int dt) { return dt == F32 ? 4 : dt == BF16 ? 2 : dt == I32 ? 4 : dt == FP8 ? 1 : 8; }
 
 // status codes of the C ABI (0 ok, negative = error; message via itts_last_error())
 enum Status : int { OK = 0, E_INVALID = -1, E_HIP = -2, E_NOMEM = -3, E_STATE = -4, E_MISSING = -5 };

@@ -4,6 +4,8 @@
 
 namespace itts {
 
+struct Lin;
+
 struct GemvArgs {
   const float* X = nullptr;  // [B, K] fp32
   const void* W = nullptr;   // [N, K] (fp32 or bf16)
@@ -22,6 +24,9 @@ struct GemvArgs {
   float ln_eps = 1e-5f;
   int ksplit = 1;            // skinny_mfma: K split across workgroups; > 1 writes raw sums to partial[split][B][ldy]
   float* partial = nullptr;
+  const struct Lin* w8src = nullptr;  // engine-internal: projection whose fp8 copy may replace W (decode GEMV)
+  const void* W8 = nullptr;      // gemv_bf16: [N, K] OCP fp8 e4m3 bytes (instead of W) ...
+  const float* wscale = nullptr; // ... with one scale per output row: y = scale[n] * (x . w8[n]) + bias[n]
   int x_tiled = 0, y_tiled = 0;  // skinny_mfma: bf16 X / Y in MFMA-fragment tiles (tile_off) instead of row-major
 };
 

@@ -268,6 +268,8 @@ int Engine::head_and_sample(hipStream_t s) {
     g.prologue = 0;
     ITTS_TRY(skinny_mfma(g, s));
   } else if (adt == BF16 && gemv_bf16_supported(g)) {
+    g.W8 = gpt.head.w8;
+    g.wscale = gpt.head.wscale;
     ITTS_TRY(gemv_bf16(g, s));
   } else if (gemv2_supported(g)) {
     ITTS_TRY(gemv2(g, gpt.head.dt, s));
@@ -336,7 +338,13 @@ int Engine::decode_step_launch(hipStream_t s) {
       g.y_tiled = g.y_bf16;
       return skinny_mfma(g, s);
     }
-    if (fast && gemv_bf16_supported(g)) return gemv_bf16(g, s);
+    if (fast && gemv_bf16_supported(g)) {
+      if (g.w8src) {  // fp8 copy of this projection (decode only; prefill / latent use the bf16 dequantisation of it)
+        g.W8 = g.w8src->w8;
+        g.wscale = g.w8src->wscale;
+      }
+      return gemv_bf16(g, s);
+    }
     ITTS_REQUIRE(!g.x_bf16 && !g.y_bf16, "decode: bf16 activation without the bf16 GEMV");
     return gemv2_supported(g) ? gemv2(g, dt, s) : gemv(g, dt, s);
   };
@@ -362,6 +370,7 @@ int Engine::decode_step_launch(hipStream_t s) {
     g.prologue = 1;
     g.ln_gamma = L.ln1.g;
     g.ln_beta = L.ln1.b;
+    g.w8src = L.attn.w8 ? &L.attn : nullptr;
     ITTS_TRY(run(g, L.attn.dt));
     const size_t lo = (size_t)l * B * H * ds.Smax * dh * es;
     ITTS_TRY(decode_attn2(ds.ctx, bf_ctx ? BF16 : F32, ds.qkv, (char*)ds.kc + lo, (char*)ds.vc + lo, ds.len, ds.kv_start,
@@ -377,6 +386,7 @@ int Engine::decode_step_launch(hipStream_t s) {
     p.K = D;
     p.ldy = D;
     p.accumulate = 1;
+    p.w8src = L.proj.w8 ? &L.proj : nullptr;
     ITTS_TRY(run(p, L.proj.dt));
     GemvArgs f;  // act = gelu_new(LN2(h) Wfc + b)
     f.B = B;
@@ -392,6 +402,7 @@ int Engine::decode_step_launch(hipStream_t s) {
     f.prologue = 1;
     f.ln_gamma = L.ln2.g;
     f.ln_beta = L.ln2.b;
+    f.w8src = L.fc.w8 ? &L.fc : nullptr;
     ITTS_TRY(run(f, L.fc.dt));
     GemvArgs q;  // h += act Wproj2 + b
     q.B = B;
@@ -404,6 +415,7 @@ int Engine::decode_step_launch(hipStream_t s) {
     q.K = 4 * D;
     q.ldy = D;
     q.accumulate = 1;
+    q.w8src = L.proj2.w8 ? &L.proj2 : nullptr;
     ITTS_TRY(run(q, L.proj2.dt));
   }
   return head_and_sample(s);

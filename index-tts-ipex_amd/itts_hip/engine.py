@@ -12,7 +12,8 @@ import torch
 from . import lib as L
 from .config import ecapa_dims, perceiver_inner
 
-_TORCH_DT = {L.F32: torch.float32, L.BF16: torch.bfloat16}
+_TORCH_DT = {L.F32: torch.float32, L.BF16: torch.bfloat16, L.FP8: torch.uint8}
+_DT_BYTES = {L.F32: 4, L.BF16: 2, L.FP8: 1}
 
 
 def make_config(cfg, dtype: int, max_batch: int = 64) -> L.Config:
@@ -58,14 +59,18 @@ class WeightArena:
         self.manifest: List[Tuple[str, int, int, Tuple[int, ...]]] = []  # name, offset, dt, shape
         off = 0
         for name, (tag, arr) in packed.items():
-            dt = dtype if tag == "w" else L.F32
-            nbytes = int(np.prod(arr.shape)) * (2 if dt == L.BF16 else 4)
+            dt = dtype if tag == "w" else (L.FP8 if tag == "q" else L.F32)  # "q": fp8 e4m3 bytes (uint8 array)
+            nbytes = int(np.prod(arr.shape)) * _DT_BYTES[dt]
             self.manifest.append((name, off, dt, tuple(int(x) for x in arr.shape)))
             off = (off + nbytes + 255) // 256 * 256
         self.nbytes = off
         self.buf = torch.empty(off, dtype=torch.uint8, device=device)
         # stage through pinned-free host tensors in chunks (bf16 rounding = torch RNE, same as the device cast)
         for (name, o, dt, shape), (tag, arr) in zip(self.manifest, packed.values()):
+            if dt == L.FP8:
+                t = torch.from_numpy(np.ascontiguousarray(arr, dtype=np.uint8))
+                self.buf[o:o + t.numel()].copy_(t.reshape(-1), non_blocking=False)
+                continue
             t = torch.from_numpy(np.ascontiguousarray(arr, dtype=np.float32))
             if dt == L.BF16:
                 t = t.to(torch.bfloat16)
@@ -75,7 +80,7 @@ class WeightArena:
     def view(self, name: str) -> torch.Tensor:
         for n, o, dt, shape in self.manifest:
             if n == name:
-                nb = int(np.prod(shape)) * (2 if dt == L.BF16 else 4)
+                nb = int(np.prod(shape)) * _DT_BYTES[dt]
                 return self.buf[o:o + nb].view(_TORCH_DT[dt]).view(*shape)
         raise KeyError(name)
 
@@ -305,14 +310,19 @@ class Engine:
 
 
 def build_engine(cfg, dtype: str = "bf16", device: str = "cuda:0", seed: int = 1234, parts=("gpt", "bigvgan", "dvae"),
-                 state_dicts: Optional[dict] = None, max_batch: int = 64) -> Engine:
-    """Engine with synthetic (PRNG) or supplied reference-layout state dicts."""
+                 state_dicts: Optional[dict] = None, max_batch: int = 64, gpt_fp8: str = "") -> Engine:
+    """Engine with synthetic (PRNG) or supplied reference-layout state dicts.  gpt_fp8: "" = plain weights;
+    "fp8" = GPT projections quantised to e4m3 (power-of-two row scales) with the fp8 bytes used by the decode GEMV;
+    "dequant" = the same quantised model but every kernel reads its bf16 dequantisation (the fp8 path's reference)."""
     from . import pack, synth
 
     eng = Engine(cfg, dtype, device, max_batch)
     sds = state_dicts or {}
     if "gpt" in parts:
-        eng.load_packed(pack.pack_gpt(sds.get("gpt") or synth.gpt_state_dict(cfg, seed), cfg))
+        packed = pack.pack_gpt(sds.get("gpt") or synth.gpt_state_dict(cfg, seed), cfg)
+        if gpt_fp8:
+            packed = pack.quantize_gpt_fp8(packed, keep_bytes=(gpt_fp8 == "fp8"))
+        eng.load_packed(packed)
     if "bigvgan" in parts:
         eng.load_packed(pack.pack_bigvgan(sds.get("bigvgan") or synth.bigvgan_state_dict(cfg, seed), cfg))
     if "dvae" in parts:

@@ -14,6 +14,7 @@ CSRC = os.path.normpath(os.path.join(_HERE, "..", "csrc"))
 LIB_PATH = os.environ.get("ITTS_HIP_LIB", os.path.join(CSRC, "libitts_hip.so"))
 
 F32, BF16 = 0, 1
+FP8 = 4  # OCP e4m3fn bytes (GPT decode weights, BASELINE config 5)
 ACT_NONE, ACT_RELU, ACT_SILU, ACT_GELU_NEW, ACT_GELU_ERF, ACT_TANH, ACT_SIGMOID = range(7)  # csrc/itts_common.h enum Act
 ACT = {"none": 0, "relu": 1, "silu": 2, "gelu_new": 3, "gelu_erf": 4, "tanh": 5, "sigmoid": 6}
 

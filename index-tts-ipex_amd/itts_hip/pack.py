@@ -257,3 +257,32 @@ def pack_dvae(sd: Dict[str, np.ndarray], cfg) -> Packed:
     P["dvae.out.weight"] = ("w", conv_w(sd[f"decoder.{idx}.weight"]))
     P["dvae.out.bias"] = ("f", sd[f"decoder.{idx}.bias"])
     return P
+
+
+def quantize_gpt_fp8(packed, keep_bytes: bool = True):
+    """GPT projection weights -> OCP fp8 e4m3 with one power-of-two scale per output row (BASELINE config 5,
+    SURVEY 8d "fp8-e4m3 GPT weights (per-output-channel scale), bf16 KV/activations").
+
+    Every `gpt.h.*.{attn.c_attn,attn.c_proj,mlp.c_fc,mlp.c_proj}.weight` and `gpt.mel_head.weight` [N, K] is replaced by
+    its dequantisation q * 2^e (exactly representable in bf16, so prefill / latent pass and the fp8 decode GEMV see the
+    same model), and - with keep_bytes - the fp8 bytes `<name>_fp8` (tag "q") + `<name>_scale` fp32 [N] are added for
+    the decode step.  Rounding is torch's float8_e4m3fn cast (round-to-nearest-even, saturating at 448)."""
+    import re
+
+    import torch
+
+    out = dict(packed)
+    pat = re.compile(r"^gpt\.(h\.\d+\.(attn\.c_attn|attn\.c_proj|mlp\.c_fc|mlp\.c_proj)|mel_head)\.weight$")
+    for name, (tag, arr) in packed.items():
+        if not pat.match(name):
+            continue
+        w = torch.from_numpy(np.ascontiguousarray(arr, dtype=np.float32))
+        amax = w.abs().amax(dim=1).clamp_min(1e-30)
+        e = torch.ceil(torch.log2(amax / 448.0))
+        scale = torch.pow(2.0, e)
+        q = (w / scale[:, None]).to(torch.float8_e4m3fn)
+        out[name] = (tag, (q.float() * scale[:, None]).numpy())
+        if keep_bytes:
+            out[name + "_fp8"] = ("q", q.view(torch.uint8).numpy())
+            out[name + "_scale"] = ("f", scale.numpy().astype(np.float32))
+    return out

@@ -240,3 +240,33 @@ def test_sampling_ids_match_oracle_fp32(eng32, gold, name, max_gen, cfgs):
     # greedy still works afterwards (sampling state is reset)
     again = eng32.generate(cond, g["text"], max_gen)
     assert np.array_equal(again, g["codes"])
+
+
+def test_fp8_decode_weights_equal_their_dequantisation(gold):
+    """BASELINE config 5 storage: GPT projections as fp8 e4m3 + power-of-two row scales.  The decode GEMV reading the
+    fp8 bytes must reproduce, bit for bit, the engine that reads the bf16 dequantisation of the same quantised model
+    (same products, power-of-two scaling commutes with fp32 rounding) - logits and greedy ids over a whole generation."""
+    c, g = gold("micro_conditioning"), gold("micro_decode_b5")
+    cond = torch.from_numpy(c["cond"])
+    e8 = ieng.build_engine(CFG, "bf16", parts=("gpt",), gpt_fp8="fp8")
+    ed = ieng.build_engine(CFG, "bf16", parts=("gpt",), gpt_fp8="dequant")
+    text = g["text"][:4]
+    out = []
+    for e in (e8, ed):
+        e.prefill(cond, text, 24, 10.0, True)
+        trace = []
+        for k in range(24):
+            trace.append(e.fetch(logits=True))
+            if k < 23:
+                e.decode(1)
+        e._exit()
+        out.append(trace)
+    for k in range(24):
+        assert np.array_equal(out[0][k][1], out[1][k][1]), k
+        assert np.array_equal(out[0][k][0], out[1][k][0]), k
+    # quantisation moves the model: report how far the first-step logits are from the unquantised bf16 engine
+    e0 = ieng.build_engine(CFG, "bf16", parts=("gpt",))
+    e0.prefill(cond, text, 24, 10.0, True)
+    _, lg0 = e0.fetch(logits=True)
+    e0._exit()
+    print(f"fp8-e4m3 weights vs bf16 weights, first-step logits rel-RMS {rms_rel(out[0][0][1], lg0):.4f}")

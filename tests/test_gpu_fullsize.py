@@ -186,3 +186,24 @@ def test_full_sampling_steps_match_oracle_pick(eng32, mel, gold):
     finally:
         eng32.set_sampling(False)
     assert (codes[0, :n] != codes[1, :n]).any()  # two rows, same text, different draws
+
+
+def test_full_fp8_decode_weights_equal_their_dequantisation(mel):
+    """IndexTTS-1.5 sizes (K = 1280 / 5120, V = 8194 head): fp8 decode GEMV == bf16 dequantisation, bit for bit."""
+    e8 = ieng.build_engine(CFG, "bf16", parts=("gpt",), gpt_fp8="fp8")
+    cond = e8.conditioning(mel)
+    text = np.stack([synth.text_ids(40, 21 + i, CFG.gpt.number_text_tokens) for i in range(2)]).astype(np.int32)
+    res = []
+    e8.prefill(cond, text, 12, 10.0, True)
+    e8.decode(11)
+    res.append(e8.fetch(logits=True))
+    e8._exit()
+    del e8
+    torch.cuda.empty_cache()
+    ed = ieng.build_engine(CFG, "bf16", parts=("gpt",), gpt_fp8="dequant")
+    ed.prefill(cond, text, 12, 10.0, True)
+    ed.decode(11)
+    res.append(ed.fetch(logits=True))
+    ed._exit()
+    assert np.array_equal(res[0][0], res[1][0])
+    assert np.array_equal(res[0][1], res[1][1])
