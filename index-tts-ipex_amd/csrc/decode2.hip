@@ -320,6 +320,10 @@ __global__ __launch_bounds__(256) void gemv_bf16_kernel(GemvArgs g) {
       for (int b = 0; b < NB; ++b) ypre[r][b] = YBF ? 0.f : g.Y[(size_t)min(b, g.B - 1) * g.ldy + n];
     }
   }
+  // every request of this kernel is now in flight.  The fence keeps it that way: without it the machine scheduler sinks
+  // most of the weight loads below the first wait on X (fewer live registers), i.e. two thirds of the weight stream
+  // would be requested one memory latency late
+  __builtin_amdgcn_sched_barrier(0);
   // ---- 2. LayerNorm(s) in registers (one barrier each), bf16 pairs to LDS ----
   if (!XBF) {
     float xv[NB][KCH][4];
