@@ -4,6 +4,8 @@
 //     (deep memory-level parallelism, no LDS round trip for streamed weights - cdna_hip_programming "GEMV" row),
 //   * keep the tiny activation vectors in LDS (fused LayerNorm / ln_f+final_norm / split-KV combine prologues),
 //   * spread over >= 256 workgroups so every CU pulls on HBM.
+#include <cstdlib>
+
 #include "itts_decode.h"
 
 namespace itts {
@@ -241,6 +243,18 @@ __device__ __forceinline__ float wave_sum_dpp(float v) {
   v += __shfl_xor(v, 32, 64);
   return v;
 }
+// full-wave sum, result uniform in every lane: DPP inside the 16-lane rows, then one v_readlane per row - no ds_bpermute
+// (an LDS-crossbar round trip with an lgkmcnt wait) on the dependent chain
+__device__ __forceinline__ float wave_sum_rl(float v) {
+  v = dpp_add<0xB1>(v);
+  v = dpp_add<0x4E>(v);
+  v = dpp_add<0x141>(v);
+  v = dpp_add<0x140>(v);
+  const int iv = __float_as_int(v);
+  const float a = __int_as_float(__builtin_amdgcn_readlane(iv, 0)), b = __int_as_float(__builtin_amdgcn_readlane(iv, 16));
+  const float c = __int_as_float(__builtin_amdgcn_readlane(iv, 32)), d = __int_as_float(__builtin_amdgcn_readlane(iv, 48));
+  return (a + b) + (c + d);
+}
 __device__ __forceinline__ uint32_t pack_bf16(float a, float b) {
   bf16x2_t v = {(bf16_t)a, (bf16_t)b};
   return __builtin_bit_cast(uint32_t, v);
@@ -257,8 +271,20 @@ __device__ __forceinline__ float dot2(uint32_t a, uint32_t b, float c) {
 // the batch (the padding/batch invariance the reference's tests/padding_test.py checks).
 // W8: weights stored as OCP fp8 e4m3 bytes with one power-of-two scale per output row (BASELINE config 5): half the
 // weight stream; two v_cvt_scalef32_pk_bf16_fp8 per 4 weights feed the same v_dot2c, the row scale multiplies the sum.
+#ifdef ITTS_GEMV_STAMPS
+#define GEMV_STAMP(i)                                                                   \
+  {                                                                                     \
+    unsigned long long t_;                                                              \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");         \
+    if (threadIdx.x == 0 && g.stamp) g.stamp[(size_t)blockIdx.x * 8 + (i)] = t_;        \
+  }
+#else
+#define GEMV_STAMP(i)
+#endif
+
 template <int NB, int RPW, int NCH, int PRO, bool XBF, bool YBF, bool W8 = false>
 __global__ __launch_bounds__(256) void gemv_bf16_kernel(GemvArgs g) {
+  GEMV_STAMP(0)
   constexpr int EPC = XBF ? 8 : 4;                                  // elements per 16-byte chunk
   constexpr int KCH = (NCH * 512 + 256 * EPC - 1) / (256 * EPC);    // chunks per row per thread
   extern __shared__ __attribute__((aligned(16))) uint32_t sxb[];    // [NB][K/2] bf16 pairs
@@ -308,22 +334,24 @@ __global__ __launch_bounds__(256) void gemv_bf16_kernel(GemvArgs g) {
   }
   // bias and the residual-stream value this row accumulates into: requested now (youngest loads, wave-uniform
   // addresses, unconditional), so the epilogue has no dependent memory latency of its own
-  float bpre[RPW], ypre[RPW][NB], spre[RPW];
-  {
-    const float* bp = g.bias ? g.bias : reinterpret_cast<const float*>(W8 ? g.W8 : g.W);  // any readable address when there is no bias
-#pragma unroll
-    for (int r = 0; r < RPW; ++r) {
-      const int n = min(n0 + r, g.N - 1);
-      bpre[r] = bp[n];
-      spre[r] = W8 ? g.wscale[n] : 1.f;
-#pragma unroll
-      for (int b = 0; b < NB; ++b) ypre[r][b] = YBF ? 0.f : g.Y[(size_t)min(b, g.B - 1) * g.ldy + n];
-    }
-  }
+  // epilogue operands of the output this lane will finish, (row lane / NB, batch lane % NB): bias, fp8 row scale and the
+  // residual-stream value it accumulates into are requested now (youngest loads, unconditional), so the epilogue has no
+  // dependent memory latency of its own
+  const int er = min(lane / NB, RPW - 1), eb = lane % NB;
+  const int en = min(n0 + er, g.N - 1);
+  const float* bp = g.bias ? g.bias : reinterpret_cast<const float*>(W8 ? g.W8 : g.W);  // any readable address when there is no bias
+  const float bpre = bp[en];
+  const float spre = W8 ? g.wscale[en] : 1.f;
+  const float ypre = YBF ? 0.f : g.Y[(size_t)min(eb, g.B - 1) * g.ldy + en];
   // every request of this kernel is now in flight.  The fence keeps it that way: without it the machine scheduler sinks
   // most of the weight loads below the first wait on X (fewer live registers), i.e. two thirds of the weight stream
   // would be requested one memory latency late
   __builtin_amdgcn_sched_barrier(0);
+  GEMV_STAMP(1)
+#ifdef ITTS_GEMV_STAMPS
+  { unsigned pr_ = xr[0][0][0]; asm volatile("" ::"v"(pr_)); }
+  GEMV_STAMP(2)
+#endif
   // ---- 2. LayerNorm(s) in registers (one barrier each), bf16 pairs to LDS ----
   if (!XBF) {
     float xv[NB][KCH][4];
@@ -348,8 +376,8 @@ __global__ __launch_bounds__(256) void gemv_bf16_kernel(GemvArgs g) {
             s[b] += d;
             q[b] = fmaf(d, d, q[b]);
           }
-        s[b] = wave_sum_dpp(s[b]);
-        q[b] = wave_sum_dpp(q[b]);
+        s[b] = wave_sum_rl(s[b]);
+        q[b] = wave_sum_rl(q[b]);
       }
       if (lane == 0)
 #pragma unroll
@@ -394,6 +422,7 @@ __global__ __launch_bounds__(256) void gemv_bf16_kernel(GemvArgs g) {
         if (xok[j]) *reinterpret_cast<u32x4*>(sxb + (b * K + (tid + j * 256) * 8) / 2) = xr[b][j];
   }
   __syncthreads();
+  GEMV_STAMP(3)
   // ---- 3. dot products: 4 x v_dot2c per weight fragment and batch row ----
   float acc[RPW][NB];
 #pragma unroll
@@ -425,30 +454,199 @@ __global__ __launch_bounds__(256) void gemv_bf16_kernel(GemvArgs g) {
       }
     }
   }
+  // wave reduction, then one lane per output: lane l < RPW * NB stores (row l / NB, batch l % NB)
+  float mine = 0.f;
 #pragma unroll
   for (int r = 0; r < RPW; ++r)
 #pragma unroll
-    for (int b = 0; b < NB; ++b) acc[r][b] = wave_sum_dpp(acc[r][b]);
-  if (lane == 0) {
+    for (int b = 0; b < NB; ++b) {
+      const float t = wave_sum_rl(acc[r][b]);
+      mine = lane == r * NB + b ? t : mine;
+    }
+  GEMV_STAMP(4)
+  if (lane < RPW * NB && n0 + er < g.N && eb < g.B) {
+    float v = mine * spre + (g.bias ? bpre : 0.f);
+    v = act_apply(g.act, v);
+    const size_t o = (size_t)eb * g.ldy + en;
+    if (YBF)
+      ((bf16_t*)g.Y)[o] = (bf16_t)v;
+    else
+      g.Y[o] = g.accumulate ? ypre + v : v;
+  }
+  GEMV_STAMP(5)
+}
+
+// ---------------------------------------------------------------------------------------------
+// gemv_wave_kernel: the same projection, but every WAVE is autonomous.  A wave needs, for its RPW weight rows, exactly
+// the activations x[c*512 + lane*8 .. +8] that multiply its lane's weight fragments - so each lane loads those itself
+// (L2 hits: every wave of the grid reads the same 5-20 KB), LayerNorm statistics are two DPP wave reductions per row on
+// registers, and the normalised bf16 pairs feed v_dot2c directly.  No LDS, no barrier, no inter-wave dependency: the
+// phase timeline of the block-cooperative kernel above (tools/ubench_gemv2.hip) showed its LayerNorm + 2 barriers on the
+// critical path for 1.4 us while the weight stream had already landed, and a serial lane-0 epilogue of 0.5 us.
+// The epilogue is spread over lanes: lane l < RPW*NB finishes output (row l / NB, batch l % NB) with ONE store.
+// ---------------------------------------------------------------------------------------------
+template <int NB, int RPW, int NCH, int PRO, bool XBF, bool YBF, bool W8>
+__global__ __launch_bounds__(256) void gemv_wave_kernel(GemvArgs g) {
+  GEMV_STAMP(0)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int K = g.K;
+  const int n0 = (blockIdx.x * 4 + wave) * RPW;
+  int kc[NCH];
+  bool kok[NCH];
 #pragma unroll
-    for (int r = 0; r < RPW; ++r) {
-      const int n = n0 + r;
-      if (n < g.N) {
+  for (int c = 0; c < NCH; ++c) {
+    const int k = c * 512 + lane * 8;
+    kok[c] = k < K;
+    kc[c] = kok[c] ? k : K - 8;  // clamped, in bounds; masked below
+  }
+  // ---- 1. every request of the wave: activations first (LayerNorm starts on them), then weights, then the epilogue operands
+  u32x4 xraw[NB][NCH][XBF ? 1 : 2];
 #pragma unroll
-        for (int b = 0; b < NB; ++b) {
-          if (b < g.B) {
-            float v = acc[r][b] * spre[r] + (g.bias ? bpre[r] : 0.f);
-            v = act_apply(g.act, v);
-            if (YBF) {
-              ((bf16_t*)g.Y)[(size_t)b * g.ldy + n] = (bf16_t)v;
-            } else {
-              g.Y[(size_t)b * g.ldy + n] = g.accumulate ? (ypre[r][b] + v) : v;
-            }
-          }
-        }
+  for (int b = 0; b < NB; ++b)
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const size_t ro = (size_t)min(b, g.B - 1) * K + kc[c];
+      if constexpr (XBF) {
+        xraw[b][c][0] = *reinterpret_cast<const u32x4*>((const bf16_t*)g.X + ro);
+      } else {
+        xraw[b][c][0] = *reinterpret_cast<const u32x4*>(g.X + ro);
+        xraw[b][c][1] = *reinterpret_cast<const u32x4*>(g.X + ro + 4);
       }
     }
+  f32x4 gm[PRO == 2 ? NCH : 1][2], bt[PRO == 2 ? NCH : 1][2];
+  if constexpr (PRO == 2) {
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        gm[c][hh] = *reinterpret_cast<const f32x4*>(g.ln_gamma + kc[c] + 4 * hh);
+        bt[c][hh] = *reinterpret_cast<const f32x4*>(g.ln_beta + kc[c] + 4 * hh);
+      }
   }
+  const bf16_t* __restrict__ W = (const bf16_t*)g.W;
+  const uint8_t* __restrict__ Wq = (const uint8_t*)g.W8;
+  u32x4 w[W8 ? 1 : RPW][W8 ? 1 : NCH];
+  u32x2 w8[W8 ? RPW : 1][W8 ? NCH : 1];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c)
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+      const size_t wo = (size_t)min(n0 + r, g.N - 1) * K + kc[c];
+      if constexpr (W8)
+        w8[r][c] = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(Wq + wo));
+      else
+        w[r][c] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(W + wo));
+    }
+  // epilogue operands of the output this lane will finish: (row lane / NB, batch lane % NB)
+  const int er = min(lane / NB, RPW - 1), eb = lane % NB;
+  const int en = min(n0 + er, g.N - 1);
+  const float* bp = g.bias ? g.bias : reinterpret_cast<const float*>(W8 ? g.W8 : g.W);  // any readable address without a bias
+  const float bpre = bp[en];
+  const float spre = W8 ? g.wscale[en] : 1.f;
+  const float ypre = YBF ? 0.f : g.Y[(size_t)min(eb, g.B - 1) * g.ldy + en];
+  __builtin_amdgcn_sched_barrier(0);  // keep all of the above in flight before the first wait (see gemv_bf16_kernel)
+  GEMV_STAMP(1)
+  // ---- 2. LayerNorm(s) in registers: two wave reductions per row and pass, then bf16 pairs ----
+  uint32_t xq[NB][NCH][4];
+  if constexpr (!XBF) {
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      float xv[NCH][8];
+#pragma unroll
+      for (int c = 0; c < NCH; ++c)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) xv[c][e] = __uint_as_float(xraw[b][c][e >> 2][e & 3]);
+#pragma unroll
+      for (int pass = 0; pass < PRO; ++pass) {
+        // one pass: moments about a pivot (the row's first element for the raw residual stream, 0 for a LayerNorm output),
+        // both sums go through the wave reduction together
+        const float pv = pass == 0 ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(xv[0][0]), 0)) : 0.f;
+        float sm = 0.f, sq = 0.f;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float d = kok[c] ? xv[c][e] - pv : 0.f;
+            sm += d;
+            sq = fmaf(d, d, sq);
+          }
+        sm = wave_sum_rl(sm);
+        sq = wave_sum_rl(sq);
+        const float md = sm / K;
+        const float mean = pv + md;
+        const float rstd = rsqrtf(fmaxf(sq / K - md * md, 0.f) + g.ln_eps);
+#pragma unroll
+        for (int c = 0; c < NCH; ++c)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            float v = (xv[c][e] - mean) * rstd;
+            if (PRO == 2 && pass == 0) v = v * gm[c][e >> 2][e & 3] + bt[c][e >> 2][e & 3];
+            xv[c][e] = v;
+          }
+      }
+#pragma unroll
+      for (int c = 0; c < NCH; ++c)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) xq[b][c][e] = kok[c] ? pack_bf16(xv[c][2 * e], xv[c][2 * e + 1]) : 0u;
+    }
+  } else {
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+      for (int c = 0; c < NCH; ++c)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) xq[b][c][e] = kok[c] ? xraw[b][c][0][e] : 0u;
+  }
+  GEMV_STAMP(3)
+  // ---- 3. dot products ----
+  float acc[RPW][NB];
+#pragma unroll
+  for (int r = 0; r < RPW; ++r)
+#pragma unroll
+    for (int b = 0; b < NB; ++b) acc[r][b] = 0.f;
+#pragma unroll
+  for (int c = 0; c < NCH; ++c)
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+      if constexpr (W8) {
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2) {
+          const uint32_t q = w8[r][c][h2];
+          const uint32_t lo = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(q, 1.0f, false));
+          const uint32_t hi = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(q, 1.0f, true));
+#pragma unroll
+          for (int b = 0; b < NB; ++b) {
+            acc[r][b] = dot2(lo, xq[b][c][2 * h2], acc[r][b]);
+            acc[r][b] = dot2(hi, xq[b][c][2 * h2 + 1], acc[r][b]);
+          }
+        }
+      } else {
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[r][b] = dot2(w[r][c][e], xq[b][c][e], acc[r][b]);
+      }
+    }
+  // ---- 4. wave reduction, then one lane per output ----
+  float mine = 0.f;
+#pragma unroll
+  for (int r = 0; r < RPW; ++r)
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      const float t = wave_sum_rl(acc[r][b]);
+      mine = lane == r * NB + b ? t : mine;
+    }
+  GEMV_STAMP(4)
+  if (lane < RPW * NB && n0 + er < g.N && eb < g.B) {
+    float v = mine * spre + (g.bias ? bpre : 0.f);
+    v = act_apply(g.act, v);
+    const size_t o = (size_t)eb * g.ldy + en;
+    if (YBF)
+      ((bf16_t*)g.Y)[o] = (bf16_t)v;
+    else
+      g.Y[o] = g.accumulate ? ypre + v : v;
+  }
+  GEMV_STAMP(5)
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -909,13 +1107,26 @@ int gemv2(const GemvArgs& g, int tw, hipStream_t s) {
 #undef GO
 }
 
+static int g_gemv_mode = 0;  // ITTS_GEMV_MODE: 0 / 2 block-cooperative kernel (default, measured fastest), 1 wave-autonomous kernel
+                             // everywhere, 3 wave-autonomous only for the short bf16-x projection
+
 template <int NB, int RPW, int NCH, int PRO, bool XBF, bool YBF>
 static int launch_gemv_bf16(const GemvArgs& g, hipStream_t s) {
   dim3 grid((g.N + 4 * RPW - 1) / (4 * RPW)), blk(256);
-  if (g.W8)
-    hipLaunchKernelGGL((gemv_bf16_kernel<NB, RPW, NCH, PRO, XBF, YBF, true>), grid, blk, (size_t)NB * g.K * 2, s, g);
-  else
-    hipLaunchKernelGGL((gemv_bf16_kernel<NB, RPW, NCH, PRO, XBF, YBF>), grid, blk, (size_t)NB * g.K * 2, s, g);
+  // measured (bench, 2 rows): all block-cooperative 0.602 ms per step, all wave-autonomous 0.615 ms - the per-wave copies
+  // of x cost more address-pipeline time (16 clk per KiB wave-load per CU) than the LDS hand-over and its barriers
+  const bool block = g_gemv_mode == 2 || g_gemv_mode == 0 || (g_gemv_mode == 3 && !(XBF && NCH < 4));
+  if (block) {
+    if (g.W8)
+      hipLaunchKernelGGL((gemv_bf16_kernel<NB, RPW, NCH, PRO, XBF, YBF, true>), grid, blk, (size_t)NB * g.K * 2, s, g);
+    else
+      hipLaunchKernelGGL((gemv_bf16_kernel<NB, RPW, NCH, PRO, XBF, YBF>), grid, blk, (size_t)NB * g.K * 2, s, g);
+  } else {
+    if (g.W8)
+      hipLaunchKernelGGL((gemv_wave_kernel<NB, RPW, NCH, PRO, XBF, YBF, true>), grid, blk, 0, s, g);
+    else
+      hipLaunchKernelGGL((gemv_wave_kernel<NB, RPW, NCH, PRO, XBF, YBF, false>), grid, blk, 0, s, g);
+  }
   ITTS_HIP_CHECK(hipGetLastError());
   return OK;
 }
@@ -952,6 +1163,12 @@ bool gemv_bf16_supported(const GemvArgs& g) {
 }
 
 int gemv_bf16(const GemvArgs& g, hipStream_t s) {
+  static const bool once = [] {
+    const char* m = getenv("ITTS_GEMV_MODE");
+    g_gemv_mode = m ? atoi(m) : 0;
+    return true;
+  }();
+  (void)once;
   ITTS_REQUIRE(g.X && (g.W || g.W8) && g.Y && g.N > 0, "gemv_bf16: bad args");
   ITTS_REQUIRE(!g.W8 || g.wscale, "gemv_bf16: fp8 weights need their row scales");
   ITTS_REQUIRE(gemv_bf16_supported(g), "gemv_bf16: unsupported shape");

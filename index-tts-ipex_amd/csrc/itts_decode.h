@@ -27,6 +27,7 @@ struct GemvArgs {
   const struct Lin* w8src = nullptr;  // engine-internal: projection whose fp8 copy may replace W (decode GEMV)
   const void* W8 = nullptr;      // gemv_bf16: [N, K] OCP fp8 e4m3 bytes (instead of W) ...
   const float* wscale = nullptr; // ... with one scale per output row: y = scale[n] * (x . w8[n]) + bias[n]
+  unsigned long long* stamp = nullptr;  // -DITTS_GEMV_STAMPS builds only (tools/ubench_gemv2.hip): s_memtime per phase
   int x_tiled = 0, y_tiled = 0;  // skinny_mfma: bf16 X / Y in MFMA-fragment tiles (tile_off) instead of row-major
 };
 
