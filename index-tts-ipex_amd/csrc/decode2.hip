@@ -291,6 +291,7 @@ __global__ __launch_bounds__(256) void gemv_bf16_kernel(GemvArgs g) {
   __shared__ float red[2][4][2 * NB];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int K = g.K;
+  const float invK = 1.f / (float)K;  // off the critical path: the LayerNorm chain multiplies instead of dividing
   const int n0 = (blockIdx.x * 4 + wave) * RPW;
   // ---- 1. activations (+ LayerNorm parameters) first, weights second; all unconditional ----
   u32x4 xr[NB][KCH];  // XBF: 8 bf16; else 4 floats
@@ -390,9 +391,9 @@ __global__ __launch_bounds__(256) void gemv_bf16_kernel(GemvArgs g) {
       for (int b = 0; b < NB; ++b) {
         const float S = red[pass][0][2 * b] + red[pass][1][2 * b] + red[pass][2][2 * b] + red[pass][3][2 * b];
         const float Q = red[pass][0][2 * b + 1] + red[pass][1][2 * b + 1] + red[pass][2][2 * b + 1] + red[pass][3][2 * b + 1];
-        const float md = S / K;
+        const float md = S * invK;
         const float mean = (pass == 0 ? pivot[b] : 0.f) + md;
-        const float rstd = rsqrtf(fmaxf(Q / K - md * md, 0.f) + g.ln_eps);
+        const float rstd = __builtin_amdgcn_rsqf(fmaxf(Q * invK - md * md, 0.f) + g.ln_eps);
 #pragma unroll
         for (int j = 0; j < KCH; ++j)
 #pragma unroll
