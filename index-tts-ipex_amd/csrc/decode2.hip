@@ -677,6 +677,18 @@ template <> struct CacheVec<float> {
 // NIT = key pairs per slot held in registers (NIT * 2 * SLOTS keys: 768 with bf16 at NIT = 3).  The first pair is
 // requested before any device scalar is read, the rest as soon as the sequence length is known, all before the first
 // use: the whole cache read costs two overlapped memory latencies instead of one per iteration.
+#ifdef ITTS_GEMV_STAMPS
+__device__ unsigned long long* g_attn_stamp = nullptr;
+#define ATTN_STAMP(i)                                                                                  \
+  {                                                                                                    \
+    unsigned long long t_;                                                                             \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                        \
+    if (threadIdx.x == 0 && g_attn_stamp) g_attn_stamp[(size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 8 + (i)] = t_; \
+  }
+#else
+#define ATTN_STAMP(i)
+#endif
+
 // NT = threads per (row, head): 1024 for the latency-bound small batches (one workgroup per CU), 256 once there are
 // enough (row, head) pairs to fill the CUs several times over - 5 workgroups per CU overlap their load / softmax /
 // merge phases, where the 86-VGPR 1024-thread form runs its 5 rounds per CU back to back.
@@ -688,6 +700,7 @@ __global__ __launch_bounds__(NT) void decode_attn2_kernel(TO* __restrict__ ctx, 
                                                           int ctx_bt) {
   constexpr int DH = 64, VEC = CacheVec<TC>::VEC, LPK = CacheVec<TC>::LPK, NW = NT / 64, SLOTS = NT / LPK;
   constexpr int SD = NT >= 1024 ? 2 : 4;  // rows per slot in flight beyond the register window
+  ATTN_STAMP(0)
   __shared__ float sm[NW], sl[NW];
   __shared__ float so[NW][DH];
   const int h = blockIdx.x, b = blockIdx.y;
@@ -699,8 +712,12 @@ __global__ __launch_bounds__(NT) void decode_attn2_kernel(TO* __restrict__ ctx, 
   // (a) the first pair of key/value rows of this slot, requested before ANYTHING else: their addresses depend on no
   //     device scalar (rows are clamped to the cache capacity; rows >= S are masked out below)
   CacheVec<TC> kr[2 * NIT], vr[2 * NIT];
+  // UNC pairs are requested blind (rows past S cost their bytes but nothing waits for the length): 2 pairs cover every
+  // prefix; with 1024 threads 4 pairs = 512 rows cover the sequence for most of a generation, so the device-scalar
+  // -> load chain (a second full memory latency) only remains for the late steps
+  constexpr int UNC = 2;  // 4 blind pairs (512 rows) measured slower: 0.602 vs 0.593 ms per step - the extra bytes cost more than the chain
 #pragma unroll
-  for (int u = 0; u < 2; ++u) {
+  for (int u = 0; u < UNC; ++u) {
     const int j = min(u * SLOTS + slot, Smax - 1);
     kr[u].load(kb + (size_t)j * DH + sub * VEC);
     vr[u].load(vb + (size_t)j * DH + sub * VEC);
@@ -723,12 +740,13 @@ __global__ __launch_bounds__(NT) void decode_attn2_kernel(TO* __restrict__ ctx, 
   //     This comes BEFORE anything that consumes the q/k/v slice - vmcnt is in-order, and the K/V append below would
   //     otherwise make the wave sit out the first loads' latency before these are even issued
 #pragma unroll
-  for (int u = 2; u < 2 * NIT; ++u)
+  for (int u = UNC; u < 2 * NIT; ++u)
     if (u * SLOTS < S) {  // block-uniform
       const int j = min(u * SLOTS + slot, Smax - 1);
       kr[u].load(kb + (size_t)j * DH + sub * VEC);
       vr[u].load(vb + (size_t)j * DH + sub * VEC);
     }
+  ATTN_STAMP(1)
   // (d) the step's own q / k / v: scale, round as the cache does, append
   float qr[VEC], kown[VEC], vown[VEC];  // the appended row with the cache's rounding, never read back from HBM
 #pragma unroll
@@ -744,6 +762,7 @@ __global__ __launch_bounds__(NT) void decode_attn2_kernel(TO* __restrict__ ctx, 
       stf(vb + (size_t)pos * DH + sub * VEC + i, vown[i]);
     }
   }
+  ATTN_STAMP(2)
   float m = -INFINITY, l = 0.f, acc[VEC];
 #pragma unroll
   for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
@@ -773,7 +792,7 @@ __global__ __launch_bounds__(NT) void decode_attn2_kernel(TO* __restrict__ ctx, 
   };
 #pragma unroll
   for (int u = 0; u < 2 * NIT; ++u)
-    if (u * SLOTS < S) consume(kr[u], vr[u], u * SLOTS + slot);  // block-uniform condition
+    if (u < UNC || u * SLOTS < S) consume(kr[u], vr[u], u * SLOTS + slot);  // block-uniform condition (rows >= S are masked)
   // sequences longer than the register-resident window: stream the rest two rows at a time
   for (int jb = 2 * NIT * SLOTS; jb < S; jb += SD * SLOTS) {
     CacheVec<TC> k2[SD], v2[SD];
@@ -786,19 +805,35 @@ __global__ __launch_bounds__(NT) void decode_attn2_kernel(TO* __restrict__ ctx, 
 #pragma unroll
     for (int u = 0; u < SD; ++u) consume(k2[u], v2[u], jb + u * SLOTS + slot);
   }
+  ATTN_STAMP(3)
   // merge the 64/LPK key slots of this wave (lanes with equal `sub`)
+  // merge across the wave without the LDS crossbar: lane ^ 8 is a DPP rotate inside the 16-lane row; lane ^ 16 and
+  // lane ^ 32 are v_permlane16_swap / v_permlane32_swap (CDNA4), which hand every lane BOTH partners' values
+  // (tools/probe_permlane.hip prints the lane maps) - a sum or max of the two results is the butterfly step
+  auto bfly_max = [&](float x, int o) {
+    if (o == 8) return fmaxf(x, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x128, 0xf, 0xf, true)));
+    const u32x2 r = o == 16 ? __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false)
+                            : __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+  };
+  auto bfly_sum = [&](float x, int o) {
+    if (o == 8) return x + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x128, 0xf, 0xf, true));
+    const u32x2 r = o == 16 ? __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false)
+                            : __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+  };
   float M = m;
 #pragma unroll
-  for (int o = LPK; o < 64; o <<= 1) M = fmaxf(M, __shfl_xor(M, o, 64));
+  for (int o = LPK; o < 64; o <<= 1) M = bfly_max(M, o);
   const float sc0 = M > -INFINITY ? __expf(m - M) : 0.f;
   l *= sc0;
 #pragma unroll
   for (int i = 0; i < VEC; ++i) acc[i] *= sc0;
 #pragma unroll
   for (int o = LPK; o < 64; o <<= 1) {
-    l += __shfl_xor(l, o, 64);
+    l = bfly_sum(l, o);
 #pragma unroll
-    for (int i = 0; i < VEC; ++i) acc[i] += __shfl_xor(acc[i], o, 64);
+    for (int i = 0; i < VEC; ++i) acc[i] = bfly_sum(acc[i], o);
   }
   if (lane < LPK)
 #pragma unroll
@@ -807,7 +842,9 @@ __global__ __launch_bounds__(NT) void decode_attn2_kernel(TO* __restrict__ ctx, 
     sm[wave] = M;
     sl[wave] = l;
   }
+  ATTN_STAMP(4)
   __syncthreads();
+  ATTN_STAMP(5)
   if (tid < DH) {
     float MM = sm[0];
 #pragma unroll
@@ -821,6 +858,7 @@ __global__ __launch_bounds__(NT) void decode_attn2_kernel(TO* __restrict__ ctx, 
     }
     stf(ctx + (ctx_bt ? tile_off(b, h * DH + tid, ctx_bt) : (size_t)b * D + h * DH + tid), o / L);
   }
+  ATTN_STAMP(6)
 }
 
 // bookkeeping shared by the greedy and the sampling kernels (thread 0 of the row's block)

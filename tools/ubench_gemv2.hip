@@ -55,5 +55,38 @@ int main() {
     printf("\n");
     CK(hipGraphExecDestroy(ge)); CK(hipGraphDestroy(g));
   }
+  // ---- cache attention (2 rows x 20 heads, S = 380 of Smax = 768), same stamping ----
+  {
+    const int H = 20, Smax = 768, S = 380;
+    bf16_t *kc, *vc, *ctx; float* qkv; int *len, *kvs, *pre; unsigned long long* AS;
+    const size_t per = (size_t)B * H * Smax * 64;
+    CK(hipMalloc(&kc, per * 2 * REP)); CK(hipMalloc(&vc, per * 2 * REP)); CK(hipMemset(kc, 0, per * 2 * REP)); CK(hipMemset(vc, 0, per * 2 * REP));
+    CK(hipMalloc(&ctx, B * 1280 * 2)); CK(hipMalloc(&qkv, B * 3840 * 4)); CK(hipMemset(qkv, 0, B * 3840 * 4));
+    CK(hipMalloc(&len, 16)); CK(hipMalloc(&kvs, 16)); CK(hipMalloc(&pre, 64)); CK(hipMemset(kvs, 0, 16));
+    int hl[2] = {S - 140, S - 140}, hp = 139;
+    CK(hipMemcpy(len, hl, 8, hipMemcpyHostToDevice)); CK(hipMemcpy(pre, &hp, 4, hipMemcpyHostToDevice));
+    CK(hipMalloc(&AS, (size_t)64 * 8 * 8)); CK(hipMemset(AS, 0, (size_t)64 * 8 * 8));
+    CK(hipMemcpyToSymbol(HIP_SYMBOL(g_attn_stamp), &AS, sizeof(AS)));
+    hipGraph_t g; hipGraphExec_t ge;
+    CK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+    for (int i = 0; i < REP; ++i)
+      if (decode_attn2(ctx, BF16, qkv, kc + per * i, vc + per * i, len, kvs, pre, B, H, 64, Smax, BF16, s, 0) != OK) return 1;
+    CK(hipStreamEndCapture(s, &g)); CK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+    CK(hipGraphLaunch(ge, s)); CK(hipStreamSynchronize(s));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    CK(hipEventRecord(e0, s)); for (int r = 0; r < 5; ++r) CK(hipGraphLaunch(ge, s)); CK(hipEventRecord(e1, s)); CK(hipStreamSynchronize(s));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    std::vector<unsigned long long> h(64 * 8);
+    CK(hipMemcpy(h.data(), AS, h.size() * 8, hipMemcpyDeviceToHost));
+    printf("cache attention S=%d          40 blocks %.2f us/launch |", S, ms * 1e3 / (5 * REP));
+    const char* an[] = {"", "requests out", "q/k/v used", "softmax done", "wave merged", "barrier", "end"};
+    for (int ph = 1; ph < 7; ++ph) {
+      std::vector<double> v;
+      for (int b = 0; b < 40; ++b) v.push_back((double)(h[(size_t)b * 8 + ph] - h[(size_t)b * 8]));
+      std::sort(v.begin(), v.end());
+      printf(" %s %5.0f", an[ph], v[v.size() / 2]);
+    }
+    printf("\n");
+  }
   return 0;
 }
