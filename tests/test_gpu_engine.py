@@ -263,7 +263,7 @@ def test_fp8_decode_weights_equal_their_dequantisation(gold):
         out.append(trace)
     for k in range(24):
         assert np.array_equal(out[0][k][1], out[1][k][1]), k
-        assert np.array_equal(out[0][k][0], out[1][k][0]), k
+        assert np.array_equal(out[0][k][0][:, :k + 1], out[1][k][0][:, :k + 1]), k  # ids emitted so far (the rest of the buffer is unwritten)
     # quantisation moves the model: report how far the first-step logits are from the unquantised bf16 engine
     e0 = ieng.build_engine(CFG, "bf16", parts=("gpt",))
     e0.prefill(cond, text, 24, 10.0, True)

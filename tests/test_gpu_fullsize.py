@@ -205,5 +205,5 @@ def test_full_fp8_decode_weights_equal_their_dequantisation(mel):
     ed.decode(11)
     res.append(ed.fetch(logits=True))
     ed._exit()
-    assert np.array_equal(res[0][0], res[1][0])
+    assert np.array_equal(res[0][0][:, :12], res[1][0][:, :12])
     assert np.array_equal(res[0][1], res[1][1])
