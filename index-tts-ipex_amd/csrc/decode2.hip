@@ -766,33 +766,74 @@ __global__ __launch_bounds__(NT) void decode_attn2_kernel(TO* __restrict__ ctx, 
   float m = -INFINITY, l = 0.f, acc[VEC];
 #pragma unroll
   for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
-  // (e) online softmax over the slot's keys
-  auto consume = [&](const CacheVec<TC>& kk, const CacheVec<TC>& vv, int j) {
-    const bool own = j == pos;
-    const bool ok = j < S && j >= ks;
+  // score of one cached key row for this slot (the LPK lanes of the key hold VEC dims each; DPP sums them: quad swaps,
+  // half-row mirror, row mirror - no LDS crossbar trips)
+  auto score = [&](const CacheVec<TC>& kk) {
     float sc = 0.f;
 #pragma unroll
-    for (int i = 0; i < VEC; ++i) sc = fmaf(qr[i], own ? kown[i] : kk.get(i), sc);
-    // sum over the LPK lanes of this key with DPP (quad swaps, half-row mirror, row mirror): no LDS crossbar trips
+    for (int i = 0; i < VEC; ++i) sc = fmaf(qr[i], kk.get(i), sc);
     sc = dpp_add<0xB1>(sc);
     sc = dpp_add<0x4E>(sc);
     sc = dpp_add<0x141>(sc);
     if (LPK == 16) sc = dpp_add<0x140>(sc);
-    sc = ok ? sc : -INFINITY;  // also discards whatever an out-of-range (uninitialised) row produced
+    return sc;
+  };
+  // (e) the register window in two phases, as torch.softmax does it: all scores, their maximum, then one exp per key and
+  //     the weighted sum - half the VALU work of a per-key online update (no rescale of the accumulator per key), and the
+  //     16 waves of a workgroup share 4 SIMDs, so this phase is issue-bound.  The row appended by this step (j == pos)
+  //     is masked out of the window and enters as one extra key of slot 0, from registers.  Rows past S multiply by
+  //     p = 0: the cache is zero-filled at allocation, so whatever they hold is finite.
+  {
+    float sc[2 * NIT + 1];
+#pragma unroll
+    for (int u = 0; u < 2 * NIT; ++u) {
+      const int j = u * SLOTS + slot;
+      const bool live = u < UNC || u * SLOTS < S;  // block-uniform: was this pair requested
+      const float t = live ? score(kr[u]) : 0.f;
+      sc[u] = (live && j < S && j >= ks && j != pos) ? t : -INFINITY;
+    }
+    {
+      float t = 0.f;
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) t = fmaf(qr[i], kown[i], t);
+      t = dpp_add<0xB1>(t);
+      t = dpp_add<0x4E>(t);
+      t = dpp_add<0x141>(t);
+      if (LPK == 16) t = dpp_add<0x140>(t);
+      sc[2 * NIT] = slot == 0 ? t : -INFINITY;
+    }
+    float mw = sc[0];
+#pragma unroll
+    for (int u = 1; u <= 2 * NIT; ++u) mw = fmaxf(mw, sc[u]);
+    if (mw > -INFINITY) {
+#pragma unroll
+      for (int u = 0; u < 2 * NIT; ++u)
+        if (u < UNC || u * SLOTS < S) {        // block-uniform: pairs that were never requested hold no data at all
+          const float p = __expf(sc[u] - mw);  // exp(-inf) = 0 for masked rows
+          l += p;
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) acc[i] = fmaf(p, vr[u].get(i), acc[i]);
+        }
+      const float p = __expf(sc[2 * NIT] - mw);
+      l += p;
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) acc[i] = fmaf(p, vown[i], acc[i]);
+      m = mw;
+    }
+  }
+  // online update for rows beyond the window (never the appended row when it lies inside the window)
+  auto consume = [&](const CacheVec<TC>& kk, const CacheVec<TC>& vv, int j) {
+    const bool ok = j < S && j >= ks && j != pos;
+    float sc = score(kk);
+    sc = ok ? sc : -INFINITY;  // also discards whatever an out-of-range row produced
     const float mn = fmaxf(m, sc);
     const float corr = mn > -INFINITY ? __expf(m - mn) : 1.f;
     const float p = ok ? __expf(sc - mn) : 0.f;
     l = l * corr + p;
 #pragma unroll
-    for (int i = 0; i < VEC; ++i) {
-      const float vval = ok ? (own ? vown[i] : vv.get(i)) : 0.f;
-      acc[i] = fmaf(p, vval, acc[i] * corr);
-    }
+    for (int i = 0; i < VEC; ++i) acc[i] = fmaf(p, ok ? vv.get(i) : 0.f, acc[i] * corr);
     m = mn;
   };
-#pragma unroll
-  for (int u = 0; u < 2 * NIT; ++u)
-    if (u < UNC || u * SLOTS < S) consume(kr[u], vr[u], u * SLOTS + slot);  // block-uniform condition (rows >= S are masked)
   // sequences longer than the register-resident window: stream the rest two rows at a time
   for (int jb = 2 * NIT * SLOTS; jb < S; jb += SD * SLOTS) {
     CacheVec<TC> k2[SD], v2[SD];

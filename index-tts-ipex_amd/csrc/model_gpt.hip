@@ -120,6 +120,10 @@ int Engine::ensure_decode_state(int B, int Smax, int max_gen, hipStream_t s) {
   if (need > d.cache_bytes) {
     ITTS_TRY(dev_alloc(&d.kc, need));
     ITTS_TRY(dev_alloc(&d.vc, need));
+    // zero-filled once: the decode attention multiplies rows past the sequence end by p = 0 instead of selecting them
+    // away, so whatever such a row holds has to be finite
+    ITTS_HIP_CHECK(hipMemsetAsync(d.kc, 0, need, s));
+    ITTS_HIP_CHECK(hipMemsetAsync(d.vc, 0, need, s));
     d.cache_bytes = need;
   }
   if (regrow) {
