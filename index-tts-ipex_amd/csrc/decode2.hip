@@ -295,6 +295,8 @@ __global__ __launch_bounds__(256) void gemv_bf16_kernel(GemvArgs g) {
   const int n0 = (blockIdx.x * 4 + wave) * RPW;
   // ---- 1. activations (+ LayerNorm parameters) first, weights second; all unconditional ----
   u32x4 xr[NB][KCH];  // XBF: 8 bf16; else 4 floats
+  f32x4 pm[PRO == 3 ? NB : 1][KCH], pl[PRO == 3 ? NB : 1][KCH], po[PRO == 3 ? NB : 1][KCH][ATTN_NSPLIT][2];
+  static_assert(PRO != 3 || (XBF && ATTN_NSPLIT == 4), "prologue 3 feeds bf16 pairs and reads 4 partials as one float4");
   f32x4 gm[PRO == 2 ? KCH : 1], bt[PRO == 2 ? KCH : 1];
   bool xok[KCH];
 #pragma unroll
@@ -305,8 +307,23 @@ __global__ __launch_bounds__(256) void gemv_bf16_kernel(GemvArgs g) {
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
       const size_t ro = (size_t)min(b, g.B - 1) * K + ic;
-      if (XBF) xr[b][j] = *reinterpret_cast<const u32x4*>((const bf16_t*)g.X + ro);
-      else xr[b][j] = *reinterpret_cast<const u32x4*>(g.X + ro);
+      if constexpr (PRO == 3) {
+        // x is the attention output, still in ATTN_NSPLIT partials: this thread's 8 dims of head ic / 64
+        const size_t bh = (size_t)min(b, g.B - 1) * (K >> 6) + (ic >> 6);
+        const float* ml = g.attn_ml + bh * 2 * ATTN_NSPLIT;
+        pm[b][j] = *reinterpret_cast<const f32x4*>(ml);
+        pl[b][j] = *reinterpret_cast<const f32x4*>(ml + ATTN_NSPLIT);
+#pragma unroll
+        for (int sp = 0; sp < ATTN_NSPLIT; ++sp) {
+          const float* po_ = g.attn_o + (bh * ATTN_NSPLIT + sp) * 64 + (ic & 63);
+          po[b][j][sp][0] = *reinterpret_cast<const f32x4*>(po_);
+          po[b][j][sp][1] = *reinterpret_cast<const f32x4*>(po_ + 4);
+        }
+      } else if (XBF) {
+        xr[b][j] = *reinterpret_cast<const u32x4*>((const bf16_t*)g.X + ro);
+      } else {
+        xr[b][j] = *reinterpret_cast<const u32x4*>(g.X + ro);
+      }
     }
     if (PRO == 2) {
       gm[j] = *reinterpret_cast<const f32x4*>(g.ln_gamma + ic);
@@ -315,7 +332,7 @@ __global__ __launch_bounds__(256) void gemv_bf16_kernel(GemvArgs g) {
   }
   float pivot[NB];
 #pragma unroll
-  for (int b = 0; b < NB; ++b) pivot[b] = PRO >= 1 ? g.X[(size_t)min(b, g.B - 1) * K] : 0.f;
+  for (int b = 0; b < NB; ++b) pivot[b] = (PRO == 1 || PRO == 2) ? g.X[(size_t)min(b, g.B - 1) * K] : 0.f;
   const bf16_t* __restrict__ W = (const bf16_t*)g.W;
   const uint8_t* __restrict__ Wq = (const uint8_t*)g.W8;
   u32x4 w[W8 ? 1 : RPW][W8 ? 1 : NCH];
@@ -416,6 +433,32 @@ __global__ __launch_bounds__(256) void gemv_bf16_kernel(GemvArgs g) {
           *reinterpret_cast<uint2*>(sxb + (b * K + i) / 2) = p;
         }
   } else {
+    if constexpr (PRO == 3) {
+      // merge the split-attention partials: weights exp(max_p - max), one division per head
+#pragma unroll
+      for (int b = 0; b < NB; ++b)
+#pragma unroll
+        for (int j = 0; j < KCH; ++j) {
+          const float M = fmaxf(fmaxf(pm[b][j][0], pm[b][j][1]), fmaxf(pm[b][j][2], pm[b][j][3]));
+          float wgt[ATTN_NSPLIT], L = 0.f;
+#pragma unroll
+          for (int sp = 0; sp < ATTN_NSPLIT; ++sp) {
+            wgt[sp] = pm[b][j][sp] > -INFINITY ? __expf(pm[b][j][sp] - M) : 0.f;
+            L = fmaf(wgt[sp], pl[b][j][sp], L);
+          }
+          const float inv = 1.f / L;
+          float xm[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            float a = 0.f;
+#pragma unroll
+            for (int sp = 0; sp < ATTN_NSPLIT; ++sp) a = fmaf(wgt[sp], po[b][j][sp][e >> 2][e & 3], a);
+            xm[e] = a * inv;
+          }
+#pragma unroll
+          for (int e = 0; e < 4; ++e) xr[b][j][e] = pack_bf16(xm[2 * e], xm[2 * e + 1]);
+        }
+    }
 #pragma unroll
     for (int b = 0; b < NB; ++b)
 #pragma unroll
@@ -692,18 +735,24 @@ __device__ unsigned long long* g_attn_stamp = nullptr;
 // NT = threads per (row, head): 1024 for the latency-bound small batches (one workgroup per CU), 256 once there are
 // enough (row, head) pairs to fill the CUs several times over - 5 workgroups per CU overlap their load / softmax /
 // merge phases, where the 86-VGPR 1024-thread form runs its 5 rounds per CU back to back.
-template <typename TC, typename TO, int NIT, int NT>
+// NSPLIT > 1: the keys of one (row, head) are dealt round-robin, SLOTS rows at a time, to NSPLIT workgroups
+// (blockIdx.z); each writes an un-normalised partial (max, sum, weighted V) and the consumer - the attention-projection
+// GEMV, prologue 3 - merges them while it loads its activations.  At 2 rows x 20 heads this turns 40 workgroups of 16
+// waves (4 waves per SIMD: the softmax phase is issue-bound and the last wave trails the first by 1.4 us on the phase
+// timeline) into 160 workgroups of 4 waves, one per SIMD, on 160 CUs.
+template <typename TC, typename TO, int NIT, int NT, int NSPLIT = 1>
 __global__ __launch_bounds__(NT) void decode_attn2_kernel(TO* __restrict__ ctx, const float* __restrict__ qkv,
                                                           TC* __restrict__ kc, TC* __restrict__ vc,
                                                           const int* __restrict__ len, const int* __restrict__ kv_start,
                                                           const int* __restrict__ prefix, int H, int Smax, float scale,
-                                                          int ctx_bt) {
+                                                          int ctx_bt, float* __restrict__ part_o = nullptr,
+                                                          float* __restrict__ part_ml = nullptr) {
   constexpr int DH = 64, VEC = CacheVec<TC>::VEC, LPK = CacheVec<TC>::LPK, NW = NT / 64, SLOTS = NT / LPK;
   constexpr int SD = NT >= 1024 ? 2 : 4;  // rows per slot in flight beyond the register window
   ATTN_STAMP(0)
   __shared__ float sm[NW], sl[NW];
   __shared__ float so[NW][DH];
-  const int h = blockIdx.x, b = blockIdx.y;
+  const int h = blockIdx.x, b = blockIdx.y, sp = NSPLIT > 1 ? blockIdx.z : 0;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int D = H * DH;
   TC* kb = kc + ((size_t)b * H + h) * Smax * DH;
@@ -718,7 +767,7 @@ __global__ __launch_bounds__(NT) void decode_attn2_kernel(TO* __restrict__ ctx, 
   constexpr int UNC = 2;  // 4 blind pairs (512 rows) measured slower: 0.602 vs 0.593 ms per step - the extra bytes cost more than the chain
 #pragma unroll
   for (int u = 0; u < UNC; ++u) {
-    const int j = min(u * SLOTS + slot, Smax - 1);
+    const int j = min((u * NSPLIT + sp) * SLOTS + slot, Smax - 1);
     kr[u].load(kb + (size_t)j * DH + sub * VEC);
     vr[u].load(vb + (size_t)j * DH + sub * VEC);
   }
@@ -741,8 +790,8 @@ __global__ __launch_bounds__(NT) void decode_attn2_kernel(TO* __restrict__ ctx, 
   //     otherwise make the wave sit out the first loads' latency before these are even issued
 #pragma unroll
   for (int u = UNC; u < 2 * NIT; ++u)
-    if (u * SLOTS < S) {  // block-uniform
-      const int j = min(u * SLOTS + slot, Smax - 1);
+    if ((u * NSPLIT + sp) * SLOTS < S) {  // block-uniform
+      const int j = min((u * NSPLIT + sp) * SLOTS + slot, Smax - 1);
       kr[u].load(kb + (size_t)j * DH + sub * VEC);
       vr[u].load(vb + (size_t)j * DH + sub * VEC);
     }
@@ -755,7 +804,7 @@ __global__ __launch_bounds__(NT) void decode_attn2_kernel(TO* __restrict__ ctx, 
     kown[i] = (float)(TC)(&kraw[i >> 2].x)[i & 3];
     vown[i] = (float)(TC)(&vraw[i >> 2].x)[i & 3];
   }
-  if (tid < LPK) {  // slot 0: its LPK lanes cover the 64 dims
+  if (tid < LPK && sp == 0) {  // slot 0 (of split 0): its LPK lanes cover the 64 dims
 #pragma unroll
     for (int i = 0; i < VEC; ++i) {
       stf(kb + (size_t)pos * DH + sub * VEC + i, kown[i]);
@@ -787,8 +836,8 @@ __global__ __launch_bounds__(NT) void decode_attn2_kernel(TO* __restrict__ ctx, 
     float sc[2 * NIT + 1];
 #pragma unroll
     for (int u = 0; u < 2 * NIT; ++u) {
-      const int j = u * SLOTS + slot;
-      const bool live = u < UNC || u * SLOTS < S;  // block-uniform: was this pair requested
+      const int j = (u * NSPLIT + sp) * SLOTS + slot;
+      const bool live = u < UNC || (u * NSPLIT + sp) * SLOTS < S;  // block-uniform: was this pair requested
       const float t = live ? score(kr[u]) : 0.f;
       sc[u] = (live && j < S && j >= ks && j != pos) ? t : -INFINITY;
     }
@@ -800,7 +849,7 @@ __global__ __launch_bounds__(NT) void decode_attn2_kernel(TO* __restrict__ ctx, 
       t = dpp_add<0x4E>(t);
       t = dpp_add<0x141>(t);
       if (LPK == 16) t = dpp_add<0x140>(t);
-      sc[2 * NIT] = slot == 0 ? t : -INFINITY;
+      sc[2 * NIT] = (slot == 0 && sp == 0) ? t : -INFINITY;
     }
     float mw = sc[0];
 #pragma unroll
@@ -808,7 +857,7 @@ __global__ __launch_bounds__(NT) void decode_attn2_kernel(TO* __restrict__ ctx, 
     if (mw > -INFINITY) {
 #pragma unroll
       for (int u = 0; u < 2 * NIT; ++u)
-        if (u < UNC || u * SLOTS < S) {        // block-uniform: pairs that were never requested hold no data at all
+        if (u < UNC || (u * NSPLIT + sp) * SLOTS < S) {  // block-uniform: pairs that were never requested hold no data at all
           const float p = __expf(sc[u] - mw);  // exp(-inf) = 0 for masked rows
           l += p;
 #pragma unroll
@@ -835,16 +884,16 @@ __global__ __launch_bounds__(NT) void decode_attn2_kernel(TO* __restrict__ ctx, 
     m = mn;
   };
   // sequences longer than the register-resident window: stream the rest two rows at a time
-  for (int jb = 2 * NIT * SLOTS; jb < S; jb += SD * SLOTS) {
+  for (int cb = 2 * NIT; (cb * NSPLIT + sp) * SLOTS < S; cb += SD) {  // chunk cb of this split = rows (cb*NSPLIT+sp)*SLOTS ..
     CacheVec<TC> k2[SD], v2[SD];
 #pragma unroll
     for (int u = 0; u < SD; ++u) {
-      const int j = min(jb + u * SLOTS + slot, Smax - 1);
+      const int j = min(((cb + u) * NSPLIT + sp) * SLOTS + slot, Smax - 1);
       k2[u].load(kb + (size_t)j * DH + sub * VEC);
       v2[u].load(vb + (size_t)j * DH + sub * VEC);
     }
 #pragma unroll
-    for (int u = 0; u < SD; ++u) consume(k2[u], v2[u], jb + u * SLOTS + slot);
+    for (int u = 0; u < SD; ++u) consume(k2[u], v2[u], ((cb + u) * NSPLIT + sp) * SLOTS + slot);
   }
   ATTN_STAMP(3)
   // merge the 64/LPK key slots of this wave (lanes with equal `sub`)
@@ -897,7 +946,16 @@ __global__ __launch_bounds__(NT) void decode_attn2_kernel(TO* __restrict__ ctx, 
       o = fmaf(e, so[i][tid], o);
       L = fmaf(e, sl[i], L);
     }
-    stf(ctx + (ctx_bt ? tile_off(b, h * DH + tid, ctx_bt) : (size_t)b * D + h * DH + tid), o / L);
+    if constexpr (NSPLIT > 1) {
+      // partial of this split: [row][head][split][64] un-normalised, and [row][head][2][NSPLIT] = (max..., sum...)
+      part_o[(((size_t)b * H + h) * NSPLIT + sp) * DH + tid] = o;
+      if (tid == 0) {
+        part_ml[((size_t)b * H + h) * 2 * NSPLIT + sp] = MM;
+        part_ml[((size_t)b * H + h) * 2 * NSPLIT + NSPLIT + sp] = L;
+      }
+    } else {
+      stf(ctx + (ctx_bt ? tile_off(b, h * DH + tid, ctx_bt) : (size_t)b * D + h * DH + tid), o / L);
+    }
   }
   ATTN_STAMP(6)
 }
@@ -1195,7 +1253,7 @@ static int launch_gemv_bf16(const GemvArgs& g, hipStream_t s) {
   dim3 grid((g.N + 4 * RPW - 1) / (4 * RPW)), blk(256);
   // measured (bench, 2 rows): all block-cooperative 0.602 ms per step, all wave-autonomous 0.615 ms - the per-wave copies
   // of x cost more address-pipeline time (16 clk per KiB wave-load per CU) than the LDS hand-over and its barriers
-  const bool block = g_gemv_mode == 2 || g_gemv_mode == 0 || (g_gemv_mode == 3 && !(XBF && NCH < 4));
+  const bool block = PRO == 3 || g_gemv_mode == 2 || g_gemv_mode == 0 || (g_gemv_mode == 3 && !(XBF && NCH < 4));
   if (block) {
     if (g.W8)
       hipLaunchKernelGGL((gemv_bf16_kernel<NB, RPW, NCH, PRO, XBF, YBF, true>), grid, blk, (size_t)NB * g.K * 2, s, g);
@@ -1220,11 +1278,13 @@ static int dispatch_gemv_bf16(const GemvArgs& g, hipStream_t s) {
     if (g.prologue == 1 && !g.x_bf16 && !g.y_bf16) return launch_gemv_bf16<NB, 1, 1, 1, false, false>(g, s);
     if (g.prologue == 2 && !g.x_bf16 && !g.y_bf16) return launch_gemv_bf16<NB, 1, 1, 2, false, false>(g, s);
     if (g.prologue == 0 && g.x_bf16 && !g.y_bf16) return launch_gemv_bf16<NB, 1, 1, 0, true, false>(g, s);
+    if (g.prologue == 3 && g.x_bf16 && !g.y_bf16) return launch_gemv_bf16<NB, 1, 1, 3, true, false>(g, s);
   } else if (nch <= 3) {
     if (g.prologue == 1 && !g.x_bf16 && g.y_bf16) return launch_gemv_bf16<NB, 2, 3, 1, false, true>(g, s);    // fc
     if (g.prologue == 1 && !g.x_bf16 && !g.y_bf16) return launch_gemv_bf16<NB, 2, 3, 1, false, false>(g, s);  // qkv
     if (g.prologue == 2 && !g.x_bf16 && !g.y_bf16) return launch_gemv_bf16<NB, 4, 3, 2, false, false>(g, s);  // head
     if (g.prologue == 0 && g.x_bf16 && !g.y_bf16) return launch_gemv_bf16<NB, 2, 3, 0, true, false>(g, s);    // proj
+    if (g.prologue == 3 && g.x_bf16 && !g.y_bf16) return launch_gemv_bf16<NB, 2, 3, 3, true, false>(g, s);    // proj fed by split attention
   } else if (nch <= 4) {
     if (g.prologue == 0 && g.x_bf16 && !g.y_bf16) return launch_gemv_bf16<NB, 2, 4, 0, true, false>(g, s);
   } else if (nch <= 10) {
@@ -1237,6 +1297,7 @@ static int dispatch_gemv_bf16(const GemvArgs& g, hipStream_t s) {
 bool gemv_bf16_supported(const GemvArgs& g) {
   const int nch = (g.K + 511) / 512;
   if (!(g.B >= 1 && g.B <= 4 && g.K % 8 == 0 && g.K >= 64 && nch <= 10)) return false;
+  if (g.x_bf16 && g.prologue == 3) return !g.y_bf16 && g.K % 64 == 0 && (nch <= 1 || nch == 3) && g.attn_o && g.attn_ml;
   if (g.x_bf16) return g.prologue == 0 && !g.y_bf16 && (nch <= 1 || nch == 3 || nch == 4 || (nch > 4 && nch <= 10));
   if (g.prologue == 0 || nch > 3) return false;
   return !(g.prologue == 2 && g.y_bf16);
@@ -1249,7 +1310,7 @@ int gemv_bf16(const GemvArgs& g, hipStream_t s) {
     return true;
   }();
   (void)once;
-  ITTS_REQUIRE(g.X && (g.W || g.W8) && g.Y && g.N > 0, "gemv_bf16: bad args");
+  ITTS_REQUIRE((g.X || g.prologue == 3) && (g.W || g.W8) && g.Y && g.N > 0, "gemv_bf16: bad args");
   ITTS_REQUIRE(!g.W8 || g.wscale, "gemv_bf16: fp8 weights need their row scales");
   ITTS_REQUIRE(gemv_bf16_supported(g), "gemv_bf16: unsupported shape");
   ITTS_REQUIRE(!(g.accumulate && g.y_bf16), "gemv_bf16: accumulate needs an fp32 output");
@@ -1259,8 +1320,17 @@ int gemv_bf16(const GemvArgs& g, hipStream_t s) {
 }
 
 int decode_attn2(void* ctx, int to, const float* qkv, void* kc, void* vc, const int* len, const int* kv_start,
-                 const int* prefix_dev, int B, int H, int dh, int Smax, int tc, hipStream_t s, int ctx_tiled) {
+                 const int* prefix_dev, int B, int H, int dh, int Smax, int tc, hipStream_t s, int ctx_tiled, float* part_o,
+                 float* part_ml) {
   ITTS_REQUIRE(dh == 64, "decode_attn2: head dim must be 64");
+  if (part_o) {  // split form: 4 workgroups of 256 threads per (row, head), partials merged by the projection GEMV
+    ITTS_REQUIRE(part_ml && tc == BF16, "decode_attn2: split form needs both partial buffers and a bf16 cache");
+    const float scale = 1.f / sqrtf((float)dh);
+    hipLaunchKernelGGL((decode_attn2_kernel<bf16_t, bf16_t, 3, 256, ATTN_NSPLIT>), dim3(H, B, ATTN_NSPLIT), dim3(256), 0, s, (bf16_t*)nullptr,
+                       qkv, (bf16_t*)kc, (bf16_t*)vc, len, kv_start, prefix_dev, H, Smax, scale, 0, part_o, part_ml);
+    ITTS_HIP_CHECK(hipGetLastError());
+    return OK;
+  }
   ITTS_REQUIRE(!ctx_tiled || to == BF16, "decode_attn2: tiled ctx is bf16 only");
   const float scale = 1.f / sqrtf((float)dh);
   dim3 grid(H, B);

@@ -110,6 +110,7 @@ struct DecodeState {
   size_t cache_bytes = 0;
   void *kc = nullptr, *vc = nullptr;  // [layers][B][H][Smax][dh]
   float *h = nullptr, *qkv = nullptr, *ctx = nullptr, *act = nullptr, *hn = nullptr, *logits = nullptr;
+  float *attn_o = nullptr, *attn_ml = nullptr;  // split decode attention partials (decode2.hip ATTN_NSPLIT), small batches
   float* partial = nullptr;           // [4][B][D] split-K partial sums of the residual projections (batched decode)
   int pend_split = 0;                 // launch-time bookkeeping: partials waiting to be absorbed by the next LayerNorm
   const float* pend_bias = nullptr;

@@ -14,7 +14,7 @@ struct GemvArgs {
   int B = 0, N = 0, K = 0, ldy = 0;
   int act = ACT_NONE;
   int accumulate = 0;                // Y += result (residual stream)
-  int prologue = 0;                  // 0 plain, 1 LayerNorm(X), 2 LN2(LN(X))
+  int prologue = 0;                  // 0 plain, 1 LayerNorm(X), 2 LN2(LN(X)), 3 merge split-attention partials
   int x_bf16 = 0;                    // X is bf16 [B, K] (gemv_bf16 only)
   int y_bf16 = 0;                    // Y is bf16 [B, ldy] (gemv_bf16 only; no accumulate)
   const float* ln_gamma = nullptr;
@@ -25,6 +25,9 @@ struct GemvArgs {
   int ksplit = 1;            // skinny_mfma: K split across workgroups; > 1 writes raw sums to partial[split][B][ldy]
   float* partial = nullptr;
   const struct Lin* w8src = nullptr;  // engine-internal: projection whose fp8 copy may replace W (decode GEMV)
+  // prologue 3 (gemv_bf16): x = the attention output merged from ATTN_NSPLIT partials of decode_attn2 (K = heads * 64)
+  const float* attn_o = nullptr;   // [B][heads][ATTN_NSPLIT][64] un-normalised weighted V
+  const float* attn_ml = nullptr;  // [B][heads][2][ATTN_NSPLIT] partial max / sum
   const void* W8 = nullptr;      // gemv_bf16: [N, K] OCP fp8 e4m3 bytes (instead of W) ...
   const float* wscale = nullptr; // ... with one scale per output row: y = scale[n] * (x . w8[n]) + bias[n]
   unsigned long long* stamp = nullptr;  // -DITTS_GEMV_STAMPS builds only (tools/ubench_gemv2.hip): s_memtime per phase
@@ -68,7 +71,9 @@ int kv_scatter(void* kc, void* vc, const void* qkv, int B, int S, int H, int dh,
 bool gemv2_supported(const GemvArgs& g);
 int gemv2(const GemvArgs& g, int tw, hipStream_t s);
 int decode_attn2(void* ctx, int to, const float* qkv, void* kc, void* vc, const int* len, const int* kv_start,
-                 const int* prefix_dev, int B, int H, int dh, int Smax, int tc, hipStream_t s, int ctx_tiled = 0);
+                 const int* prefix_dev, int B, int H, int dh, int Smax, int tc, hipStream_t s, int ctx_tiled = 0,
+                 float* part_o = nullptr, float* part_ml = nullptr);
+constexpr int ATTN_NSPLIT = 4;  // workgroups per (row, head) in the split form of decode_attn2
 bool gemv_bf16_supported(const GemvArgs& g);
 int gemv_bf16(const GemvArgs& g, hipStream_t s);
 int sampler2_step(const SamplerArgs& a, int B, hipStream_t s);

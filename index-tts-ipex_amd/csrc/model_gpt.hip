@@ -6,6 +6,8 @@
 #include <cmath>
 #include <cstring>
 
+#include <cstdlib>
+
 #include "engine.h"
 
 namespace itts {
@@ -135,6 +137,8 @@ int Engine::ensure_decode_state(int B, int Smax, int max_gen, hipStream_t s) {
     ITTS_TRY(dev_alloc((void**)&d.act, (size_t)cb * 4 * D * 4));
     ITTS_TRY(dev_alloc((void**)&d.hn, (size_t)cb * D * 4));
     ITTS_TRY(dev_alloc((void**)&d.partial, (size_t)4 * cb * D * 4));
+    ITTS_TRY(dev_alloc((void**)&d.attn_o, (size_t)cb * D * ATTN_NSPLIT * 4));
+    ITTS_TRY(dev_alloc((void**)&d.attn_ml, (size_t)cb * H * 2 * ATTN_NSPLIT * 4));
     ITTS_TRY(dev_alloc((void**)&d.logits, (size_t)cb * V * 4));
     ITTS_TRY(dev_alloc((void**)&d.kv_start, (size_t)cb * 4));
     ITTS_TRY(dev_alloc((void**)&d.cur_tok, (size_t)cb * 4));
@@ -377,8 +381,15 @@ int Engine::decode_step_launch(hipStream_t s) {
     g.w8src = L.attn.w8 ? &L.attn : nullptr;
     ITTS_TRY(run(g, L.attn.dt));
     const size_t lo = (size_t)l * B * H * ds.Smax * dh * es;
-    ITTS_TRY(decode_attn2(ds.ctx, bf_ctx ? BF16 : F32, ds.qkv, (char*)ds.kc + lo, (char*)ds.vc + lo, ds.len, ds.kv_start,
-                          ds.prefix_dev, B, H, dh, ds.Smax, adt, s, skinny ? 1 : 0));
+    // few (row, head) pairs: the keys of each pair go to ATTN_NSPLIT workgroups and the projection merges the partials
+    static const bool no_split = getenv("ITTS_ATTN_NOSPLIT") != nullptr;
+    const bool split = fast && bf_ctx && !no_split && (long)B * H <= 128 && D % 64 == 0;
+    if (split)
+      ITTS_TRY(decode_attn2(nullptr, BF16, ds.qkv, (char*)ds.kc + lo, (char*)ds.vc + lo, ds.len, ds.kv_start, ds.prefix_dev, B, H,
+                            dh, ds.Smax, adt, s, 0, ds.attn_o, ds.attn_ml));
+    else
+      ITTS_TRY(decode_attn2(ds.ctx, bf_ctx ? BF16 : F32, ds.qkv, (char*)ds.kc + lo, (char*)ds.vc + lo, ds.len, ds.kv_start,
+                            ds.prefix_dev, B, H, dh, ds.Smax, adt, s, skinny ? 1 : 0));
     GemvArgs p;  // h += ctx Wproj + b
     p.B = B;
     p.X = ds.ctx;
@@ -390,6 +401,12 @@ int Engine::decode_step_launch(hipStream_t s) {
     p.K = D;
     p.ldy = D;
     p.accumulate = 1;
+    if (split) {
+      p.prologue = 3;
+      p.attn_o = ds.attn_o;
+      p.attn_ml = ds.attn_ml;
+      ITTS_REQUIRE(gemv_bf16_supported(p), "decode: split attention needs the bf16 GEMV with prologue 3");
+    }
     p.w8src = L.proj.w8 ? &L.proj : nullptr;
     ITTS_TRY(run(p, L.proj.dt));
     GemvArgs f;  // act = gelu_new(LN2(h) Wfc + b)
