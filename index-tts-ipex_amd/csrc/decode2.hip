@@ -266,7 +266,7 @@ __device__ __forceinline__ float dot2(uint32_t a, uint32_t b, float c) {
 
 // PRO: 0 plain, 1 LayerNorm without affine (gamma/beta are folded into W by the packer), 2 LayerNorm(affine) then
 // LayerNorm without affine (ln_f, then final_norm folded into mel_head).  XBF: X is bf16 [B, K].  YBF: Y is bf16.
-// (A wave-specialised variant - dedicated activation waves - was measured slower: profiles/README.md.)
+// (A wave-specialised variant - dedicated activation waves - was measured slower.)
 // Every batch row uses the SAME thread <-> element mapping, so a row's result does not depend on its position in
 // the batch (the padding/batch invariance the reference's tests/padding_test.py checks).
 // W8: weights stored as OCP fp8 e4m3 bytes with one power-of-two scale per output row (BASELINE config 5): half the
@@ -350,8 +350,6 @@ __global__ __launch_bounds__(256) void gemv_bf16_kernel(GemvArgs g) {
         w[r][c] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(W + (size_t)min(n0 + r, g.N - 1) * K + k));
     }
   }
-  // bias and the residual-stream value this row accumulates into: requested now (youngest loads, wave-uniform
-  // addresses, unconditional), so the epilogue has no dependent memory latency of its own
   // epilogue operands of the output this lane will finish, (row lane / NB, batch lane % NB): bias, fp8 row scale and the
   // residual-stream value it accumulates into are requested now (youngest loads, unconditional), so the epilogue has no
   // dependent memory latency of its own
