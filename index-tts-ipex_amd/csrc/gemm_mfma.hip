@@ -237,7 +237,9 @@ int dispatch(const GemmArgs& g, hipStream_t s) {
   // ring depth: deep where a CU holds 1-2 workgroups (nothing else hides the refill latency), 1 where there are many
   // tiles per CU (the extra registers would cost more occupancy than the ring buys)
   if (g.N <= 32) return launch<128, 32, TC, 1>(g, s);
-  if (g.N >= 128 && tiles(128, 128) >= 768)
+  // N = 192 (BigVGAN stage 3): two 128-wide tiles would waste a quarter of the MFMA work, three 64-wide tiles none
+  const bool ragged128 = g.N % 128 != 0 && g.N % 64 == 0 && g.N < 256;
+  if (g.N >= 128 && tiles(128, 128) >= 768 && !ragged128)
     return tiles(128, 128) >= 1536 ? launch<128, 128, TC, 1>(g, s) : launch<128, 128, TC, 2>(g, s);
   if (tiles(128, 64) >= 512 || g.M <= 64) {
     if (g.M <= 64) return launch<64, 64, TC, 4>(g, s);
