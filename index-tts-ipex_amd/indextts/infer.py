@@ -130,15 +130,20 @@ class IndexTTS:
             t_gen += time.perf_counter() - t0
             if (codes[:, -1] != self.stop_mel_token).any():
                 warnings.warn(f"WARN: generation stopped due to exceeding `max_mel_tokens` ({max_mel_tokens}).", RuntimeWarning)
-            for r, item in enumerate(bk):
+            # latent pass for the whole bucket in one launch sequence (left-padded, masked: each sentence gets exactly its
+            # batch-1 latent), then the vocoder per sentence (code lengths differ after remove_long_silence)
+            clean = []
+            for r in range(len(bk)):
                 c, n = infer_core.remove_long_silence(codes[r:r + 1], self.stop_mel_token)
-                t0 = time.perf_counter()
-                lat = self.engine.latent(cond, item["sent"], c[0, : int(n[0])])
-                t_fwd += time.perf_counter() - t0
-                t0 = time.perf_counter()
+                clean.append(c[0, : int(n[0])])
+            t0 = time.perf_counter()
+            lats = self.engine.latent_batch(cond, [item["sent"] for item in bk], clean)
+            t_fwd += time.perf_counter() - t0
+            t0 = time.perf_counter()
+            for lat, item in zip(lats, bk):
                 wav = self.engine.bigvgan(lat, spk)
-                t_voc += time.perf_counter() - t0
                 wav_by_idx[item["idx"]] = torch.clamp(32767 * wav.squeeze(1), -32767.0, 32767.0).cpu()
+            t_voc += time.perf_counter() - t0
             self._set_gr_progress(0.2 + 0.7 * (bi + 1) / len(buckets), f"synthesis {bi + 1}/{len(buckets)}")
         wav = torch.cat([wav_by_idx[i] for i in range(len(sents))], dim=1)
         total = time.perf_counter() - start
