@@ -236,6 +236,13 @@ int dispatch(const GemmArgs& g, hipStream_t s) {
   auto tiles = [&](int bm, int bn) { return (long)((g.M + bm - 1) / bm) * ((g.N + bn - 1) / bn) * g.nphase; };
   // ring depth: deep where a CU holds 1-2 workgroups (nothing else hides the refill latency), 1 where there are many
   // tiles per CU (the extra registers would cost more occupancy than the ring buys)
+  static const int force = [] {  // ITTS_GEMM_TILE=1 (128x128) / 2 (128x64) / 3 (64x64): experiments only
+    const char* e = getenv("ITTS_GEMM_TILE");
+    return e ? atoi(e) : 0;
+  }();
+  if (force == 1 && g.N >= 64) return launch<128, 128, TC, 2>(g, s);
+  if (force == 2 && g.N >= 64) return launch<128, 64, TC, 2>(g, s);
+  if (force == 3 && g.N >= 64) return launch<64, 64, TC, 4>(g, s);
   if (g.N <= 32) return launch<128, 32, TC, 1>(g, s);
   // N = 192 (BigVGAN stage 3): two 128-wide tiles would waste a quarter of the MFMA work, three 64-wide tiles none
   const bool ragged128 = g.N % 128 != 0 && g.N % 64 == 0 && g.N < 256;
