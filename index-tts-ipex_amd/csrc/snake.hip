@@ -20,6 +20,7 @@ namespace itts {
 namespace {
 
 constexpr int RUN = 32;
+constexpr int RUNL = 36;  // LDS-tiled kernel: a multiple of 6, the rotation period of its unrolled inner loop
 
 template <typename T>
 struct SnakeCtx {
@@ -127,7 +128,7 @@ __global__ __launch_bounds__(256) void snake_aa_lds_kernel(T* __restrict__ y, co
                                                            int Tn, int C, int CT, int tiles_t, int slabs) {
   constexpr int VEC = 16 / (int)sizeof(T);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_snake[];
-  const int runs = 256 / CT, TT = runs * RUN;
+  const int runs = 256 / CT, TT = runs * RUNL;
   T* sx = reinterpret_cast<T*>(smem_snake);                       // [(TT + 12)][CT]
   T* so = sx + (size_t)(TT + 12) * CT;                            // [TT][CT]
   int bid = blockIdx.x;
@@ -163,10 +164,9 @@ __global__ __launch_bounds__(256) void snake_aa_lds_kernel(T* __restrict__ y, co
       return u + inv_b * sn * sn;
     };
     const T* col = sx + c;
-    auto xin = [&](int t) {  // x[clamp(t)] of this channel; t within [t0 - 6, t0 + TT + 6)
-      t = t < 0 ? 0 : (t >= Tn ? Tn - 1 : t);
-      return ldf(col + (size_t)(t - (t0 - 6)) * CT);
-    };
+    // x[clamp(t)] of this channel for t in [t0 - 6, t0 + TT + 6): the replicate padding was resolved when the tile was
+    // loaded (row i holds x[clamp(t0 - 6 + i)]), so this is a plain row lookup
+    auto xin = [&](int t) { return ldf(col + (t - (t0 - 6)) * CT); };
     const int mlast = 2 * Tn - 1;
     auto v_at = [&](int m) {
       m = m < 0 ? 0 : (m > mlast ? mlast : m);
@@ -181,8 +181,8 @@ __global__ __launch_bounds__(256) void snake_aa_lds_kernel(T* __restrict__ y, co
       }
       return act(2.f * u);
     };
-    const int ts = t0 + run * RUN;
-    const int te = min(ts + RUN, Tn);
+    const int ts = t0 + run * RUNL;
+    const int te = min(ts + RUNL, Tn);
     if (ts < Tn) {
       float v[12], xs[6];
 #if defined(SNAKE_EXPERIMENT) && SNAKE_EXPERIMENT == 2
@@ -194,34 +194,56 @@ __global__ __launch_bounds__(256) void snake_aa_lds_kernel(T* __restrict__ y, co
 #endif
 #pragma unroll
       for (int i = 0; i < 6; ++i) xs[i] = xin(ts + i);
-#if defined(SNAKE_EXPERIMENT) && SNAKE_EXPERIMENT == 1
-      for (int t = ts; t < te; ++t) stf(so + (size_t)(t - t0) * CT + c, xin(t) + v[0]);
-      if (false)
-#endif
-      for (int t = ts; t < te; ++t) {
-        float uo = 0.f, ue = 0.f;
+      const T* px = col + (ts + 6 - (t0 - 6)) * CT;  // next input row to enter the window
+      T* po = so + (ts - t0) * CT + c;
+      if (2 * (te - 1) + 6 <= mlast) {
+        // interior run (every tile but the last of a sequence): no end-of-stream selects; unrolled by the rotation
+        // period of the two register windows so the shifts become renames
+#pragma unroll 6
+        for (int t = ts; t < te; ++t) {
+          float uo = 0.f, ue = 0.f;
 #pragma unroll
-        for (int r = 0; r < 6; ++r) {
-          uo = fmaf(fu[2 * r], xs[5 - r], uo);
-          ue = fmaf(fu[2 * r + 1], xs[5 - r], ue);
+          for (int r = 0; r < 6; ++r) {
+            uo = fmaf(fu[2 * r], xs[5 - r], uo);
+            ue = fmaf(fu[2 * r + 1], xs[5 - r], ue);
+          }
+          v[10] = act(2.f * uo);
+          v[11] = act(2.f * ue);
+          float o = 0.f;
+#pragma unroll
+          for (int j = 0; j < 12; ++j) o = fmaf(fd[j], v[j], o);
+          stf(po, o);
+          po += CT;
+#pragma unroll
+          for (int j = 0; j < 10; ++j) v[j] = v[j + 2];
+#pragma unroll
+          for (int i = 0; i < 5; ++i) xs[i] = xs[i + 1];
+          xs[5] = ldf(px);
+          px += CT;
         }
-        const float vprev = v[9];
-#if defined(SNAKE_EXPERIMENT) && SNAKE_EXPERIMENT == 3
-        v[10] = (2 * t + 5 <= mlast) ? 2.f * uo : vprev;
-        v[11] = (2 * t + 6 <= mlast) ? 2.f * ue : v[10];
-#else
-        v[10] = (2 * t + 5 <= mlast) ? act(2.f * uo) : vprev;
-        v[11] = (2 * t + 6 <= mlast) ? act(2.f * ue) : v[10];
-#endif
-        float o = 0.f;
+      } else {
+        for (int t = ts; t < te; ++t) {
+          float uo = 0.f, ue = 0.f;
 #pragma unroll
-        for (int j = 0; j < 12; ++j) o = fmaf(fd[j], v[j], o);
-        stf(so + (size_t)(t - t0) * CT + c, o);
+          for (int r = 0; r < 6; ++r) {
+            uo = fmaf(fu[2 * r], xs[5 - r], uo);
+            ue = fmaf(fu[2 * r + 1], xs[5 - r], ue);
+          }
+          const float vprev = v[9];
+          v[10] = (2 * t + 5 <= mlast) ? act(2.f * uo) : vprev;
+          v[11] = (2 * t + 6 <= mlast) ? act(2.f * ue) : v[10];
+          float o = 0.f;
 #pragma unroll
-        for (int j = 0; j < 10; ++j) v[j] = v[j + 2];
+          for (int j = 0; j < 12; ++j) o = fmaf(fd[j], v[j], o);
+          stf(po, o);
+          po += CT;
 #pragma unroll
-        for (int i = 0; i < 5; ++i) xs[i] = xs[i + 1];
-        xs[5] = xin(t + 6);
+          for (int j = 0; j < 10; ++j) v[j] = v[j + 2];
+#pragma unroll
+          for (int i = 0; i < 5; ++i) xs[i] = xs[i + 1];
+          xs[5] = ldf(px);
+          px += CT;
+        }
       }
     }
   }
@@ -243,7 +265,7 @@ static int launch_snake_lds(void* y, const void* x, const float* la, const float
     CT = 64;
     while (C % CT) CT -= 8;
   }
-  const int runs = 256 / CT, TT = runs * RUN;
+  const int runs = 256 / CT, TT = runs * RUNL;
   const int tiles_t = (Tn + TT - 1) / TT, slabs = C / CT;
   const size_t lds = ((size_t)(TT + 12) * CT + (size_t)TT * CT) * sizeof(T);
   hipLaunchKernelGGL((snake_aa_lds_kernel<T, FAST>), dim3((unsigned)((long)B * tiles_t * slabs)), dim3(256), lds, s, (T*)y,
