@@ -144,6 +144,7 @@ __global__ __launch_bounds__(256) void conv_lds_kernel(GemmArgs g, int tiles_per
   const bf16_t* __restrict__ R = g.R ? (const bf16_t*)g.R + (size_t)b * T * g.ldr : nullptr;
   const bf16_t* __restrict__ ADD = g.ADD ? (const bf16_t*)g.ADD + (size_t)b * T * g.ldadd : nullptr;
   const float* bias = g.bias ? g.bias + (size_t)b * g.bias_bstride : nullptr;
+  const bool plain = g.act == ACT_NONE && g.act2 == ACT_NONE && !g.scale && !g.shift && (!bias || ((uintptr_t)bias & 15) == 0);
   for (int v = tid; v < BM * nv; v += 256) {
     const int m = v / nv, q = v - m * nv, t = t0 + m;
     if (t >= T) continue;
@@ -159,17 +160,36 @@ __global__ __launch_bounds__(256) void conv_lds_kernel(GemmArgs g, int tiles_per
     const bf16_t* ab = reinterpret_cast<const bf16_t*>(&av);
     u32x4 ov;
     bf16_t* ob = reinterpret_cast<bf16_t*>(&ov);
+    if (plain) {
+      // the AMP-block form (bias, residual, alpha, beta * running sum; no activation / BN affine): straight-line code -
+      // on the narrow stages this epilogue is issue-bound
+      float bv[8];
+      if (bias) {
+        const float4 b0 = *reinterpret_cast<const float4*>(bias + n), b1 = *reinterpret_cast<const float4*>(bias + n + 4);
+        bv[0] = b0.x; bv[1] = b0.y; bv[2] = b0.z; bv[3] = b0.w; bv[4] = b1.x; bv[5] = b1.y; bv[6] = b1.z; bv[7] = b1.w;
+      } else {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      float x = o[e];
-      if (bias) x += bias[n + e];
-      x = act_apply(g.act, x);
-      x = x * (g.scale ? g.scale[n + e] : 1.f) + (g.shift ? g.shift[n + e] : 0.f);
-      x = act_apply(g.act2, x);
-      if (R) x += (float)rb[e];
-      x *= g.alpha;
-      if (ADD) x += g.beta * (float)ab[e];
-      ob[e] = (bf16_t)x;
+        for (int e = 0; e < 8; ++e) bv[e] = 0.f;
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float x = o[e] + bv[e] + (float)rb[e];        // rv / av are zero vectors when R / ADD are absent
+        x = fmaf(g.beta, (float)ab[e], x * g.alpha);
+        ob[e] = (bf16_t)x;
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float x = o[e];
+        if (bias) x += bias[n + e];
+        x = act_apply(g.act, x);
+        x = x * (g.scale ? g.scale[n + e] : 1.f) + (g.shift ? g.shift[n + e] : 0.f);
+        x = act_apply(g.act2, x);
+        if (R) x += (float)rb[e];
+        x *= g.alpha;
+        if (ADD) x += g.beta * (float)ab[e];
+        ob[e] = (bf16_t)x;
+      }
     }
     *reinterpret_cast<u32x4*>(Cc + (size_t)t * g.ldc + n) = ov;
   }
