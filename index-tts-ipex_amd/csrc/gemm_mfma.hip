@@ -180,24 +180,38 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmArgs g) {
   const TC* __restrict__ R = (const TC*)g.R;
   const TC* __restrict__ ADD = (const TC*)g.ADD;
   const int cr = (lane >> 4) * 4, cc = lane & 15;
+  // per-column operands once per column tile, per-row operands (batch item of the row -> bias row) once per row: the
+  // m / T division used to run per element
+  const bool plain = g.act == ACT_NONE && g.act2 == ACT_NONE && !g.scale && !g.shift;
+  float sc[NT], sh[NT];
+  int ncol[NT];
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
     const int n = n0 + wn * WN + j * 16 + cc;
-    if (n >= g.N) continue;
-    const int col = phase * g.N + n;
-    const float sc = g.scale ? g.scale[n] : 1.f;
-    const float sh = g.shift ? g.shift[n] : 0.f;
+    ncol[j] = n;
+    const int nc = min(n, g.N - 1);
+    sc[j] = g.scale ? g.scale[nc] : 1.f;
+    sh[j] = g.shift ? g.shift[nc] : 0.f;
+  }
 #pragma unroll
-    for (int i = 0; i < MT; ++i) {
+  for (int i = 0; i < MT; ++i) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int m = m0 + wm * WM + i * 16 + cr + r;
-        if (m >= g.M) continue;
+    for (int r = 0; r < 4; ++r) {
+      const int m = m0 + wm * WM + i * 16 + cr + r;
+      if (m >= g.M) continue;
+      const float* brow = g.bias ? g.bias + (g.bias_bstride ? (size_t)(m / T) * g.bias_bstride : 0) : nullptr;
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const int n = ncol[j];
+        if (n >= g.N) continue;
+        const int col = phase * g.N + n;
         float v = acc[i][j][r];
-        if (g.bias) v += g.bias[(size_t)(m / T) * g.bias_bstride + n];
-        v = act_apply(g.act, v);
-        v = v * sc + sh;
-        v = act_apply(g.act2, v);
+        if (brow) v += brow[n];
+        if (!plain) {
+          v = act_apply(g.act, v);
+          v = v * sc[j] + sh[j];
+          v = act_apply(g.act2, v);
+        }
         if (R) v += ldf(R + (size_t)m * g.ldr + col);
         v *= g.alpha;
         if (ADD) v += g.beta * ldf(ADD + (size_t)m * g.ldadd + col);
