@@ -120,7 +120,7 @@ struct DecodeState {
   int cap_B = 0, cap_gen = 0;
   float penalty = 1.f;
   int suppress_stop = 0;
-  hipGraphExec_t graph = nullptr;
+  hipGraphExec_t graph = nullptr, graphK = nullptr;  // one decode step / ITTS_GRAPH_STEPS (8) steps per launch
   int graph_B = 0, graph_Smax = 0, graph_suppress = 0;
   // multinomial sampling (itts_gpt_set_sampling): parameters baked into the captured step, uniforms [max_gen][B]
   int do_sample = 0, top_k = 0, graph_sample = 0, graph_top_k = 0;

@@ -14,6 +14,7 @@ Engine::~Engine() {
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (d.graph) (void)hipGraphExecDestroy(d.graph);
+  if (d.graphK) (void)hipGraphExecDestroy(d.graphK);
 }
 
 int Engine::ws_reserve(size_t bytes, hipStream_t s) {

@@ -114,10 +114,11 @@ int Engine::ensure_decode_state(int B, int Smax, int max_gen, hipStream_t s) {
   const bool regrow = B > d.cap_B || max_gen > d.cap_gen;
   if (need > d.cache_bytes || regrow || B != d.B || Smax != d.Smax) {
     ITTS_HIP_CHECK(hipStreamSynchronize(s));
-    if (d.graph) {
-      (void)hipGraphExecDestroy(d.graph);
-      d.graph = nullptr;
-    }
+    for (hipGraphExec_t* ge : {&d.graph, &d.graphK})
+      if (*ge) {
+        (void)hipGraphExecDestroy(*ge);
+        *ge = nullptr;
+      }
   }
   if (need > d.cache_bytes) {
     ITTS_TRY(dev_alloc(&d.kc, need));
@@ -181,10 +182,11 @@ int Engine::gpt_prefill(const float* cond_dev, const int32_t* text_ids, int B, i
     ITTS_REQUIRE(sample_uniforms.size() >= need_u, "gpt_prefill: sampling enabled but fewer than max_gen * B uniforms were supplied");
     if (need_u > ds.uniforms_cap) {
       ITTS_HIP_CHECK(hipStreamSynchronize(s));
-      if (ds.graph) {  // the captured sampler holds the old pointer
-        (void)hipGraphExecDestroy(ds.graph);
-        ds.graph = nullptr;
-      }
+      for (hipGraphExec_t* ge : {&ds.graph, &ds.graphK})  // the captured samplers hold the old pointer
+        if (*ge) {
+          (void)hipGraphExecDestroy(*ge);
+          *ge = nullptr;
+        }
       ITTS_TRY(dev_alloc((void**)&ds.uniforms, need_u * 4));
       ds.uniforms_cap = need_u;
     }
@@ -472,22 +474,33 @@ int Engine::gpt_decode(int nsteps, hipStream_t s) {
     const bool stale = !d.graph || d.graph_B != d.B || d.graph_Smax != d.Smax || d.graph_penalty != d.penalty ||
                        d.graph_suppress != d.suppress_stop || d.graph_sample != d.do_sample || d.graph_top_k != d.top_k ||
                        d.graph_top_p != d.top_p || d.graph_temperature != d.temperature;
+    // two executables: one step, and GK steps back to back (one launch per GK tokens: the gap between consecutive graph
+    // launches is paid once per GK steps; every step reads its lengths from device memory, so any mix is valid)
+    static const int GK = [] {
+      const char* e = getenv("ITTS_GRAPH_STEPS");
+      const int v = e ? atoi(e) : 8;
+      return v < 1 ? 1 : (v > 32 ? 32 : v);
+    }();
     if (stale && nsteps > 0) {
-      if (d.graph) {
-        (void)hipGraphExecDestroy(d.graph);
-        d.graph = nullptr;
+      for (hipGraphExec_t* ge : {&d.graph, &d.graphK})
+        if (*ge) {
+          (void)hipGraphExecDestroy(*ge);
+          *ge = nullptr;
+        }
+      for (int which = 0; which < (GK > 1 ? 2 : 1); ++which) {
+        hipGraph_t g = nullptr;
+        ITTS_HIP_CHECK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+        int st = OK;
+        for (int k = 0; k < (which ? GK : 1) && st == OK; ++k) st = decode_step_launch(s);
+        const hipError_t ee = hipStreamEndCapture(s, &g);
+        if (st != OK) {
+          if (g) (void)hipGraphDestroy(g);
+          return st;
+        }
+        ITTS_HIP_CHECK(ee);
+        ITTS_HIP_CHECK(hipGraphInstantiate(which ? &d.graphK : &d.graph, g, nullptr, nullptr, 0));
+        (void)hipGraphDestroy(g);
       }
-      hipGraph_t g = nullptr;
-      ITTS_HIP_CHECK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-      const int st = decode_step_launch(s);
-      const hipError_t ee = hipStreamEndCapture(s, &g);
-      if (st != OK) {
-        if (g) (void)hipGraphDestroy(g);
-        return st;
-      }
-      ITTS_HIP_CHECK(ee);
-      ITTS_HIP_CHECK(hipGraphInstantiate(&d.graph, g, nullptr, nullptr, 0));
-      (void)hipGraphDestroy(g);
       d.graph_B = d.B;
       d.graph_Smax = d.Smax;
       d.graph_penalty = d.penalty;
@@ -497,7 +510,10 @@ int Engine::gpt_decode(int nsteps, hipStream_t s) {
       d.graph_top_p = d.top_p;
       d.graph_temperature = d.temperature;
     }
-    for (int i = 0; i < nsteps; ++i) ITTS_HIP_CHECK(hipGraphLaunch(d.graph, s));
+    int left = nsteps;
+    if (d.graphK)
+      for (; left >= GK; left -= GK) ITTS_HIP_CHECK(hipGraphLaunch(d.graphK, s));
+    for (; left > 0; --left) ITTS_HIP_CHECK(hipGraphLaunch(d.graph, s));
     return OK;
   }
   for (int i = 0; i < nsteps; ++i) ITTS_TRY(decode_step_launch(s));
