@@ -1001,24 +1001,52 @@ __global__ __launch_bounds__(1024) void sampler2_kernel(SamplerArgs a) {
   const int k_pre = a.step[b], unf_pre = a.unfinished[b];  // requested with the logits: nothing to wait for after the argmax
   float best = -INFINITY;
   int bi = 0x7fffffff;
-#pragma unroll 4
-  for (int i = tid; i < a.V; i += 1024) {
-    float v = lg[i];
-    if (a.penalty != 1.f && seen[i]) v = v < 0.f ? v * a.penalty : v / a.penalty;
-    if (a.suppress_stop && i == a.stop) v = -INFINITY;
+  auto take = [&](float v, int i) {
     if (v > best || (v == best && i < bi)) {
       best = v;
       bi = i;
     }
-  }
+  };
+  auto score = [&](float v, int i) {
+    if (a.penalty != 1.f && seen[i]) v = v < 0.f ? v * a.penalty : v / a.penalty;
+    if (a.suppress_stop && i == a.stop) v = -INFINITY;
+    return v;
+  };
+  // 8 consecutive logits per thread as two 16-byte loads (rows are dword aligned), the tail scalar
+  const int nvec = a.V >> 3;
+  for (int c = tid; c < nvec; c += 1024) {
+    const float4 q0 = *reinterpret_cast<const float4*>(lg + c * 8), q1 = *reinterpret_cast<const float4*>(lg + c * 8 + 4);
+    const float q[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    const float ov = __shfl_xor(best, o, 64);
-    const int oi = __shfl_xor(bi, o, 64);
+    for (int e = 0; e < 8; ++e) take(score(q[e], c * 8 + e), c * 8 + e);
+  }
+  for (int i = nvec * 8 + tid; i < a.V; i += 1024) take(score(lg[i], i), i);
+  // wave argmax without the LDS crossbar: DPP inside the 16-lane rows, v_permlane16/32_swap across them
+  auto merge = [&](float ov, int oi) {
     if (ov > best || (ov == best && oi < bi)) {
       best = ov;
       bi = oi;
     }
+  };
+#define SAMPLER_DPP(CTRL)                                                                                  \
+  merge(__int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(best), CTRL, 0xf, 0xf, true)),       \
+        __builtin_amdgcn_update_dpp(0, bi, CTRL, 0xf, 0xf, true))
+  SAMPLER_DPP(0xB1);
+  SAMPLER_DPP(0x4E);
+  SAMPLER_DPP(0x141);
+  SAMPLER_DPP(0x140);
+#undef SAMPLER_DPP
+  {
+    const u32x2 v16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(best), __float_as_uint(best), false, false);
+    const u32x2 i16 = __builtin_amdgcn_permlane16_swap((unsigned)bi, (unsigned)bi, false, false);
+    best = __uint_as_float(v16[0]);
+    bi = (int)i16[0];
+    merge(__uint_as_float(v16[1]), (int)i16[1]);
+    const u32x2 v32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(best), __float_as_uint(best), false, false);
+    const u32x2 i32 = __builtin_amdgcn_permlane32_swap((unsigned)bi, (unsigned)bi, false, false);
+    best = __uint_as_float(v32[0]);
+    bi = (int)i32[0];
+    merge(__uint_as_float(v32[1]), (int)i32[1]);
   }
   if (lane == 0) {
     sv[wave] = best;
