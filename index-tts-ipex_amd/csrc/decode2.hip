@@ -282,17 +282,20 @@ __device__ __forceinline__ float dot2(uint32_t a, uint32_t b, float c) {
 #define GEMV_STAMP(i)
 #endif
 
-template <int NB, int RPW, int NCH, int PRO, bool XBF, bool YBF, bool W8 = false>
-__global__ __launch_bounds__(256) void gemv_bf16_kernel(GemvArgs g) {
+// WAVES per workgroup: 4, or 5 so that the per-layer projections (3840 / 1280 / 5120 rows) split into exactly 256
+// workgroups - one per CU, every CU streaming the same share of the weights and loading x once.
+template <int NB, int RPW, int NCH, int PRO, bool XBF, bool YBF, bool W8 = false, int WAVES = 4>
+__global__ __launch_bounds__(WAVES * 64) void gemv_bf16_kernel(GemvArgs g) {
+  constexpr int NTHR = WAVES * 64;
   GEMV_STAMP(0)
   constexpr int EPC = XBF ? 8 : 4;                                  // elements per 16-byte chunk
-  constexpr int KCH = (NCH * 512 + 256 * EPC - 1) / (256 * EPC);    // chunks per row per thread
+  constexpr int KCH = (NCH * 512 + NTHR * EPC - 1) / (NTHR * EPC);  // chunks per row per thread
   extern __shared__ __attribute__((aligned(16))) uint32_t sxb[];    // [NB][K/2] bf16 pairs
-  __shared__ float red[2][4][2 * NB];
+  __shared__ float red[2][WAVES][2 * NB];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int K = g.K;
   const float invK = 1.f / (float)K;  // off the critical path: the LayerNorm chain multiplies instead of dividing
-  const int n0 = (blockIdx.x * 4 + wave) * RPW;
+  const int n0 = (blockIdx.x * WAVES + wave) * RPW;
   // ---- 1. activations (+ LayerNorm parameters) first, weights second; all unconditional ----
   u32x4 xr[NB][KCH];  // XBF: 8 bf16; else 4 floats
   f32x4 pm[PRO == 3 ? NB : 1][KCH], pl[PRO == 3 ? NB : 1][KCH], po[PRO == 3 ? NB : 1][KCH][ATTN_NSPLIT][2];
@@ -301,7 +304,7 @@ __global__ __launch_bounds__(256) void gemv_bf16_kernel(GemvArgs g) {
   bool xok[KCH];
 #pragma unroll
   for (int j = 0; j < KCH; ++j) {
-    const int i = (tid + j * 256) * EPC;
+    const int i = (tid + j * NTHR) * EPC;
     xok[j] = i < K;
     const int ic = xok[j] ? i : K - EPC;
 #pragma unroll
@@ -404,8 +407,12 @@ __global__ __launch_bounds__(256) void gemv_bf16_kernel(GemvArgs g) {
       __syncthreads();
 #pragma unroll
       for (int b = 0; b < NB; ++b) {
-        const float S = red[pass][0][2 * b] + red[pass][1][2 * b] + red[pass][2][2 * b] + red[pass][3][2 * b];
-        const float Q = red[pass][0][2 * b + 1] + red[pass][1][2 * b + 1] + red[pass][2][2 * b + 1] + red[pass][3][2 * b + 1];
+        float S = 0.f, Q = 0.f;
+#pragma unroll
+        for (int ww = 0; ww < WAVES; ++ww) {
+          S += red[pass][ww][2 * b];
+          Q += red[pass][ww][2 * b + 1];
+        }
         const float md = S * invK;
         const float mean = (pass == 0 ? pivot[b] : 0.f) + md;
         const float rstd = __builtin_amdgcn_rsqf(fmaxf(Q * invK - md * md, 0.f) + g.ln_eps);
@@ -424,7 +431,7 @@ __global__ __launch_bounds__(256) void gemv_bf16_kernel(GemvArgs g) {
 #pragma unroll
       for (int j = 0; j < KCH; ++j)
         if (xok[j]) {
-          const int i = (tid + j * 256) * 4;
+          const int i = (tid + j * NTHR) * 4;
           uint2 p;
           p.x = pack_bf16(xv[b][j][0], xv[b][j][1]);
           p.y = pack_bf16(xv[b][j][2], xv[b][j][3]);
@@ -461,7 +468,7 @@ __global__ __launch_bounds__(256) void gemv_bf16_kernel(GemvArgs g) {
     for (int b = 0; b < NB; ++b)
 #pragma unroll
       for (int j = 0; j < KCH; ++j)
-        if (xok[j]) *reinterpret_cast<u32x4*>(sxb + (b * K + (tid + j * 256) * 8) / 2) = xr[b][j];
+        if (xok[j]) *reinterpret_cast<u32x4*>(sxb + (b * K + (tid + j * NTHR) * 8) / 2) = xr[b][j];
   }
   __syncthreads();
   GEMV_STAMP(3)
@@ -1271,20 +1278,22 @@ int gemv2(const GemvArgs& g, int tw, hipStream_t s) {
 #undef GO
 }
 
+static bool g_gemv_w5 = false;  // ITTS_GEMV_W5=1: 5-wave workgroups, exactly 256 of them per projection
 static int g_gemv_mode = 0;  // ITTS_GEMV_MODE: 0 / 2 block-cooperative kernel (default, measured fastest), 1 wave-autonomous kernel
                              // everywhere, 3 wave-autonomous only for the short bf16-x projection
 
-template <int NB, int RPW, int NCH, int PRO, bool XBF, bool YBF>
+template <int NB, int RPW, int NCH, int PRO, bool XBF, bool YBF, int WAVES = 4>
 static int launch_gemv_bf16(const GemvArgs& g, hipStream_t s) {
-  dim3 grid((g.N + 4 * RPW - 1) / (4 * RPW)), blk(256);
+  dim3 grid((g.N + WAVES * RPW - 1) / (WAVES * RPW)), blk(WAVES * 64);
   // measured (bench, 2 rows): all block-cooperative 0.602 ms per step, all wave-autonomous 0.615 ms - the per-wave copies
   // of x cost more address-pipeline time (16 clk per KiB wave-load per CU) than the LDS hand-over and its barriers
-  const bool block = PRO == 3 || g_gemv_mode == 2 || g_gemv_mode == 0 || (g_gemv_mode == 3 && !(XBF && NCH < 4));
+  const bool block = WAVES != 4 || PRO == 3 || g_gemv_mode == 2 || g_gemv_mode == 0 || (g_gemv_mode == 3 && !(XBF && NCH < 4));
+  const size_t lds = (size_t)NB * g.K * 2;
   if (block) {
     if (g.W8)
-      hipLaunchKernelGGL((gemv_bf16_kernel<NB, RPW, NCH, PRO, XBF, YBF, true>), grid, blk, (size_t)NB * g.K * 2, s, g);
+      hipLaunchKernelGGL((gemv_bf16_kernel<NB, RPW, NCH, PRO, XBF, YBF, true, WAVES>), grid, blk, lds, s, g);
     else
-      hipLaunchKernelGGL((gemv_bf16_kernel<NB, RPW, NCH, PRO, XBF, YBF>), grid, blk, (size_t)NB * g.K * 2, s, g);
+      hipLaunchKernelGGL((gemv_bf16_kernel<NB, RPW, NCH, PRO, XBF, YBF, false, WAVES>), grid, blk, lds, s, g);
   } else {
     if (g.W8)
       hipLaunchKernelGGL((gemv_wave_kernel<NB, RPW, NCH, PRO, XBF, YBF, true>), grid, blk, 0, s, g);
@@ -1306,6 +1315,13 @@ static int dispatch_gemv_bf16(const GemvArgs& g, hipStream_t s) {
     if (g.prologue == 0 && g.x_bf16 && !g.y_bf16) return launch_gemv_bf16<NB, 1, 1, 0, true, false>(g, s);
     if (g.prologue == 3 && g.x_bf16 && !g.y_bf16) return launch_gemv_bf16<NB, 1, 1, 3, true, false>(g, s);
   } else if (nch <= 3) {
+    // one workgroup per CU: 5 waves x RPW rows x 256 workgroups = N (3840 -> RPW 3, 5120 -> RPW 4, 1280 -> RPW 1)
+    if (g_gemv_w5 && NB <= 2) {
+      if (g.prologue == 1 && !g.x_bf16 && g.y_bf16 && g.N == 5120) return launch_gemv_bf16<NB, 4, 3, 1, false, true, 5>(g, s);
+      if (g.prologue == 1 && !g.x_bf16 && !g.y_bf16 && g.N == 3840) return launch_gemv_bf16<NB, 3, 3, 1, false, false, 5>(g, s);
+      if (g.prologue == 0 && g.x_bf16 && !g.y_bf16 && g.N == 1280) return launch_gemv_bf16<NB, 1, 3, 0, true, false, 5>(g, s);
+      if (g.prologue == 3 && g.x_bf16 && !g.y_bf16 && g.N == 1280) return launch_gemv_bf16<NB, 1, 3, 3, true, false, 5>(g, s);
+    }
     if (g.prologue == 1 && !g.x_bf16 && g.y_bf16) return launch_gemv_bf16<NB, 2, 3, 1, false, true>(g, s);    // fc
     if (g.prologue == 1 && !g.x_bf16 && !g.y_bf16) return launch_gemv_bf16<NB, 2, 3, 1, false, false>(g, s);  // qkv
     if (g.prologue == 2 && !g.x_bf16 && !g.y_bf16) return launch_gemv_bf16<NB, 4, 3, 2, false, false>(g, s);  // head
@@ -1314,6 +1330,8 @@ static int dispatch_gemv_bf16(const GemvArgs& g, hipStream_t s) {
   } else if (nch <= 4) {
     if (g.prologue == 0 && g.x_bf16 && !g.y_bf16) return launch_gemv_bf16<NB, 2, 4, 0, true, false>(g, s);
   } else if (nch <= 10) {
+    if (g_gemv_w5 && NB <= 2 && g.prologue == 0 && g.x_bf16 && !g.y_bf16 && g.N == 1280 && nch == 10)
+      return launch_gemv_bf16<NB, 1, 10, 0, true, false, 5>(g, s);
     if (g.prologue == 0 && g.x_bf16 && !g.y_bf16) return launch_gemv_bf16<NB, 2, 10, 0, true, false>(g, s);   // proj2
   }
   set_error("gemv_bf16: no instantiation for this shape");
@@ -1333,6 +1351,7 @@ int gemv_bf16(const GemvArgs& g, hipStream_t s) {
   static const bool once = [] {
     const char* m = getenv("ITTS_GEMV_MODE");
     g_gemv_mode = m ? atoi(m) : 0;
+    g_gemv_w5 = getenv("ITTS_GEMV_W5") != nullptr;
     return true;
   }();
   (void)once;
