@@ -16,6 +16,7 @@ typedef float f32x4v __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int DH = 64, QT = 64, KT = 64, KROW = 72;  // LDS row stride in bf16 (144 B: conflict-free for ds_read_b128)
+// DQK = query/key width: 64 (GPT, perceiver) or 128 (conformer rel-pos attention as [q+u | q+v] . [k | p]); values are 64 wide
 
 template <int CTRL>
 __device__ __forceinline__ float dpp_mov(float v) {
@@ -36,8 +37,10 @@ __device__ __forceinline__ float row16_sum(float v) {
   return v;
 }
 
+template <int DQK>
 __global__ __launch_bounds__(256) void attn_mfma_kernel(AttnArgs a) {
-  __shared__ __attribute__((aligned(16))) bf16_t sK[KT][KROW];      // [key][dim]
+  constexpr int KS = DQK / 32, KQROW = DQK + 8;  // k-steps of S = Q K^T; LDS row stride of the key tile
+  __shared__ __attribute__((aligned(16))) bf16_t sK[KT][KQROW];     // [key][dim]
   __shared__ __attribute__((aligned(16))) bf16_t sVt[DH][KROW];     // [dim][key]
   __shared__ __attribute__((aligned(16))) bf16_t sP[4][16][KROW];   // per wave [query][key]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -51,10 +54,10 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(AttnArgs a) {
   const int fr = lane & 15, fg = lane >> 4;
   // Q fragments of this wave's 16 rows (A operand: row fr, dims 32*ks + 8*fg .. +8), pre-scaled later in fp32
   const int qrow = min(q0 + wave * 16 + fr, a.Sq - 1);
-  bf16x8 qf[2];
+  bf16x8 qf[KS];
 #pragma unroll
-  for (int ks = 0; ks < 2; ++ks)
-    qf[ks] = *reinterpret_cast<const bf16x8*>(q + ((size_t)b * a.Sq + qrow) * a.ldq + h * DH + ks * 32 + fg * 8);
+  for (int ks = 0; ks < KS; ++ks)
+    qf[ks] = *reinterpret_cast<const bf16x8*>(q + ((size_t)b * a.Sq + qrow) * a.ldq + h * DQK + ks * 32 + fg * 8);
   f32x4v oacc[4];
 #pragma unroll
   for (int t = 0; t < 4; ++t) oacc[t] = f32x4v{0.f, 0.f, 0.f, 0.f};
@@ -67,16 +70,18 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(AttnArgs a) {
   int kend = a.Sk;
   if (a.causal) kend = min(a.Sk, q0 + QT + shift);
   // loader mapping: thread -> key row tid/4 (64 keys), 16 dims (tid&3)*16 .. +16 (two 16-byte loads)
-  const int lk = tid >> 2, ld = (tid & 3) * 16;
+  const int lk = tid >> 2, ld = (tid & 3) * 16, ldk4 = (tid & 3) * (DQK / 4);
   for (int j0 = 0; j0 < kend; j0 += KT) {
     const int jr = min(j0 + lk, a.Sk - 1);
-    const bf16_t* kp = k + ((size_t)b * a.Sk + jr) * a.ldk + h * DH + ld;
+    const bf16_t* kp = k + ((size_t)b * a.Sk + jr) * a.ldk + h * DQK + ldk4;
     const bf16_t* vp = v + ((size_t)b * a.Sk + jr) * a.ldv + h * DH + ld;
-    const u32x4 k0 = *reinterpret_cast<const u32x4*>(kp), k1 = *reinterpret_cast<const u32x4*>(kp + 8);
+    u32x4 kq[DQK / 32];
+#pragma unroll
+    for (int i = 0; i < DQK / 32; ++i) kq[i] = *reinterpret_cast<const u32x4*>(kp + 8 * i);
     const u32x4 v0 = *reinterpret_cast<const u32x4*>(vp), v1 = *reinterpret_cast<const u32x4*>(vp + 8);
     __syncthreads();  // previous tile fully consumed
-    *reinterpret_cast<u32x4*>(&sK[lk][ld]) = k0;
-    *reinterpret_cast<u32x4*>(&sK[lk][ld + 8]) = k1;
+#pragma unroll
+    for (int i = 0; i < DQK / 32; ++i) *reinterpret_cast<u32x4*>(&sK[lk][ldk4 + 8 * i]) = kq[i];
     {
       const unsigned short* e0 = reinterpret_cast<const unsigned short*>(&v0);
       const unsigned short* e1 = reinterpret_cast<const unsigned short*>(&v1);
@@ -93,7 +98,7 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(AttnArgs a) {
     for (int nt = 0; nt < 4; ++nt) {
       s[nt] = f32x4v{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
+      for (int ks = 0; ks < KS; ++ks) {
         const bf16x8 kf = *reinterpret_cast<const bf16x8*>(&sK[nt * 16 + fr][ks * 32 + fg * 8]);
         s[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[ks], kf, s[nt], 0, 0, 0);
       }
@@ -160,7 +165,7 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(AttnArgs a) {
 }  // namespace
 
 bool attention_mfma_supported(const AttnArgs& a, int dt) {
-  return dt == BF16 && a.dqk == 64 && a.dv == 64 && a.ldq % 8 == 0 && a.ldk % 8 == 0 && a.ldv % 8 == 0 &&
+  return dt == BF16 && (a.dqk == 64 || a.dqk == 128) && a.dv == 64 && a.ldq % 8 == 0 && a.ldk % 8 == 0 && a.ldv % 8 == 0 &&
          !(((uintptr_t)a.q | (uintptr_t)a.k | (uintptr_t)a.v) & 15) && a.Sq >= 16;
 }
 
@@ -168,7 +173,10 @@ int attention_mfma(const AttnArgs& a, int dt, hipStream_t s) {
   ITTS_REQUIRE(a.q && a.k && a.v && a.o, "attention_mfma: null pointer");
   ITTS_REQUIRE(attention_mfma_supported(a, dt), "attention_mfma: unsupported shape/dtype");
   dim3 grid((a.Sq + QT - 1) / QT, a.H, a.B);
-  hipLaunchKernelGGL(attn_mfma_kernel, grid, dim3(256), 0, s, a);
+  if (a.dqk == 128)
+    hipLaunchKernelGGL(attn_mfma_kernel<128>, grid, dim3(256), 0, s, a);
+  else
+    hipLaunchKernelGGL(attn_mfma_kernel<64>, grid, dim3(256), 0, s, a);
   ITTS_HIP_CHECK(hipGetLastError());
   return OK;
 }

@@ -371,3 +371,23 @@ def test_conv_lds_amp_shapes(lib, case):
     assert relerr(out.float().transpose(1, 2), ref.float()) < 1.5e-2
     gen = run_gemm(lib, A, W, (B, T, Cc), L.BF16, L.BF16, L.BF16, 1, **kw)  # vector kernel, fp32 accumulate
     assert relerr(out.float(), gen.float()) < 1.5e-2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", [(1, 8, 255, 255), (2, 3, 70, 133)])
+def test_attention_mfma_wide_keys(lib, case):
+    """conformer rel-pos attention shape: 128-wide queries / keys ([q+u | q+v] . [k | p]), 64-wide values, non-causal."""
+    B, H, Sq, Sk = case
+    q = rnd("aw.q", (B, Sq, H * 128)).to(torch.bfloat16)
+    k = rnd("aw.k", (B, Sk, H * 128)).to(torch.bfloat16)
+    v = rnd("aw.v", (B, Sk, H * 64)).to(torch.bfloat16)
+    qf = q.double().view(B, Sq, H, 128).transpose(1, 2)
+    kf = k.double().view(B, Sk, H, 128).transpose(1, 2)
+    vf = v.double().view(B, Sk, H, 64).transpose(1, 2)
+    ref = (torch.softmax(qf @ kf.transpose(-1, -2) * 0.125, -1) @ vf).transpose(1, 2).reshape(B, Sq, H * 64)
+    qd, kd, vd = q.to(DEV), k.to(DEV), v.to(DEV)
+    o = torch.full((B, Sq, H * 64), float("nan"), dtype=torch.bfloat16, device=DEV)
+    L.check(lib.itts_attention(o.data_ptr(), qd.data_ptr(), kd.data_ptr(), vd.data_ptr(), B, H, Sq, Sk, 128, 64, H * 128,
+                               H * 128, H * 64, H * 64, 0.125, 0, None, L.BF16, stream()))
+    torch.cuda.synchronize()
+    assert relerr(o.float(), ref.float()) < 1.5e-2
