@@ -301,7 +301,7 @@ int Engine::finalize() {
   if (any_prefix(*this, "spk.")) {
     ec = EcapaW();
     const int* chs = c.ec_channels;
-    ec.b0 = r.lin("spk.b0", wdt, chs[0], c.bv_num_mels, c.ec_kernels[0], true, 1, true);
+    ec.b0 = r.lin("spk.b0", wdt, chs[0], (c.bv_num_mels + 7) / 8 * 8, c.ec_kernels[0], true, 1, true);  // mel bins padded to x8
     for (int i = 1; i <= 3; ++i) {
       const std::string p = "spk.b" + std::to_string(i) + ".";
       EcapaW::Blk b;

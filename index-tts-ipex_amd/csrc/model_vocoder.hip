@@ -68,7 +68,15 @@ int Engine::ecapa(const void* mel, int B, int F, float* spk_out, hipStream_t s) 
   };
   auto body = [&]() -> int {
     void* x0 = alloc((size_t)M * C * es);
-    ITTS_TRY(tdnn(x0, C, mel, c.bv_num_mels, ec.b0, c.ec_dils[0]));
+    const int melp = (c.bv_num_mels + 7) / 8 * 8;  // 100 mel bins -> 104 zero-padded channels: 16-byte rows for the MFMA conv
+    const void* mel_in = mel;
+    if (melp != c.bv_num_mels) {
+      void* mp = alloc((size_t)M * melp * es);
+      if (!dry) ITTS_HIP_CHECK(hipMemsetAsync(mp, 0, (size_t)M * melp * es, s));
+      K(copy_rows(mp, melp, mel, c.bv_num_mels, M, c.bv_num_mels, adt, s));
+      mel_in = mp;
+    }
+    ITTS_TRY(tdnn(x0, C, mel_in, melp, ec.b0, c.ec_dils[0]));
     void* cat = alloc((size_t)M * CC * es);  // outputs of the three SE-Res2Net blocks, concatenated
     void* y1 = alloc((size_t)M * C * es);
     void* y2 = alloc((size_t)M * C * es);

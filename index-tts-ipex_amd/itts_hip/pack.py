@@ -204,7 +204,12 @@ def pack_bigvgan(sd: Dict[str, np.ndarray], cfg) -> Packed:
     s = "speaker_encoder."
 
     def tdnn(dst, src):
-        P[dst + ".weight"] = ("w", conv_w(sd[src + ".conv.conv.weight"]))
+        w = np.asarray(sd[src + ".conv.conv.weight"], dtype=np.float32)
+        if w.shape[1] % 8:  # the first block reads the 100-bin mel: input channels zero-padded to a multiple of 8 so the
+            wp = np.zeros((w.shape[0], (w.shape[1] + 7) // 8 * 8, w.shape[2]), dtype=np.float32)  # conv runs on MFMA
+            wp[:, : w.shape[1]] = w
+            w = wp
+        P[dst + ".weight"] = ("w", conv_w(w))
         P[dst + ".bias"] = ("f", sd[src + ".conv.conv.bias"])
         sc, sh = bn_fold(sd, src + ".norm.norm")
         P[dst + ".bn_scale"], P[dst + ".bn_shift"] = ("f", sc), ("f", sh)
