@@ -1381,9 +1381,12 @@ int decode_attn2(void* ctx, int to, const float* qkv, void* kc, void* vc, const 
   dim3 grid(H, B);
   const int bt = ctx_tiled ? (B + 15) / 16 : 0;
   const bool many = (long)B * H >= 512;
+#ifndef ATTN_NIT_MANY
+#define ATTN_NIT_MANY 8
+#endif
 #define LAUNCH(TCT, TOT)                                                                                                  \
   if (many)                                                                                                               \
-    hipLaunchKernelGGL((decode_attn2_kernel<TCT, TOT, 3, 256>), grid, dim3(256), 0, s, (TOT*)ctx, qkv, (TCT*)kc, (TCT*)vc, len, \
+    hipLaunchKernelGGL((decode_attn2_kernel<TCT, TOT, ATTN_NIT_MANY, 256>), grid, dim3(256), 0, s, (TOT*)ctx, qkv, (TCT*)kc, (TCT*)vc, len, \
                        kv_start, prefix_dev, H, Smax, scale, bt);                                                         \
   else                                                                                                                    \
     hipLaunchKernelGGL((decode_attn2_kernel<TCT, TOT, 3, 1024>), grid, dim3(1024), 0, s, (TOT*)ctx, qkv, (TCT*)kc, (TCT*)vc,    \
