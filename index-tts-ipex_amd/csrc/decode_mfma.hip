@@ -130,6 +130,7 @@ __global__ __launch_bounds__(256) void ln_rows_bf16_kernel(bf16_t* __restrict__ 
   const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   float v[MAXE];
   float* xr = x + (size_t)row * D;
+  const float pv0 = xr[0];
 #pragma unroll
   for (int i = 0; i < MAXE; ++i) v[i] = tid + i * 256 < D ? xr[tid + i * 256] : 0.f;
   if (nsplit > 0) {
@@ -155,23 +156,29 @@ __global__ __launch_bounds__(256) void ln_rows_bf16_kernel(bf16_t* __restrict__ 
     }
   }
   for (int pass = 0; pass < passes; ++pass) {
-    float s = 0.f;
-#pragma unroll
-    for (int i = 0; i < MAXE; ++i) s += v[i];
-    s = wave_sum(s);
-    if (lane == 0) red[pass][0][wave] = s;
-    __syncthreads();
-    const float mean = (red[pass][0][0] + red[pass][0][1] + red[pass][0][2] + red[pass][0][3]) / D;
-    float q = 0.f;
+    // one reduction round per pass: moments about a pivot (the row's first element as it was before this kernel's
+    // residual add - any value near the mean will do - for the raw residual stream, zero for a LayerNorm output), sum
+    // and sum of squares travel together - one barrier instead of two
+    const float pv = pass == 0 ? pv0 : 0.f;
+    float s = 0.f, q = 0.f;
 #pragma unroll
     for (int i = 0; i < MAXE; ++i) {
-      const float d = tid + i * 256 < D ? v[i] - mean : 0.f;
+      const float d = tid + i * 256 < D ? v[i] - pv : 0.f;
+      s += d;
       q = fmaf(d, d, q);
     }
+    s = wave_sum(s);
     q = wave_sum(q);
-    if (lane == 0) red[pass][1][wave] = q;
+    if (lane == 0) {
+      red[pass][0][wave] = s;
+      red[pass][1][wave] = q;
+    }
     __syncthreads();
-    const float rstd = rsqrtf((red[pass][1][0] + red[pass][1][1] + red[pass][1][2] + red[pass][1][3]) / D + eps);
+    const float invD = 1.f / D;
+    const float md = (red[pass][0][0] + red[pass][0][1] + red[pass][0][2] + red[pass][0][3]) * invD;
+    const float mean = pv + md;
+    const float var = fmaxf((red[pass][1][0] + red[pass][1][1] + red[pass][1][2] + red[pass][1][3]) * invD - md * md, 0.f);
+    const float rstd = rsqrtf(var + eps);
 #pragma unroll
     for (int i = 0; i < MAXE; ++i) {
       const int c = tid + i * 256;
