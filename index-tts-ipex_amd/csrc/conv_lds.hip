@@ -38,9 +38,15 @@ __global__ __launch_bounds__(256) void conv_lds_kernel(GemmArgs g, int tiles_per
 
   // ---- resident input tile: rows t0 - pad_left + i, zero outside [0, T); pad columns zero ----
   {
+    // (row, 16-byte column) of vector v = tid + 256 * step, stepped without a division per vector
     const int vpr = CP >> 3, cv = C >> 3, nvec = HR * vpr;
-    for (int v = tid; v < nvec; v += 256) {
-      const int i = v / vpr, q = v - i * vpr;
+    const int di = 256 / vpr, dq = 256 - di * vpr;
+    int i = tid / vpr, q = tid - i * vpr;
+    for (int v = tid; v < nvec; v += 256, i += di, q += dq) {
+      if (q >= vpr) {
+        q -= vpr;
+        ++i;
+      }
       const int ts = t0 - g.pad_left + i;
       u32x4 val = u32x4{0u, 0u, 0u, 0u};
       if (q < cv && ts >= 0 && ts < T) val = *reinterpret_cast<const u32x4*>(A + (size_t)ts * g.lda + q * 8);
@@ -145,8 +151,14 @@ __global__ __launch_bounds__(256) void conv_lds_kernel(GemmArgs g, int tiles_per
   const bf16_t* __restrict__ ADD = g.ADD ? (const bf16_t*)g.ADD + (size_t)b * T * g.ldadd : nullptr;
   const float* bias = g.bias ? g.bias + (size_t)b * g.bias_bstride : nullptr;
   const bool plain = g.act == ACT_NONE && g.act2 == ACT_NONE && !g.scale && !g.shift && (!bias || ((uintptr_t)bias & 15) == 0);
-  for (int v = tid; v < BM * nv; v += 256) {
-    const int m = v / nv, q = v - m * nv, t = t0 + m;
+  const int dm = 256 / nv, dq2 = 256 - dm * nv;
+  int m = tid / nv, q = tid - m * nv;
+  for (int v = tid; v < BM * nv; v += 256, m += dm, q += dq2) {
+    if (q >= nv) {
+      q -= nv;
+      ++m;
+    }
+    const int t = t0 + m;
     if (t >= T) continue;
     const int n = q * 8;
     float o[8];

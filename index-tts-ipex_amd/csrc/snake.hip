@@ -141,8 +141,13 @@ __global__ __launch_bounds__(256) void snake_aa_lds_kernel(T* __restrict__ y, co
   const int tid = threadIdx.x;
   {
     const int vpr = CT / VEC, nvec = (TT + 12) * vpr;
-    for (int v = tid; v < nvec; v += 256) {
-      const int i = v / vpr, q = v - i * vpr;
+    const int di = 256 / vpr, dq = 256 - di * vpr;  // (row, vector) stepped without a division per vector
+    int i = tid / vpr, q = tid - i * vpr;
+    for (int v = tid; v < nvec; v += 256, i += di, q += dq) {
+      if (q >= vpr) {
+        q -= vpr;
+        ++i;
+      }
       int t = t0 - 6 + i;
       t = t < 0 ? 0 : (t >= Tn ? Tn - 1 : t);  // replicate padding resolved at load time
       *reinterpret_cast<uint4*>(sx + (size_t)i * CT + q * VEC) = *reinterpret_cast<const uint4*>(xb + (size_t)t * C + q * VEC);
@@ -250,8 +255,13 @@ __global__ __launch_bounds__(256) void snake_aa_lds_kernel(T* __restrict__ y, co
   __syncthreads();
   {
     const int vpr = CT / VEC, rows = min(TT, Tn - t0), nvec = rows * vpr;
-    for (int v = tid; v < nvec; v += 256) {
-      const int i = v / vpr, q = v - i * vpr;
+    const int di = 256 / vpr, dq = 256 - di * vpr;
+    int i = tid / vpr, q = tid - i * vpr;
+    for (int v = tid; v < nvec; v += 256, i += di, q += dq) {
+      if (q >= vpr) {
+        q -= vpr;
+        ++i;
+      }
       *reinterpret_cast<uint4*>(yb + (size_t)(t0 + i) * C + q * VEC) = *reinterpret_cast<const uint4*>(so + (size_t)i * CT + q * VEC);
     }
   }
