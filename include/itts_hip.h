@@ -6,7 +6,7 @@
  * `itts_last_error()` returns the message (thread-local).  One engine per host thread (the reference's
  * web UI shares one engine between threads without a lock, webui.py:441-452: callers must serialise).
  *
- * dtype codes: 0 = f32, 1 = bf16.  Activations are channels-last ([B, T, C]) everywhere.
+ * dtype codes: 0 = f32, 1 = bf16, 5 = f16 (itts_snake_aa_fwd only).  Activations are channels-last ([B, T, C]) everywhere.
  */
 #ifndef ITTS_HIP_H
 #define ITTS_HIP_H
@@ -21,6 +21,7 @@ typedef struct itts_engine itts_engine;
 
 #define ITTS_F32 0
 #define ITTS_BF16 1
+#define ITTS_F16 5 /* IEEE half: accepted by itts_snake_aa_fwd only (the reference op dispatches float/half/bf16) */
 
 const char* itts_last_error(void);
 int itts_abi_version(void);
@@ -122,6 +123,13 @@ int itts_ecapa(itts_engine* e, const void* mel_bfc, int B, int F, float* spk_out
  * 1 <= top_k <= 64, 0 < top_p <= 1, temperature > 0. */
 int itts_gpt_set_sampling(itts_engine* e, int do_sample, int top_k, float top_p, float temperature, const float* uniforms_host,
                           int64_t n_uniforms);
+
+/* Forced tokens for the first n steps of every following generation (n = 0 clears): ids_host int32 [B, n] (B = 1 is
+ * broadcast to every row; -1 = leave that step free).  This is the `input_tokens` continuation of
+ * UnifiedVoice.inference_speech (gpt/model.py:672-686: given mel tokens are appended to the prompt and generation
+ * continues after them) and the teacher forcing the parity tests use; the forced tokens are returned by
+ * itts_gpt_fetch as steps 0..n-1 (the reference strips them with trunc_index, model.py:687,704). */
+int itts_gpt_set_forced(itts_engine* e, const int32_t* ids_host, int B, int n);
 
 /* G1/G3/G4 step 0: prepare_gpt_inputs (model.py:591-654) + prefill + first greedy token.
  * cond fp32 [latents, D]; text ids host int32 [B, L] (may hold start/stop padding ids, stripped per row).

@@ -180,6 +180,10 @@ int itts_gpt_set_sampling(itts_engine* e, int do_sample, int top_k, float top_p,
   ENG(e);
   return e->e.gpt_set_sampling(do_sample, top_k, top_p, temperature, uniforms_host, (long)n_uniforms);
 }
+int itts_gpt_set_forced(itts_engine* e, const int32_t* ids_host, int B, int n) {
+  ENG(e);
+  return e->e.gpt_set_forced(ids_host, B, n);
+}
 int itts_gpt_decode(itts_engine* e, int nsteps, itts_stream s) {
   ENG(e);
   return e->e.gpt_decode(nsteps, (hipStream_t)s);

@@ -969,6 +969,10 @@ __global__ __launch_bounds__(NT) void decode_attn2_kernel(TO* __restrict__ ctx, 
 __device__ __forceinline__ void sampler_commit(const SamplerArgs& a, int b, int choice, int* si, int k, int unf) {
   si[1] = -1;
   if (k < a.max_gen) {  // graph replays past the end are no-ops
+    if (a.forced) {
+      const int f = a.forced[(size_t)b * a.max_gen + k];
+      choice = f >= 0 ? f : choice;
+    }
     const int tok = unf ? choice : a.stop;
     a.ids[(size_t)b * a.max_gen + k] = tok;
     a.cur_tok[b] = tok;

@@ -121,12 +121,14 @@ struct DecodeState {
   float penalty = 1.f;
   int suppress_stop = 0;
   hipGraphExec_t graph = nullptr, graphK = nullptr;  // one decode step / ITTS_GRAPH_STEPS (8) steps per launch
-  int graph_B = 0, graph_Smax = 0, graph_suppress = 0;
+  int graph_B = 0, graph_Smax = 0, graph_suppress = 0, graph_max_gen = 0;
   // multinomial sampling (itts_gpt_set_sampling): parameters baked into the captured step, uniforms [max_gen][B]
   int do_sample = 0, top_k = 0, graph_sample = 0, graph_top_k = 0;
   float top_p = 1.f, temperature = 1.f, graph_top_p = 1.f, graph_temperature = 1.f;
   float* uniforms = nullptr;
   size_t uniforms_cap = 0;
+  int* forced = nullptr;  // [cap_B][cap_gen] forced token per (row, step) or -1; allocated with ids
+  int use_forced = 0, graph_forced = 0;
   float graph_penalty = 0.f;
   bool active = false;
 };
@@ -181,6 +183,9 @@ struct Engine {
   int gpt_decode(int nsteps, hipStream_t s);
   int gpt_set_sampling(int do_sample, int top_k, float top_p, float temperature, const float* uniforms_host, long n);
   std::vector<float> sample_uniforms;  // host copy, uploaded by the next prefill
+  int gpt_set_forced(const int32_t* ids_host, int B, int n);
+  std::vector<int32_t> forced_host;  // [forced_B][forced_n], uploaded by the next prefill
+  int forced_B = 0, forced_n = 0;
   int gpt_status(int* steps, int* n_unf, hipStream_t s);
   int gpt_fetch(int32_t* codes, float* logits, hipStream_t s);
   int gpt_latent(const float* cond, const int32_t* text_ids, int L, const int32_t* codes, int T, void* latent_out,

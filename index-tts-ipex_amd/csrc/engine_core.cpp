@@ -10,7 +10,7 @@ Engine::~Engine() {
   if (ws) (void)hipFree(ws);
   DecodeState& d = ds;
   void* ptrs[] = {d.kc, d.vc, d.h, d.qkv, d.ctx, d.act, d.hn, d.logits, d.len, d.prefix_dev,
-                  d.kv_start, d.cur_tok, d.ids, d.unfinished, d.seen};
+                  d.kv_start, d.cur_tok, d.ids, d.unfinished, d.seen, d.partial, d.attn_o, d.attn_ml, d.uniforms, d.forced};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (d.graph) (void)hipGraphExecDestroy(d.graph);

@@ -7,12 +7,13 @@
 namespace itts {
 
 typedef __bf16 bf16_t;
+typedef _Float16 f16_t;
 
-enum DType : int { F32 = 0, BF16 = 1, I32 = 2, I64 = 3, FP8 = 4 };  // FP8 = OCP e4m3fn bytes (weights only)
+enum DType : int { F32 = 0, BF16 = 1, I32 = 2, I64 = 3, FP8 = 4, F16 = 5 };  // F16: operator-level boundary only (itts_snake_aa_fwd)  // FP8 = OCP e4m3fn bytes (weights only)
 enum Act : int { ACT_NONE = 0, ACT_RELU = 1, ACT_SILU = 2, ACT_GELU_NEW = 3, ACT_GELU_ERF = 4, ACT_TANH = 5, ACT_SIGMOID = 6 };
 enum PadMode : int { PAD_ZERO = 0, PAD_REFLECT = 1 };
 
-inline size_t dtype_size(int dt) { return dt == F32 ? 4 : dt == BF16 ? 2 : dt == I32 ? 4 : dt == FP8 ? 1 : 8; }
+inline size_t dtype_size(int dt) { return dt == F32 ? 4 : (dt == BF16 || dt == F16) ? 2 : dt == I32 ? 4 : dt == FP8 ? 1 : 8; }
 
 // status codes of the C ABI (0 ok, negative = error; message via itts_last_error())
 enum Status : int { OK = 0, E_INVALID = -1, E_HIP = -2, E_NOMEM = -3, E_STATE = -4, E_MISSING = -5 };
@@ -48,8 +49,10 @@ const char* last_error();
 // ---- device helpers ----
 __device__ __forceinline__ float ldf(const float* p) { return *p; }
 __device__ __forceinline__ float ldf(const bf16_t* p) { return (float)(*p); }
+__device__ __forceinline__ float ldf(const f16_t* p) { return (float)(*p); }
 __device__ __forceinline__ void stf(float* p, float v) { *p = v; }
 __device__ __forceinline__ void stf(bf16_t* p, float v) { *p = (bf16_t)v; }
+__device__ __forceinline__ void stf(f16_t* p, float v) { *p = (f16_t)v; }
 
 __device__ __forceinline__ float act_apply(int act, float x) {
   switch (act) {

@@ -60,6 +60,9 @@ struct SamplerArgs {
   int do_sample = 0, top_k = 0, B = 0;
   float top_p = 1.f, temperature = 1.f;
   const float* uniforms = nullptr;  // [max_gen][B]
+  // forced tokens (HF `input_tokens` continuation, model.py:672-686 / teacher forcing): forced[b][k] >= 0 replaces the
+  // choice of step k for row b; nullptr = nothing forced (the table is only read when it exists)
+  const int* forced = nullptr;  // [B][max_gen]
 };
 
 int gemv(const GemvArgs& g, int tw, hipStream_t s);

@@ -145,6 +145,7 @@ int Engine::ensure_decode_state(int B, int Smax, int max_gen, hipStream_t s) {
     ITTS_TRY(dev_alloc((void**)&d.cur_tok, (size_t)cb * 4));
     ITTS_TRY(dev_alloc((void**)&d.unfinished, (size_t)cb * 4));
     ITTS_TRY(dev_alloc((void**)&d.ids, (size_t)cb * cg * 4));
+    ITTS_TRY(dev_alloc((void**)&d.forced, (size_t)cb * cg * 4));
     ITTS_TRY(dev_alloc((void**)&d.seen, (size_t)cb * V));
     ITTS_TRY(dev_alloc((void**)&d.len, (size_t)cb * 4));
     if (!d.prefix_dev) ITTS_TRY(dev_alloc((void**)&d.prefix_dev, 64));
@@ -191,6 +192,16 @@ int Engine::gpt_prefill(const float* cond_dev, const int32_t* text_ids, int B, i
       ds.uniforms_cap = need_u;
     }
     ITTS_HIP_CHECK(hipMemcpyAsync(ds.uniforms, sample_uniforms.data(), need_u * 4, hipMemcpyHostToDevice, s));
+    ITTS_HIP_CHECK(hipStreamSynchronize(s));
+  }
+  ds.use_forced = forced_n > 0;
+  if (ds.use_forced) {
+    ITTS_REQUIRE(forced_B == B || forced_B == 1, "gpt_prefill: forced tokens were set for a different batch size");
+    ITTS_REQUIRE(forced_n <= max_gen, "gpt_prefill: more forced tokens than max_gen");
+    std::vector<int32_t> tab((size_t)B * max_gen, -1);
+    for (int b = 0; b < B; ++b)
+      for (int k = 0; k < forced_n; ++k) tab[(size_t)b * max_gen + k] = forced_host[(size_t)(forced_B == 1 ? 0 : b) * forced_n + k];
+    ITTS_HIP_CHECK(hipMemcpyAsync(ds.forced, tab.data(), tab.size() * 4, hipMemcpyHostToDevice, s));
     ITTS_HIP_CHECK(hipStreamSynchronize(s));
   }
   // host: row descriptors (prepare_gpt_inputs, model.py:615-639)
@@ -313,6 +324,7 @@ int Engine::head_and_sample(hipStream_t s) {
   sa.top_p = ds.top_p;
   sa.temperature = ds.temperature;
   sa.uniforms = ds.uniforms;
+  sa.forced = ds.use_forced ? ds.forced : nullptr;
   sa.B = B;
   return sampler2_step(sa, B, s);
 }
@@ -463,6 +475,23 @@ int Engine::gpt_set_sampling(int do_sample, int top_k, float top_p, float temper
   return OK;
 }
 
+// Tokens that replace the sampler's choice for the first n steps of every following generation (n = 0 clears):
+// the HF `input_tokens` continuation of inference_speech (model.py:672-686) and teacher forcing for parity tests.
+int Engine::gpt_set_forced(const int32_t* ids_host, int B, int n) {
+  if (n <= 0 || !ids_host) {
+    forced_host.clear();
+    forced_B = forced_n = 0;
+    return OK;
+  }
+  ITTS_REQUIRE(B >= 1, "gpt_set_forced: B < 1");
+  for (long i = 0; i < (long)B * n; ++i)
+    ITTS_REQUIRE(ids_host[i] >= -1 && ids_host[i] < cfg.number_mel_codes, "gpt_set_forced: token id out of range");
+  forced_host.assign(ids_host, ids_host + (size_t)B * n);
+  forced_B = B;
+  forced_n = n;
+  return OK;
+}
+
 int Engine::gpt_decode(int nsteps, hipStream_t s) {
   if (!ds.active) {
     set_error("gpt_decode: call itts_gpt_prefill first");
@@ -471,9 +500,11 @@ int Engine::gpt_decode(int nsteps, hipStream_t s) {
   ITTS_REQUIRE(nsteps >= 0, "gpt_decode: nsteps < 0");
   if (use_graph && s != nullptr) {
     DecodeState& d = ds;
-    const bool stale = !d.graph || d.graph_B != d.B || d.graph_Smax != d.Smax || d.graph_penalty != d.penalty ||
-                       d.graph_suppress != d.suppress_stop || d.graph_sample != d.do_sample || d.graph_top_k != d.top_k ||
-                       d.graph_top_p != d.top_p || d.graph_temperature != d.temperature;
+    // everything SamplerArgs carries by value is baked into the captured nodes: max_gen is the ids row stride and the
+    // `k < max_gen` bound, so a per-request max_mel_tokens must re-capture (same B / Smax notwithstanding)
+    const bool stale = !d.graph || d.graph_B != d.B || d.graph_Smax != d.Smax || d.graph_max_gen != d.max_gen ||
+                       d.graph_forced != d.use_forced || d.graph_penalty != d.penalty || d.graph_suppress != d.suppress_stop || d.graph_sample != d.do_sample ||
+                       d.graph_top_k != d.top_k || d.graph_top_p != d.top_p || d.graph_temperature != d.temperature;
     // two executables: one step, and GK steps back to back (one launch per GK tokens: the gap between consecutive graph
     // launches is paid once per GK steps; every step reads its lengths from device memory, so any mix is valid)
     static const int GK = [] {
@@ -503,6 +534,8 @@ int Engine::gpt_decode(int nsteps, hipStream_t s) {
       }
       d.graph_B = d.B;
       d.graph_Smax = d.Smax;
+      d.graph_max_gen = d.max_gen;
+      d.graph_forced = d.use_forced;
       d.graph_penalty = d.penalty;
       d.graph_suppress = d.suppress_stop;
       d.graph_sample = d.do_sample;

@@ -354,6 +354,9 @@ int snake_aa_bct(void* y, const void* x, const float* log_alpha, const float* lo
   else if (dt == BF16)
     hipLaunchKernelGGL(snake_aa_bct_kernel<bf16_t>, grid, dim3(256), 0, s, (bf16_t*)y, (const bf16_t*)x, log_alpha,
                        log_beta, up12, down12, C, T);
+  else if (dt == F16)  // the reference dispatches float / half / bf16 (type_shim.h:20-43); fp32 arithmetic inside, as its kernel
+    hipLaunchKernelGGL(snake_aa_bct_kernel<f16_t>, grid, dim3(256), 0, s, (f16_t*)y, (const f16_t*)x, log_alpha,
+                       log_beta, up12, down12, C, T);
   else {
     set_error("snake_aa_bct: unsupported dtype");
     return E_INVALID;
@@ -379,6 +382,9 @@ int snake_aa(void* y, const void* x, const float* log_alpha, const float* log_be
                        log_beta, up12, down12, B, T, C, nchunk);
   else if (dt == BF16)
     hipLaunchKernelGGL(snake_aa_kernel<bf16_t>, dim3(blocks), dim3(256), 0, s, (bf16_t*)y, (const bf16_t*)x, log_alpha,
+                       log_beta, up12, down12, B, T, C, nchunk);
+  else if (dt == F16)
+    hipLaunchKernelGGL(snake_aa_kernel<f16_t>, dim3(blocks), dim3(256), 0, s, (f16_t*)y, (const f16_t*)x, log_alpha,
                        log_beta, up12, down12, B, T, C, nchunk);
   else {
     set_error("snake_aa: unsupported dtype");

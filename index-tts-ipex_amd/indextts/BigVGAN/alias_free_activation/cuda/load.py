@@ -31,7 +31,9 @@ class _AntiAliasActivation:
             dt = L.F32
         elif inputs.dtype == torch.bfloat16:
             dt = L.BF16
-        else:  # the reference dispatches float/half/bfloat16 (type_shim.h:20-43); half is not built here
+        elif inputs.dtype == torch.float16:  # the reference's GPU default is .half() (infer.py:44,52)
+            dt = L.F16
+        else:  # the reference dispatches float/half/bfloat16 and AT_ERRORs on anything else (type_shim.h:20-43)
             raise RuntimeError(f"anti_alias_activation_cuda.forward: unsupported dtype {inputs.dtype}")
         B, Cc, T = inputs.shape
         dev = inputs.device

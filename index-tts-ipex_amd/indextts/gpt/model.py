@@ -37,17 +37,20 @@ class UnifiedVoice:
 
     @torch.no_grad()
     def get_conditioning(self, speech_conditioning_input, cond_mel_lengths=None):
-        """[1, n_mels, F] -> [1, 32, D]; cached per prompt tensor (the reference recomputes it twice per sentence,
+        """[1, n_mels, F] -> [1, 32, D]; cached per prompt tensor object (the reference recomputes it twice per sentence,
         model.py:540,670).  Only full-length single prompts are supported (what infer.py passes)."""
         x = speech_conditioning_input
         if x.ndim == 2:
             x = x.unsqueeze(0)
         if cond_mel_lengths is not None and int(torch.as_tensor(cond_mel_lengths).reshape(-1)[0]) != x.shape[-1]:
             raise NotImplementedError("partial-length conditioning prompts")
-        key = (x.data_ptr(), tuple(x.shape), x._version)
-        if key != self._cond_key:
-            self._cond, self._cond_key = self._eng.conditioning(x), key
-        return self._cond
+        # cached per prompt TENSOR OBJECT: the key holds a reference to it, so its storage cannot be freed and handed to a
+        # different same-shape prompt while the entry is alive (an address-only key would alias two speakers)
+        with self._eng.lock:
+            hit = self._cond_key is not None and self._cond_key[0] is x and self._cond_key[1] == x._version
+            if not hit:
+                self._cond, self._cond_key = self._eng.conditioning(x), (x, x._version)
+            return self._cond
 
     @torch.no_grad()
     def inference_speech(self, speech_conditioning_mel, text_inputs, cond_mel_lengths=None, input_tokens=None,
@@ -70,7 +73,8 @@ class UnifiedVoice:
             ids = ids[None]
         max_gen = self.max_mel_tokens - 1 if max_generate_length is None else int(max_generate_length)
         rep = float(hf_generate_kwargs.get("repetition_penalty", 1.0) or 1.0)
-        codes = self._eng.generate(cond, ids, max_gen, repetition_penalty=rep, **sample_kw)
+        with self._eng.lock:
+            codes = self._eng.generate(cond, ids, max_gen, repetition_penalty=rep, **sample_kw)
         return torch.from_numpy(codes).to(self._eng.device)
 
     @torch.no_grad()
@@ -83,6 +87,7 @@ class UnifiedVoice:
         cond = self.get_conditioning(speech_conditioning_latent, cond_mel_lengths)
         t = text_inputs.detach().cpu().numpy().reshape(-1)
         c = mel_codes.detach().cpu().numpy().reshape(-1)
-        return self._eng.latent(cond, t, c)
+        with self._eng.lock:
+            return self._eng.latent(cond, t, c)
 
     __call__ = forward

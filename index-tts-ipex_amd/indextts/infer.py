@@ -107,59 +107,154 @@ class IndexTTS:
             return [np.asarray(self.tokenizer.convert_tokens_to_ids(s), dtype=np.int32) for s in sents]
         return [np.asarray(s, dtype=np.int32).reshape(-1) for s in text]  # pre-tokenised: list of id lists
 
-    def _synthesize(self, prompt_mel, text, output_path, max_text_tokens_per_sentence, bucket, verbose, kw):
-        start = time.perf_counter()
-        do_sample = kw.pop("do_sample", True)
-        num_beams = kw.pop("num_beams", 3)
-        top_p, top_k, temperature = kw.pop("top_p", 0.8), kw.pop("top_k", 30), kw.pop("temperature", 1.0)
-        kw.pop("length_penalty", None)
-        rep = kw.pop("repetition_penalty", 10.0)
-        max_mel_tokens = kw.pop("max_mel_tokens", 600)
-        sample_kw = infer_core.sampling_kwargs(do_sample, num_beams, top_k, top_p, temperature)
-        sents = self._sentences_to_ids(text, max_text_tokens_per_sentence)
-        self._set_gr_progress(0.1, "text processing...")
-        cond = self.gpt.get_conditioning(prompt_mel)
-        spk = self.engine.ecapa(prompt_mel.transpose(1, 2))
-        t_gen = t_fwd = t_voc = 0.0
-        buckets = infer_core.bucket_sentences(sents, bucket)
-        wav_by_idx = {}
-        for bi, bk in enumerate(buckets):
-            t0 = time.perf_counter()
-            ids = infer_core.pad_tokens_cat([x["sent"] for x in bk], self.cfg.gpt.stop_text_token)
-            codes = self.engine.generate(cond, ids, max_mel_tokens, repetition_penalty=rep, **sample_kw)
-            t_gen += time.perf_counter() - t0
-            if (codes[:, -1] != self.stop_mel_token).any():
-                warnings.warn(f"WARN: generation stopped due to exceeding `max_mel_tokens` ({max_mel_tokens}).", RuntimeWarning)
-            # latent pass for the whole bucket in one launch sequence (left-padded, masked: each sentence gets exactly its
-            # batch-1 latent), then the vocoder per sentence (code lengths differ after remove_long_silence)
-            clean = []
-            for r in range(len(bk)):
-                c, n = infer_core.remove_long_silence(codes[r:r + 1], self.stop_mel_token)
-                clean.append(c[0, : int(n[0])])
-            t0 = time.perf_counter()
-            lats = self.engine.latent_batch(cond, [item["sent"] for item in bk], clean)
-            t_fwd += time.perf_counter() - t0
-            t0 = time.perf_counter()
-            for lat, item in zip(lats, bk):
-                wav = self.engine.bigvgan(lat, spk)
-                wav_by_idx[item["idx"]] = torch.clamp(32767 * wav.squeeze(1), -32767.0, 32767.0).cpu()
-            t_voc += time.perf_counter() - t0
-            self._set_gr_progress(0.2 + 0.7 * (bi + 1) / len(buckets), f"synthesis {bi + 1}/{len(buckets)}")
-        wav = torch.cat([wav_by_idx[i] for i in range(len(sents))], dim=1)
+    def _gen_kwargs(self, kw):
+        """The generation kwargs `infer` / `infer_fast` pop (infer.py:116-124), with the reference's defaults."""
+        kw = dict(kw)
+        g = dict(do_sample=kw.pop("do_sample", True), top_p=kw.pop("top_p", 0.8), top_k=kw.pop("top_k", 30),
+                 temperature=kw.pop("temperature", 1.0), length_penalty=kw.pop("length_penalty", 0.0),
+                 num_beams=kw.pop("num_beams", 3), repetition_penalty=kw.pop("repetition_penalty", 10.0),
+                 max_mel_tokens=kw.pop("max_mel_tokens", 600))
+        g["typical_sampling"] = kw.pop("typical_sampling", False)
+        g["typical_mass"] = kw.pop("typical_mass", 0.9)
+        return g
+
+    def _generate_rows(self, cond, sents, g):
+        """Mel codes for a list of sentences: decode batches of at most `engine max_batch` rows (HF pads / stops per
+        batch, so a group is exactly one `inference_speech` call of the reference)."""
+        sample_kw = infer_core.sampling_kwargs(g["do_sample"], g["num_beams"], g["top_k"], g["top_p"], g["temperature"],
+                                               g["typical_sampling"], g["typical_mass"])
+        cap = max(1, self.engine.ccfg.max_batch // max(1, sample_kw.get("num_beams", 1)))
+        rows = []
+        for lo in range(0, len(sents), cap):
+            grp = sents[lo:lo + cap]
+            ids = infer_core.pad_tokens_cat(grp, self.cfg.gpt.stop_text_token)
+            codes = self.engine.generate(cond, ids, g["max_mel_tokens"], repetition_penalty=g["repetition_penalty"], **sample_kw)
+            rows.extend(codes[r] for r in range(len(grp)))
+        return rows
+
+    def _clean_and_latents(self, cond, sents, code_rows, max_mel_tokens):
+        """remove_long_silence per sentence (infer.py:190 / :463), then the latent pass (batch-1 semantics per sentence,
+        stacked as masked left-padded rows in one launch sequence)."""
+        if any(r[-1] != self.stop_mel_token for r in code_rows):
+            warnings.warn(f"WARN: generation stopped due to exceeding `max_mel_tokens` ({max_mel_tokens}). "
+                          "Consider reducing `max_text_tokens_per_sentence` or increasing `max_mel_tokens`.", RuntimeWarning)
+        clean = []
+        for r in code_rows:
+            c, n = infer_core.remove_long_silence(np.asarray(r)[None], self.stop_mel_token)
+            clean.append(c[0, : int(n[0])])
+        lats = []
+        cap = self.engine.ccfg.max_batch
+        for lo in range(0, len(sents), cap):
+            lats.extend(self.engine.latent_batch(cond, sents[lo:lo + cap], clean[lo:lo + cap]))
+        return lats
+
+    def _finish(self, wavs, output_path, start, timers, verbose, tag=""):
+        wav = torch.cat(wavs, dim=1)
         total = time.perf_counter() - start
         wav_len = wav.shape[-1] / 24000
         if verbose:
-            print(f">> gpt_gen_time: {t_gen:.2f}s  gpt_forward_time: {t_fwd:.2f}s  bigvgan_time: {t_voc:.2f}s")
-        print(f">> Total inference time: {total:.2f} seconds; generated audio: {wav_len:.2f} s; RTF: {total / max(wav_len, 1e-9):.4f}")
+            print(f">> gpt_gen_time: {timers[0]:.2f}s  gpt_forward_time: {timers[1]:.2f}s  bigvgan_time: {timers[2]:.2f}s")
+        print(f">> Total {tag}inference time: {total:.2f} seconds; generated audio: {wav_len:.2f} s; RTF: {total / max(wav_len, 1e-9):.4f}")
         wav16 = wav.type(torch.int16)
         if output_path:
             from scipy.io import wavfile
 
+            if os.path.isfile(output_path):
+                os.remove(output_path)
             if os.path.dirname(output_path):
                 os.makedirs(os.path.dirname(output_path), exist_ok=True)
             wavfile.write(output_path, 24000, wav16.numpy().T)
             return output_path
         return (24000, wav16.numpy().T)
+
+    def _to_int16_range(self, wav):
+        return torch.clamp(32767 * wav.squeeze(1), -32767.0, 32767.0).cpu()  # infer.py:208-212
+
+    def _synthesize(self, prompt_mel, text, output_path, max_text_tokens_per_sentence, bucket, verbose, kw, fast):
+        """`infer` (fast=False: vocoder per sentence, infer.py:134-212) and `infer_fast` (fast=True: length-sorted buckets
+        for the AR decode, vocoder over time-concatenated chunks of 2 latents, infer.py:385-498)."""
+        start = time.perf_counter()
+        g = self._gen_kwargs(kw)
+        sents = self._sentences_to_ids(text, max_text_tokens_per_sentence)
+        if not sents:
+            # the reference ends in torch.cat([]) -> RuntimeError; same class, clearer message
+            raise RuntimeError("IndexTTS: the text produced no sentences (empty input)")
+        self._set_gr_progress(0.1, "text processing...")
+        with self.engine.lock:
+            cond = self.gpt.get_conditioning(prompt_mel)
+            spk = self.engine.ecapa(prompt_mel.transpose(1, 2))
+            t_gen = t_fwd = t_voc = 0.0
+            t0 = time.perf_counter()
+            code_rows = [None] * len(sents)
+            if fast:
+                for bk in infer_core.bucket_sentences(sents, bucket):
+                    for item, row in zip(bk, self._generate_rows(cond, [x["sent"] for x in bk], g)):
+                        code_rows[item["idx"]] = row
+            else:
+                code_rows = self._generate_rows(cond, sents, g)
+            t_gen = time.perf_counter() - t0
+            self._set_gr_progress(0.5, "gpt inference latents...")
+            t0 = time.perf_counter()
+            lats = self._clean_and_latents(cond, sents, code_rows, g["max_mel_tokens"])  # original sentence order
+            t_fwd = time.perf_counter() - t0
+            self._set_gr_progress(0.7, "bigvgan decode...")
+            t0 = time.perf_counter()
+            wavs = []
+            if fast:
+                chunk = 2  # infer.py:480: BigVGAN runs over pairs of sentences concatenated along time
+                for lo in range(0, len(lats), chunk):
+                    wavs.append(self._to_int16_range(self.engine.bigvgan(torch.cat(lats[lo:lo + chunk], dim=1), spk)))
+            else:
+                for lat in lats:
+                    wavs.append(self._to_int16_range(self.engine.bigvgan(lat, spk)))
+            t_voc = time.perf_counter() - t0
+        self._set_gr_progress(0.9, "save audio...")
+        return self._finish(wavs, output_path, start, (t_gen, t_fwd, t_voc), verbose, "fast " if fast else "")
+
+    @torch.no_grad()
+    def infer_batch(self, prompt_mels, texts, output_paths=None, max_text_tokens_per_sentence=120, verbose=False,
+                    **generation_kwargs):
+        """Several utterances in one call (the multi-utterance / data-parallel entry point): the sentences of
+        all utterances that share a prompt are decoded together in length-sorted batches of up to `max_batch` rows,
+        the latent pass is stacked, the vocoder runs per sentence.  Under torch.distributed (one process per GPU) each
+        rank should pass its own shard - see itts_hip.dp.run_sharded.  prompt_mels: one tensor for all utterances or a
+        list with one per utterance.  Returns a list of (24000, int16 [n, 1]) or of written paths."""
+        n = len(texts)
+        prompts = [prompt_mels] * n if isinstance(prompt_mels, torch.Tensor) else list(prompt_mels)
+        assert len(prompts) == n and (output_paths is None or len(output_paths) == n)
+        g = self._gen_kwargs(generation_kwargs)
+        start = time.perf_counter()
+        utt_sents = [self._sentences_to_ids(t, max_text_tokens_per_sentence) for t in texts]
+        results = [None] * n
+        groups = {}
+        for u, p in enumerate(prompts):
+            groups.setdefault(id(p), []).append(u)
+        with self.engine.lock:
+            for us in groups.values():
+                mel = self._prompt(prompts[us[0]], None)
+                cond = self.gpt.get_conditioning(mel)
+                spk = self.engine.ecapa(mel.transpose(1, 2))
+                flat = [(u, k, s) for u in us for k, s in enumerate(utt_sents[u])]
+                if not flat:
+                    continue
+                order = sorted(range(len(flat)), key=lambda i: (len(flat[i][2]), i))  # length-sorted decode batches
+                rows = self._generate_rows(cond, [flat[i][2] for i in order], g)
+                code_rows = [None] * len(flat)
+                for i, r in zip(order, rows):
+                    code_rows[i] = r
+                lats = self._clean_and_latents(cond, [f[2] for f in flat], code_rows, g["max_mel_tokens"])
+                wav_parts = {u: [] for u in us}
+                for (u, k, _), wav in zip(flat, self.engine.bigvgan_grouped(lats, spk)):  # equal lengths share a launch
+                    wav_parts[u].append(self._to_int16_range(wav))
+                for u in us:
+                    if wav_parts[u]:
+                        results[u] = wav_parts[u]
+        out = []
+        for u in range(n):
+            if results[u] is None:
+                raise RuntimeError(f"IndexTTS.infer_batch: utterance {u} produced no sentences (empty input)")
+            out.append(self._finish(results[u], output_paths[u] if output_paths else None, start, (0, 0, 0), False, "batch "))
+        return out
 
     def _prompt(self, prompt_mel, audio_prompt):
         if prompt_mel is None and audio_prompt is None:
@@ -173,9 +268,9 @@ class IndexTTS:
     def infer(self, prompt_mel=None, text=None, output_path=None, max_text_tokens_per_sentence=120, verbose=False,
               audio_prompt=None, **generation_kwargs):
         return self._synthesize(self._prompt(prompt_mel, audio_prompt), text, output_path, max_text_tokens_per_sentence,
-                                10 ** 9, verbose, generation_kwargs)
+                                10 ** 9, verbose, generation_kwargs, fast=False)
 
     def infer_fast(self, prompt_mel=None, text=None, output_path=None, max_text_tokens_per_sentence=120, verbose=False,
                    sentences_bucket_max_size=4, audio_prompt=None, **generation_kwargs):
         return self._synthesize(self._prompt(prompt_mel, audio_prompt), text, output_path, max_text_tokens_per_sentence,
-                                sentences_bucket_max_size, verbose, generation_kwargs)
+                                sentences_bucket_max_size, verbose, generation_kwargs, fast=True)

@@ -7,7 +7,11 @@ import torch
 
 
 def read_state_dict(path: str, key: str = None):
-    ck = torch.load(path, map_location="cpu", weights_only=False)
+    # tensors only, as the reference's torch.load default (weights_only=True on current torch): a downloaded checkpoint
+    # must not be able to run pickled code.  ITTS_UNSAFE_PICKLE=1 is the explicit opt-in for legacy pickles.
+    import os
+
+    ck = torch.load(path, map_location="cpu", weights_only=os.environ.get("ITTS_UNSAFE_PICKLE") != "1")
     if key is not None and key in ck:
         ck = ck[key]
     elif "model" in ck and isinstance(ck["model"], dict):

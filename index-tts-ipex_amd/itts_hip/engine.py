@@ -4,6 +4,7 @@ as tensor-in / tensor-out calls.  torch is used for device memory and streams on
 from __future__ import annotations
 
 import ctypes as C
+import threading
 from typing import Dict, List, Optional, Tuple
 
 import numpy as np
@@ -101,6 +102,9 @@ class Engine:
         L.check(self.lib.itts_engine_create(C.byref(self.ccfg), C.byref(h)), "engine_create")
         self.h = h
         self.arenas: List[WeightArena] = []
+        # one engine = one decode state + captured graphs: callers on several host threads (the reference web UI starts a
+        # worker thread per request into one IndexTTS, webui.py:441-452) serialise on this lock in the drop-in classes
+        self.lock = threading.RLock()
         self.up_total = int(np.prod(cfg["bigvgan"]["upsample_rates"]))
 
     def __del__(self):
@@ -195,6 +199,14 @@ class Engine:
         u = np.ascontiguousarray(uniforms, dtype=np.float32)
         L.check(self.lib.itts_gpt_set_sampling(self.h, 1, int(top_k), float(top_p), float(temperature),
                                                u.ctypes.data_as(C.c_void_p), u.size), "gpt_set_sampling")
+
+    def set_forced(self, ids: Optional[np.ndarray]):
+        """Forced tokens [B or 1, n] (int, -1 = free) for the first n steps of the following generations; None clears."""
+        if ids is None or np.asarray(ids).size == 0:
+            L.check(self.lib.itts_gpt_set_forced(self.h, None, 0, 0), "gpt_set_forced")
+            return
+        a = np.ascontiguousarray(np.atleast_2d(ids), dtype=np.int32)
+        L.check(self.lib.itts_gpt_set_forced(self.h, a.ctypes.data_as(C.c_void_p), a.shape[0], a.shape[1]), "gpt_set_forced")
 
     def decode(self, nsteps: int):
         L.check(self.lib.itts_gpt_decode(self.h, nsteps, self._s()), "gpt_decode")
@@ -294,6 +306,23 @@ class Engine:
         self._exit()
         lat.record_stream(self.stream)
         spk.record_stream(self.stream)
+        return out
+
+    def bigvgan_grouped(self, lats: List[torch.Tensor], spk: torch.Tensor) -> List[torch.Tensor]:
+        """Vocoder over several sentences: latents [1, T_i, D] of EQUAL length share one batched launch sequence (rows of
+        a batch are independent, so each result equals its batch-1 run); ragged lengths cannot be padded - the convs
+        would see conv_pre(0) = bias instead of zero "same" padding - and go in groups of their own."""
+        groups: Dict[int, List[int]] = {}
+        for i, l in enumerate(lats):
+            groups.setdefault(int(l.shape[1]), []).append(i)
+        out: List[Optional[torch.Tensor]] = [None] * len(lats)
+        cap = max(1, int(self.ccfg.max_batch))
+        for T, idx in groups.items():
+            for lo in range(0, len(idx), cap):
+                sel = idx[lo:lo + cap]
+                wav = self.bigvgan(torch.cat([lats[i] for i in sel], 0), spk.view(1, -1).expand(len(sel), -1).contiguous())
+                for j, i in enumerate(sel):
+                    out[i] = wav[j:j + 1]
         return out
 
     def dvae_decode(self, codes: np.ndarray) -> torch.Tensor:

@@ -73,7 +73,7 @@ def pad_tokens_cat(tokens: Sequence[np.ndarray], stop_text_token: int) -> np.nda
     return out
 
 
-def sampling_kwargs(do_sample, num_beams, top_k, top_p, temperature) -> dict:
+def sampling_kwargs(do_sample, num_beams, top_k, top_p, temperature, typical_sampling=False, typical_mass=0.9) -> dict:
     """HF `generate` kwargs (infer.py:116-124) -> Engine.generate keywords.  Beam search is not implemented: num_beams > 1
     warns and decodes with one beam.  top_k outside [1, 64] (HF: 0 / None disable the warper) is clamped to 64 with a
     warning - the device sampler keeps at most 64 candidates.  The seed is drawn from torch's global RNG so that
@@ -84,6 +84,8 @@ def sampling_kwargs(do_sample, num_beams, top_k, top_p, temperature) -> dict:
 
     if num_beams is not None and int(num_beams) != 1:
         warnings.warn("itts_hip: beam search is not implemented; decoding with num_beams=1", RuntimeWarning)
+    if typical_sampling:
+        warnings.warn("itts_hip: typical sampling is not implemented; using top-k / top-p", RuntimeWarning)
     if not do_sample:
         return {}
     k = int(top_k) if top_k else 0

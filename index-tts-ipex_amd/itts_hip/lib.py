@@ -15,6 +15,7 @@ LIB_PATH = os.environ.get("ITTS_HIP_LIB", os.path.join(CSRC, "libitts_hip.so"))
 
 F32, BF16 = 0, 1
 FP8 = 4  # OCP e4m3fn bytes (GPT decode weights, BASELINE config 5)
+F16 = 5  # IEEE half, operator-level boundary only (itts_snake_aa_fwd)
 ACT_NONE, ACT_RELU, ACT_SILU, ACT_GELU_NEW, ACT_GELU_ERF, ACT_TANH, ACT_SIGMOID = range(7)  # csrc/itts_common.h enum Act
 ACT = {"none": 0, "relu": 1, "silu": 2, "gelu_new": 3, "gelu_erf": 4, "tanh": 5, "sigmoid": 6}
 
@@ -73,6 +74,7 @@ _PROTOS = {
     "itts_ecapa": (i32, [vp, vp, i32, i32, vp, vp]),
     "itts_gpt_prefill": (i32, [vp, vp, vp, i32, i32, i32, f32, i32, vp]),
     "itts_gpt_set_sampling": (i32, [vp, i32, i32, f32, f32, vp, i64]),
+    "itts_gpt_set_forced": (i32, [vp, vp, i32, i32]),
     "itts_gpt_decode": (i32, [vp, i32, vp]),
     "itts_gpt_status": (i32, [vp, C.POINTER(i32), C.POINTER(i32), vp]),
     "itts_gpt_fetch": (i32, [vp, vp, vp, vp]),

@@ -87,7 +87,7 @@ def build_ref_dvae(cfg, seed):
     return m
 
 
-def ref_greedy(gpt, cond_mel, text, max_gen, rep=10.0, n_trace=None):
+def ref_greedy(gpt, cond_mel, text, max_gen, rep=10.0, n_trace=None, suppress_eos=False, trace_steps=None):
     """Hand-rolled HF-4.36.2-style greedy_search over the reference's own GPT2InferenceModel.forward
     (the installed transformers-5.x `generate` skips the prefill, so it is not used)."""
     from transformers import RepetitionPenaltyLogitsProcessor
@@ -103,15 +103,25 @@ def ref_greedy(gpt, cond_mel, text, max_gen, rep=10.0, n_trace=None):
     b = ids.shape[0]
     unfinished = torch.ones(b, dtype=torch.long)
     logits_trace = []
+    margins = []
+    step = 0
     while True:
         inp = ids if past is None else ids[:, -1:]
         out = gpt.inference_model(input_ids=inp, past_key_values=past, attention_mask=mask, use_cache=True,
                                   return_dict=True)
         past = out.past_key_values
         logits = out.logits[:, -1, :]
-        if n_trace is None or len(logits_trace) < n_trace:
+        if trace_steps is not None:
+            if step in trace_steps:
+                logits_trace.append(logits.clone())
+        elif n_trace is None or len(logits_trace) < n_trace:
             logits_trace.append(logits.clone())
         scores = proc(ids, logits.clone())
+        if suppress_eos:  # fixed-length decode: the engine's suppress_stop masks the stop score after the penalty
+            scores[:, stop] = -float("inf")
+        top2 = torch.topk(scores, 2, dim=-1).values
+        margins.append((top2[:, 0] - top2[:, 1]).clone())
+        step += 1
         nxt = torch.argmax(scores, dim=-1)
         nxt = nxt * unfinished + stop * (1 - unfinished)
         ids = torch.cat([ids, nxt[:, None]], dim=-1)
@@ -119,6 +129,7 @@ def ref_greedy(gpt, cond_mel, text, max_gen, rep=10.0, n_trace=None):
         unfinished = unfinished * (nxt != stop).long()
         if unfinished.max() == 0 or ids.shape[-1] >= s + 1 + max_gen:
             break
+    ref_greedy.last_margins = torch.stack(margins, 1)
     return ids[:, s + 1:], torch.stack(logits_trace, 1), conds, emb, mask[:, : s + 1]
 
 
@@ -284,8 +295,96 @@ def full_fixtures():
     save("full_bigvgan", latent=lat_in, wav=wav, spk=spk)
 
 
+@torch.no_grad()
+def long_fixtures():
+    """IndexTTS-1.5 sizes at the BENCHMARK shapes (L = 105, T = 480 latent, 64 vocoder frames): greedy ids for 660 steps
+    with the stop token masked (the sequence passes S = 768, beyond every register window of the decode attention),
+    top-8 logits every 32 steps and at S = 400 / 520 / 780, latent for T = 480, a 64-frame waveform."""
+    cfg = icfg.indextts_1_5()
+    g = cfg.gpt
+    print("[long] building reference UnifiedVoice ...")
+    gpt = build_ref_gpt(cfg, 1234)
+    mel = torch.from_numpy(synth.prompt_mel(511, seed=7))
+    L, NS = 105, 660
+    text = torch.from_numpy(synth.text_ids(L, 11, g.number_text_tokens)).view(1, L).int()
+    s0 = 32 + L + 2 + 1
+    steps = sorted(set(range(0, NS, 32)) | {400 - s0, 520 - s0, 780 - s0, NS - 1})
+    t0 = time.time()
+    codes, logits, conds, emb, _ = ref_greedy(gpt, mel, text, max_gen=NS, suppress_eos=True, trace_steps=set(steps))
+    print(f"  {NS}-step greedy in {time.time() - t0:.1f}s")
+    assert codes.shape == (1, NS) and logits.shape[1] == len(steps)
+    top = torch.topk(logits[0], 8, dim=-1)
+    T = 480
+    lat_codes = codes[:, :T].clone()
+    t0 = time.time()
+    latent = gpt(mel, text, torch.tensor([L]), lat_codes, torch.tensor([T * 1024]), cond_mel_lengths=torch.tensor([511]),
+                 return_latent=True, clip_inputs=False)
+    print(f"  latent T={T} in {time.time() - t0:.1f}s")
+    rows = [0, 1, 239, 478, 479]
+    save("long_decode_b1", text=text, codes=codes, trace_steps=np.asarray(steps), top_idx=top.indices, top_val=top.values,
+         margins=ref_greedy.last_margins[0], latent_sample=latent[0, :, :16], latent_rows=latent[0, rows], latent_row_idx=np.asarray(rows),
+         latent_rms=latent.pow(2).mean().sqrt())
+    del gpt
+    print("[long] BigVGAN 64 frames ...")
+    bv = build_ref_bigvgan(cfg, 1234)
+    lat_in = rnd("bigvgan.latent.long", (1, 64, cfg.bigvgan.gpt_dim), std=1.0)
+    t0 = time.time()
+    wav, _ = bv(lat_in, mel.transpose(1, 2))
+    print(f"  vocoder in {time.time() - t0:.1f}s")
+    save("long_bigvgan", wav=wav[0, 0])  # the latent regenerates from the PRNG (name bigvgan.latent.long, seed 3)
+
+
+@torch.no_grad()
+def fast_fixtures():
+    """`infer_fast` (infer.py:332-537) on the micro config, greedy: 5 sentences, bucket size 2 -> length-sorted buckets,
+    batched AR decode per bucket, per-sentence silence fix + latent, original order restored, BigVGAN over chunks of 2
+    latents concatenated along time (:480-498), clamp to the int16 range.  Every arithmetic step runs the reference's
+    own modules / methods; only the tokenizer (needs bpe.model) is replaced by pre-tokenised ids."""
+    cfg = icfg.micro()
+    g = cfg.gpt
+    gpt = build_ref_gpt(cfg, 1234)
+    bv = build_ref_bigvgan(cfg, 1234)
+    ref_import._stub("omegaconf", OmegaConf=object)
+    from indextts.infer import IndexTTS
+
+    class Dummy:
+        stop_mel_token = g.stop_mel_token
+        device = "xpu"  # any non-"cpu" string: keeps bucket_max_size (infer.py:385-386)
+        cfg = H(gpt=H(stop_text_token=g.stop_text_token))
+
+    mel = torch.from_numpy(synth.prompt_mel(61, seed=7))
+    lens = [9, 14, 6, 11, 8]
+    sents = [torch.from_numpy(synth.text_ids(n, 31 + i, g.number_text_tokens)).int() for i, n in enumerate(lens)]
+    max_mel = 12
+    buckets = IndexTTS.bucket_sentences(Dummy(), [s.tolist() for s in sents], bucket_max_size=2)
+    all_codes, all_idx, all_lat = [], [], []
+    for bk in buckets:
+        toks = [torch.tensor(x["sent"], dtype=torch.int32).unsqueeze(0) for x in bk]
+        batch = IndexTTS.pad_tokens_cat(Dummy(), toks) if len(toks) > 1 else toks[0]
+        codes, *_ = ref_greedy(gpt, mel, batch, max_gen=max_mel)
+        for i, x in enumerate(bk):
+            c, cl = IndexTTS.remove_long_silence(Dummy(), codes[i:i + 1].clone(), silent_token=52, max_consecutive=30)
+            lat = gpt(mel, toks[i], torch.tensor([toks[i].shape[-1]]), c, cl * gpt.mel_length_compression,
+                      cond_mel_lengths=torch.tensor([mel.shape[-1]]), return_latent=True, clip_inputs=False)
+            all_idx.append(x["idx"])
+            all_lat.append(lat)
+            all_codes.append(codes[i])
+    all_lat = [all_lat[all_idx.index(i)] for i in range(len(all_lat))]
+    wavs = []
+    for lo in range(0, len(all_lat), 2):
+        wav, _ = bv(torch.cat(all_lat[lo:lo + 2], dim=1), mel.transpose(1, 2))
+        wavs.append(torch.clamp(32767 * wav.squeeze(1), -32767.0, 32767.0))
+    wav = torch.cat(wavs, dim=1)
+    pad = torch.nn.utils.rnn.pad_sequence(sents, batch_first=True, padding_value=-1)
+    cpad = torch.nn.utils.rnn.pad_sequence([all_codes[all_idx.index(i)] for i in range(len(sents))], batch_first=True, padding_value=-1)
+    save("micro_infer_fast", text=pad, text_lens=np.asarray(lens), codes=cpad, wav_int16=wav.type(torch.int16),
+         max_mel_tokens=max_mel, bucket_size=2, bucket_order=np.asarray([x["idx"] for bk in buckets for x in bk]))
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
+    ap.add_argument("--long", action="store_true")
+    ap.add_argument("--fast", action="store_true")
     ap.add_argument("--full", action="store_true")
     ap.add_argument("--skip-micro", action="store_true")
     a = ap.parse_args()
@@ -295,3 +394,7 @@ if __name__ == "__main__":
         micro_fixtures()
     if a.full:
         full_fixtures()
+    if a.fast:
+        fast_fixtures()
+    if a.long:
+        long_fixtures()

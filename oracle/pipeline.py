@@ -76,3 +76,41 @@ def infer_sentence(prompt_mel, text_tokens, wg, wb, cfg, max_mel_tokens: int = 6
         timers["bigvgan"] = timers.get("bigvgan", 0.0) + t3 - t2
     wav = torch.clamp(32767 * wav.squeeze(1), -32767.0, 32767.0)
     return codes, latent, wav
+
+
+def infer_fast_sentences(prompt_mel, sentences: List[torch.Tensor], wg, wb, cfg, max_mel_tokens: int = 600,
+                         bucket_max_size: int = 4):
+    """`infer_fast` (infer.py:332-537) under greedy kwargs over pre-tokenised sentences: length-sorted buckets
+    (:303-315), one batched decode per bucket with stop-padded ids (:316-318,412-439), per sentence silence fix +
+    latent at batch 1 (:446-477), original order restored (:481), BigVGAN over chunks of 2 latents concatenated along
+    time (:480-498), clamp(32767 * wav).  Returns (codes per sentence, wav [1, n])."""
+    from importlib import import_module
+
+    ecapa = import_module("itts_hip.config").ecapa_dims(cfg["bigvgan"])
+    g = cfg["gpt"]
+    items = [{"idx": i, "sent": s, "len": int(s.numel())} for i, s in enumerate(sentences)]
+    if len(items) <= bucket_max_size:
+        buckets = [items]
+    else:
+        buckets = []
+        for it in sorted(items, key=lambda x: x["len"]):
+            if not buckets or len(buckets[-1]) >= bucket_max_size:
+                buckets.append([it])
+            else:
+                buckets[-1].append(it)
+    cond = ogpt.get_conditioning(prompt_mel, wg, g)
+    codes_by_idx, lat_by_idx = {}, {}
+    for bk in buckets:
+        rows = [x["sent"].reshape(-1) for x in bk]
+        batch = torch.nn.utils.rnn.pad_sequence(rows, batch_first=True, padding_value=g["stop_text_token"])
+        codes = ogpt.greedy_generate(cond, batch, wg, g, max_mel_tokens)
+        for i, x in enumerate(bk):
+            c, _ = remove_long_silence(codes[i:i + 1], g["stop_mel_token"])
+            codes_by_idx[x["idx"]] = codes[i]
+            lat_by_idx[x["idx"]] = ogpt.latent_forward(cond, rows[i].view(1, -1), c, wg, g)
+    lats = [lat_by_idx[i] for i in range(len(sentences))]
+    wavs = []
+    for lo in range(0, len(lats), 2):
+        wav = ovoc.bigvgan_forward(torch.cat(lats[lo:lo + 2], dim=1), prompt_mel.transpose(1, 2), wb, cfg["bigvgan"], ecapa)
+        wavs.append(torch.clamp(32767 * wav.squeeze(1), -32767.0, 32767.0))
+    return [codes_by_idx[i] for i in range(len(sentences))], torch.cat(wavs, dim=1)

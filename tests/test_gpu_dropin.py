@@ -25,6 +25,21 @@ def test_native_op_dropin(gold):
                    torch.from_numpy(g["alpha"]).cuda(), torch.from_numpy(g["beta"]).cuda())
     assert y.shape == x.shape and y.dtype == x.dtype
     assert float((y.cpu() - torch.from_numpy(g["y"])).abs().max()) < 2e-5 * float(np.abs(g["y"]).max())
+    # half and bfloat16 inputs (the reference dispatches float / half / bf16, type_shim.h:20-43; its GPU default is half):
+    # fp32 arithmetic inside, output rounded once -> within 1 ulp of the fp32 result on the rounded input
+    from oracle import vocoder as ovoc_
+
+    for dt, ulp in ((torch.float16, 2.0 ** -10), (torch.bfloat16, 2.0 ** -7)):
+        xh = x.to(dt)
+        yh = op.forward(xh, torch.from_numpy(g["filt"]).cuda(), torch.from_numpy(g["filt_down"]).cuda(),
+                        torch.from_numpy(g["alpha"]).cuda(), torch.from_numpy(g["beta"]).cuda())
+        assert yh.dtype == dt and yh.shape == x.shape
+        want = ovoc_.activation1d(xh.float().cpu(), torch.from_numpy(g["alpha"]), torch.from_numpy(g["beta"]))
+        err = (yh.float().cpu() - want).abs()
+        assert bool((err <= ulp * want.abs() + 1e-3 * ulp).all() or float(err.max()) < 1.01 * ulp * float(want.abs().max())), dt
+        assert float((yh.float().cpu() - torch.from_numpy(g["y"])).abs().max()) < 8 * ulp * float(np.abs(g["y"]).max())
+    with pytest.raises(RuntimeError):
+        op.forward(x.double(), torch.zeros(12), torch.zeros(12), torch.zeros(8), torch.zeros(8))
     with pytest.raises(RuntimeError):
         op.forward(x.cpu(), torch.zeros(12), torch.zeros(12), torch.zeros(8), torch.zeros(8))
     with pytest.raises(RuntimeError):
@@ -130,3 +145,91 @@ def test_dropin_misc(tts, gold, tmp_path):
     assert sr == 24000 and data.dtype == np.int16 and data.shape[0] % 1024 == 0
     with pytest.raises(TypeError):
         tts.infer(text=[[5, 6]])
+
+
+def test_infer_fast_matches_reference_fixture(tts, gold):
+    """`infer_fast` against the reference's own flow (oracle/make_golden.py fast_fixtures: reference modules, 5 sentences,
+    bucket size 2 -> length-sorted buckets, BigVGAN over time-concatenated chunks of 2 latents, infer.py:480-498)."""
+    import warnings
+
+    g = gold("micro_infer_fast")
+    sents = [g["text"][i, : int(n)].astype(np.int32) for i, n in enumerate(g["text_lens"])]
+    mel = torch.from_numpy(synth.prompt_mel(61, seed=7))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", RuntimeWarning)
+        sr, wav = tts.infer_fast(prompt_mel=mel, text=sents, output_path=None, max_mel_tokens=int(g["max_mel_tokens"]),
+                                 sentences_bucket_max_size=int(g["bucket_size"]), do_sample=False, num_beams=1)
+    ref = g["wav_int16"].T
+    assert sr == 24000 and wav.shape == ref.shape, (wav.shape, ref.shape)
+    err = np.sqrt(((wav.astype(np.float64) - ref) ** 2).mean()) / np.sqrt((ref.astype(np.float64) ** 2).mean())
+    assert err < 2e-3, err
+    # plain `infer` vocodes per sentence: same codes, different samples around every chunk seam
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", RuntimeWarning)
+        _, wav2 = tts.infer(prompt_mel=mel, text=sents, output_path=None, max_mel_tokens=int(g["max_mel_tokens"]),
+                            do_sample=False, num_beams=1)
+    assert wav2.shape == wav.shape and not np.array_equal(wav2, wav)
+
+
+def test_prompt_cache_is_not_aliased_and_many_sentences(tts):
+    """Two DIFFERENT same-shape prompts back to back must not share conditioning latents (the r01 cache was keyed on the
+    tensor address, which the caching allocator recycles); more sentences than the engine's max_batch are decoded in
+    groups; an empty text raises like the reference (torch.cat of nothing -> RuntimeError)."""
+    import warnings
+
+    sents = [synth.text_ids(6, 40, CFG.gpt.number_text_tokens).astype(np.int32)]
+    outs = []
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", RuntimeWarning)
+        for seed in (7, 8, 7):
+            mel = torch.from_numpy(synth.prompt_mel(61, seed=seed))  # fresh host tensor -> fresh device copy inside infer
+            outs.append(tts.infer(prompt_mel=mel, text=sents, output_path=None, max_mel_tokens=6, do_sample=False, num_beams=1)[1])
+            del mel
+        assert np.array_equal(outs[0], outs[2]) and not np.array_equal(outs[0], outs[1])
+        many = [synth.text_ids(5, 100 + i, CFG.gpt.number_text_tokens).astype(np.int32) for i in range(70)]
+        _, wav = tts.infer(prompt_mel=torch.from_numpy(synth.prompt_mel(61, seed=7)), text=many, output_path=None,
+                           max_mel_tokens=3, do_sample=False, num_beams=1)
+        assert wav.shape[0] > 0 and wav.shape[0] % 1024 == 0
+    with pytest.raises(RuntimeError):
+        tts.infer(prompt_mel=torch.from_numpy(synth.prompt_mel(61, seed=7)), text=[], output_path=None)
+
+
+def test_engine_is_serialised_across_threads(tts):
+    """The reference web UI starts a worker thread per request into ONE IndexTTS (webui.py:441-452): concurrent calls
+    must serialise on the engine lock and return what the same calls return one after the other."""
+    import threading
+    import warnings
+
+    mel = torch.from_numpy(synth.prompt_mel(61, seed=7))
+    texts = [[synth.text_ids(5 + i, 60 + i, CFG.gpt.number_text_tokens).astype(np.int32)] for i in range(4)]
+
+    def run(i, out):
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore", RuntimeWarning)
+            out[i] = tts.infer(prompt_mel=mel, text=texts[i], output_path=None, max_mel_tokens=8, do_sample=False, num_beams=1)[1]
+
+    serial = {}
+    for i in range(4):
+        run(i, serial)
+    par = {}
+    ths = [threading.Thread(target=run, args=(i, par)) for i in range(4)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    for i in range(4):
+        assert np.array_equal(serial[i], par[i]), i
+
+
+def test_infer_batch_equals_per_utterance_infer(tts):
+    import warnings
+
+    mel = torch.from_numpy(synth.prompt_mel(61, seed=7)).cuda()
+    utts = [[synth.text_ids(5 + (i + k) % 4, 200 + 10 * i + k, CFG.gpt.number_text_tokens).astype(np.int32) for k in range(1 + i % 3)]
+            for i in range(5)]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", RuntimeWarning)
+        batch = tts.infer_batch(mel, utts, max_mel_tokens=6, do_sample=False, num_beams=1)
+        for i, u in enumerate(utts):
+            sr, w = tts.infer(prompt_mel=mel, text=u, output_path=None, max_mel_tokens=6, do_sample=False, num_beams=1)
+            assert batch[i][0] == sr and np.array_equal(batch[i][1], w), i

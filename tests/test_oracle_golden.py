@@ -140,3 +140,45 @@ def test_remove_long_silence(gold):
         oc, ol = opipe.remove_long_silence(torch.from_numpy(g[f"in{i}"]), int(g["stop"]))
         assert np.array_equal(oc.numpy(), g[f"out{i}"]), i
         assert np.array_equal(ol.numpy(), g[f"len{i}"]), i
+
+
+def test_infer_fast_pipeline(gold, wg, wb):
+    """oracle.pipeline.infer_fast_sentences against the reference's own infer_fast flow (micro_infer_fast fixture)."""
+    g = gold("micro_infer_fast")
+    sents = [torch.from_numpy(g["text"][i, : int(n)].astype(np.int64)) for i, n in enumerate(g["text_lens"])]
+    mel = torch.from_numpy(synth.prompt_mel(61, seed=7))
+    codes, wav = opipe.infer_fast_sentences(mel, sents, wg, wb, CFG, max_mel_tokens=int(g["max_mel_tokens"]),
+                                            bucket_max_size=int(g["bucket_size"]))
+    for i, c in enumerate(codes):
+        ref = g["codes"][i]
+        assert np.array_equal(c.numpy(), ref[ref >= 0]), i
+    ref = g["wav_int16"].astype(np.float64)
+    got = wav.type(torch.int16).numpy().astype(np.float64)
+    assert got.shape == ref.shape
+    assert np.sqrt(((got - ref) ** 2).mean()) / np.sqrt((ref ** 2).mean()) < 1e-3
+
+
+def test_full_size_oracle_on_bench_shapes(gold):
+    """IndexTTS-1.5 sizes, L = 105: the oracle's first greedy steps / top-8 logits, the T = 480 latent pass and a 64-frame
+    waveform against the reference-generated long-run fixtures (bounded: 4 decode steps; the 660-step run is the GPU
+    parity test's job)."""
+    cfg = icfg.indextts_1_5()
+    g, gw = gold("long_decode_b1"), gold("long_bigvgan")
+    w = ogpt.to_torch(synth.gpt_state_dict(cfg, 1234))
+    mel = torch.from_numpy(synth.prompt_mel(511, seed=7))
+    with torch.no_grad():
+        cond = ogpt.get_conditioning(mel, w, cfg.gpt)
+        text = torch.from_numpy(g["text"].astype(np.int64))
+        codes = ogpt.greedy_generate(cond, text, w, cfg.gpt, 4, suppress_eos=True)
+        assert np.array_equal(codes.numpy(), g["codes"][:, :4])
+        lat = ogpt.latent_forward(cond, text, torch.from_numpy(g["codes"][:, :480]), w, cfg.gpt)
+        close(lat[0, :, :16], g["latent_sample"], rtol=1e-3, atol=1e-4)
+        close(lat[0, g["latent_row_idx"]], g["latent_rows"], rtol=1e-3, atol=1e-4)
+        del w
+        from itts_hip import prng
+
+        wb_ = ogpt.to_torch(synth.bigvgan_state_dict(cfg, 1234))
+        lat_in = torch.from_numpy(prng.tensor("bigvgan.latent.long", 3, (1, 64, cfg.bigvgan.gpt_dim), std=1.0, mean=0.0))
+        wav = ovoc.bigvgan_forward(lat_in, mel.transpose(1, 2), wb_, cfg.bigvgan, icfg.ecapa_dims(cfg.bigvgan))
+    err = float(np.sqrt(((wav[0, 0].numpy().astype(np.float64) - gw["wav"]) ** 2).mean()) / np.sqrt((gw["wav"].astype(np.float64) ** 2).mean()))
+    assert err < 1e-4, err
