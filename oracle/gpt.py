@@ -338,3 +338,65 @@ def latent_forward(cond, text_tokens, codes, w: W, cfg_gpt):
     h, _ = gpt2_stack(emb, w, g)
     enc = layer_norm(h[:, cond.shape[1]:], w, "final_norm")
     return enc[:, -m.shape[1]:][:, :-2]
+
+
+def beam_sample_generate(cond, text_inputs, w: W, cfg_gpt, max_generate_length: int, num_beams: int = 3, top_k: int = 30,
+                         top_p: float = 0.8, temperature: float = 1.0, repetition_penalty: float = 10.0,
+                         length_penalty: float = 0.0, uniforms=None, trace: Optional[dict] = None):
+    """UnifiedVoice.inference_speech under the reference's DEFAULT kwargs (infer.py:116-124: do_sample=True, num_beams=3,
+    top_k=30, top_p=0.8, length_penalty=0.0, repetition_penalty=10.0): HF 4.36.2 GenerationMixin.beam_sample +
+    BeamSearchScorer, restated in oracle/hf_beam.py, over this module's GPT-2 stack with the KV cache re-ordered by
+    beam_idx every step (GPT2InferenceModel._reorder_cache, model.py:194-207).  uniforms [max_gen, b, 2*num_beams] are
+    the draws.  Returns codes [b, <= max_generate_length] (prefix stripped, model.py:704-705)."""
+    import numpy as np
+
+    from . import hf_beam
+
+    stop = cfg_gpt["stop_mel_token"]
+    V = cfg_gpt["number_mel_codes"]
+    nb = num_beams
+    fake, prefix, mask = prepare_gpt_inputs(cond, text_inputs, w, cfg_gpt)
+    b, s, _ = prefix.shape
+    # _expand_inputs_for_generation: repeat_interleave(num_beams) on ids / mask; store_mel_emb's prefix repeats likewise
+    ids = fake.repeat_interleave(nb, 0).clone()
+    mask = mask.repeat_interleave(nb, 0)
+    prefix = prefix.repeat_interleave(nb, 0)
+    mel_emb, mel_pos = w["mel_embedding.weight"], w["mel_pos_embedding.emb.weight"]
+    emb = torch.cat([prefix, mel_emb[ids[:, s:]] + mel_pos[:1]], dim=1)
+    h, past = gpt2_stack(emb, w, cfg_gpt, key_mask=mask)
+    prompt_len = s + 1
+    scorer = hf_beam.BeamSearchScorer(b, nb, length_penalty=length_penalty, max_length=prompt_len + max_generate_length)
+    beam_scores = np.zeros(b * nb, dtype=np.float32)
+    step = 0
+    steps_log = []
+    while True:
+        logits = lm_head(h[:, -1:], w)[:, 0]
+        lp = torch.log_softmax(logits, dim=-1)
+        lp = repetition_penalty_(lp.clone(), ids, repetition_penalty) if repetition_penalty != 1.0 else lp
+        lpn = lp.numpy()
+        ns, nt, ni = [], [], []
+        for bi in range(b):
+            cands = [hf_beam.warp_row(lpn[bi * nb + r], top_k, top_p, temperature, 2) for r in range(nb)]
+            sc, tk, bm = hf_beam.beam_sample_step(cands, beam_scores[bi * nb:(bi + 1) * nb], V, uniforms[step, bi])
+            ns.append(sc)
+            nt.append(tk)
+            ni.append(bm)
+        ns, nt, ni = np.stack(ns), np.stack(nt), np.stack(ni)
+        ids_np = ids.numpy()
+        beam_scores, btok, bidx = scorer.process(ids_np, ns, nt, ni, stop, stop, prompt_len)
+        if trace is not None:
+            steps_log.append(dict(scores=ns.copy(), tokens=nt.copy(), beams=ni.copy(), beam_idx=bidx.copy(), next_tokens=btok.copy(),
+                                  beam_scores=beam_scores.copy(), done=list(scorer.done)))
+        bidx_t = torch.from_numpy(bidx)
+        ids = torch.cat([ids[bidx_t], torch.from_numpy(btok)[:, None]], dim=1)
+        mask = torch.cat([mask, torch.ones(b * nb, 1, dtype=torch.long)], dim=1)
+        past = [(k[bidx_t], v[bidx_t]) for k, v in past]
+        step += 1
+        if scorer.is_done or ids.shape[1] >= prompt_len + max_generate_length:
+            break
+        e = mel_emb[ids[:, -1]][:, None] + mel_pos[mask.shape[1] - s][None, None]
+        h, past = gpt2_stack(e, w, cfg_gpt, key_mask=mask, past=past)
+    if trace is not None:
+        trace["steps"] = steps_log
+    out = scorer.finalize(ids.numpy(), beam_scores, stop, stop, prompt_len)
+    return torch.from_numpy(out[:, prompt_len:])

@@ -133,6 +133,72 @@ def ref_greedy(gpt, cond_mel, text, max_gen, rep=10.0, n_trace=None, suppress_eo
     return ids[:, s + 1:], torch.stack(logits_trace, 1), conds, emb, mask[:, : s + 1]
 
 
+def ref_beam_sample(gpt, cond_mel, text, max_gen, uniforms, nb=3, top_k=30, top_p=0.8, temperature=1.0, rep=10.0,
+                    length_penalty=0.0):
+    """Hand-rolled HF-4.36.2 `beam_sample` over the reference's own GPT2InferenceModel.forward / _reorder_cache with the
+    INSTALLED transformers logits processors / warpers (min_tokens_to_keep = 2 under beams) and the BeamSearchScorer
+    restatement of oracle/hf_beam.py; torch.multinomial is replaced by the shared-uniform sequential draw."""
+    from transformers import (RepetitionPenaltyLogitsProcessor, TemperatureLogitsWarper, TopKLogitsWarper,
+                              TopPLogitsWarper)
+
+    from oracle import hf_beam
+
+    stop = gpt.stop_mel_token
+    lens = torch.tensor([cond_mel.shape[-1]])
+    conds = gpt.get_conditioning(cond_mel, lens)
+    ids, emb, mask = gpt.prepare_gpt_inputs(conds, text)
+    gpt.inference_model.store_mel_emb(emb)
+    s = emb.shape[1]
+    b = ids.shape[0]
+    V = gpt.number_mel_codes
+    ids = ids.repeat_interleave(nb, 0)
+    mask = mask.repeat_interleave(nb, 0)
+    proc = RepetitionPenaltyLogitsProcessor(rep)
+    warpers = []
+    if temperature != 1.0:
+        warpers.append(TemperatureLogitsWarper(temperature))
+    if top_k:
+        warpers.append(TopKLogitsWarper(top_k=top_k, min_tokens_to_keep=2))
+    if top_p is not None and top_p < 1.0:
+        warpers.append(TopPLogitsWarper(top_p=top_p, min_tokens_to_keep=2))
+    prompt_len = s + 1
+    scorer = hf_beam.BeamSearchScorer(b, nb, length_penalty=length_penalty, max_length=prompt_len + max_gen)
+    beam_scores = np.zeros(b * nb, dtype=np.float32)
+    past, step = None, 0
+    while True:
+        inp = ids if past is None else ids[:, -1:]
+        out = gpt.inference_model(input_ids=inp, past_key_values=past, attention_mask=mask, use_cache=True, return_dict=True)
+        past = out.past_key_values
+        sc = torch.log_softmax(out.logits[:, -1, :], dim=-1)
+        sc = proc(ids, sc.clone())
+        for wp in warpers:
+            sc = wp(ids, sc)
+        scn = sc.numpy()
+        ns, nt, ni = [], [], []
+        for bi in range(b):
+            cands = []
+            for r in range(nb):
+                row = scn[bi * nb + r]
+                keep = np.nonzero(np.isfinite(row))[0]
+                cands.append((keep, row[keep]))
+            a, t, m = hf_beam.beam_sample_step(cands, beam_scores[bi * nb:(bi + 1) * nb], V, uniforms[step, bi])
+            ns.append(a)
+            nt.append(t)
+            ni.append(m)
+        beam_scores, btok, bidx = scorer.process(ids.numpy(), np.stack(ns), np.stack(nt), np.stack(ni), stop, stop, prompt_len)
+        bidx_t = torch.from_numpy(bidx)
+        ids = torch.cat([ids[bidx_t], torch.from_numpy(btok)[:, None]], dim=-1)
+        mask = torch.cat([mask, torch.ones(b * nb, 1, dtype=mask.dtype)], dim=-1)
+        if isinstance(past, tuple):
+            past = type(gpt.inference_model)._reorder_cache(past, bidx_t)
+        else:
+            past.reorder_cache(bidx_t)
+        step += 1
+        if scorer.is_done or ids.shape[-1] >= prompt_len + max_gen:
+            break
+    return scorer.finalize(ids.numpy(), beam_scores, stop, stop, prompt_len)[:, prompt_len:]
+
+
 def save(name, **arrs):
     os.makedirs(GOLD, exist_ok=True)
     out = {}
@@ -231,6 +297,14 @@ def micro_fixtures():
     dcodes = torch.from_numpy(prng.randint("dvae.codes", 5, 2 * 9, 0, cfg.vqvae.num_tokens)).view(2, 9)
     out, _ = dv.decode(dcodes)
     save("micro_dvae", codes=dcodes, mel=out)
+
+    print("[micro] beam-sample (the reference's default kwargs: 3 beams, top_k 30, top_p 0.8)")
+    rng = np.random.default_rng(2024)
+    for tag, (txt, nb, tk, tp, tmp, n) in {"a": (torch.cat([text, text2], 0), 3, 30, 0.8, 1.0, 24), "b": (text, 3, 10, 0.6, 0.9, 20),
+                                            "c": (rag, 2, 30, 0.9, 1.0, 16)}.items():
+        u = rng.random((n, txt.shape[0], 2 * nb), dtype=np.float32)
+        codes_b = ref_beam_sample(gpt, mel, txt, n, u, nb=nb, top_k=tk, top_p=tp, temperature=tmp)
+        save(f"micro_beam_{tag}", text=txt, codes=codes_b, uniforms=u, num_beams=nb, top_k=tk, top_p=tp, temperature=tmp, max_gen=n)
 
     print("[int] remove_long_silence known answers")
     ref_import._stub("omegaconf", OmegaConf=object)
