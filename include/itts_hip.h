@@ -124,6 +124,18 @@ int itts_ecapa(itts_engine* e, const void* mel_bfc, int B, int F, float* spk_out
 int itts_gpt_set_sampling(itts_engine* e, int do_sample, int top_k, float top_p, float temperature, const float* uniforms_host,
                           int64_t n_uniforms);
 
+/* Beam-sample mode of the next generations: HF 4.36.2 GenerationMixin.beam_sample + BeamSearchScorer, the generate() mode
+ * the reference's DEFAULT kwargs select (infer.py:116-124: do_sample=True, num_beams=3, top_k=30, top_p=0.8,
+ * length_penalty=0.0; call site gpt/model.py:698-703; cache re-ordering gpt/model.py:194-207).  Per step and batch item:
+ * log_softmax -> RepetitionPenalty -> Temperature -> TopK -> TopP (min_tokens_to_keep 2) -> + beam scores -> 2 * num_beams
+ * draws without replacement -> BeamSearchScorer.process, all on the device; the KV cache is not copied when beams swap
+ * (per-beam ancestry rows).  itts_gpt_prefill then takes B batch items and runs B * num_beams rows (<= max_batch);
+ * itts_gpt_fetch returns the finalized best hypothesis per batch item, codes [B, max_gen] padded with the stop token.
+ * uniforms_host: [max_gen][B][2 * num_beams] floats in [0, 1): draw j of (step, item) is the inverse CDF of its uniform over
+ * the not-yet-drawn candidates in flat (beam-major, token-ascending) order.  2 <= num_beams <= 4; num_beams <= 1 = off. */
+int itts_gpt_set_beam_sample(itts_engine* e, int num_beams, int top_k, float top_p, float temperature, const float* uniforms_host,
+                             int64_t n_uniforms);
+
 /* Forced tokens for the first n steps of every following generation (n = 0 clears): ids_host int32 [B, n] (B = 1 is
  * broadcast to every row; -1 = leave that step free).  This is the `input_tokens` continuation of
  * UnifiedVoice.inference_speech (gpt/model.py:672-686: given mel tokens are appended to the prompt and generation

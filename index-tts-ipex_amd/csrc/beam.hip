@@ -1,0 +1,405 @@
+// Beam-sample on the device: one step of HF transformers 4.36.2 `GenerationMixin.beam_sample` + `BeamSearchScorer.process`
+// (the generate() mode the reference's DEFAULT kwargs select: do_sample=True, num_beams=3, top_k=30, top_p=0.8,
+// length_penalty=0.0, repetition_penalty=10.0 - indextts/infer.py:116-124, indextts/gpt/model.py:690-703), for every
+// batch item, without a host round trip per token.  Restated as oracle/hf_beam.py; pinned by tests/golden/micro_beam_*.
+//
+// One 1024-thread workgroup per batch item, its nb beams one after the other:
+//   log_softmax(logits) -> RepetitionPenalty over the beam's own id history (a bitmap rebuilt in LDS from that history:
+//   beams swap histories every step) -> Temperature -> TopK (4-pass radix select, min_tokens_to_keep = 2) -> TopP
+//   (min_tokens_to_keep = 2) -> + running beam score.
+// Then one thread: softmax over the kept candidates of all beams in flat (beam-major, token-ascending) order, 2 * nb
+// draws WITHOUT replacement by inverse CDF of caller uniforms, sort by score, the BeamSearchScorer bookkeeping
+// (finished hypotheses, worst score, done test).  Then all threads re-order what the beams own: id histories and the
+// KV-cache ancestry rows (see decode_attn2_kernel ANC - the cache itself is never copied), and prepare the next
+// step's input embeddings.
+#include "itts_decode.h"
+
+namespace itts {
+namespace {
+
+constexpr int MAXB = 4;    // beams per batch item
+constexpr int MAXC = 64;   // kept candidates per beam (top_k <= 64)
+
+__device__ __forceinline__ unsigned okey(float v) {
+  const unsigned u = __float_as_uint(v);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+__device__ __forceinline__ float block_max(float v, float* red, int tid) {
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  if ((tid & 63) == 0) red[tid >> 6] = v;
+  __syncthreads();
+  float r = red[0];
+  for (int i = 1; i < 16; ++i) r = fmaxf(r, red[i]);
+  __syncthreads();
+  return r;
+}
+__device__ __forceinline__ float block_sum(float v, float* red, int tid) {
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  if ((tid & 63) == 0) red[tid >> 6] = v;
+  __syncthreads();
+  float r = 0.f;
+  for (int i = 0; i < 16; ++i) r += red[i];
+  __syncthreads();
+  return r;
+}
+
+__global__ __launch_bounds__(1024) void beam_sample_kernel(BeamArgs a) {
+  extern __shared__ float ssc[];  // [V] processed scores of the beam being worked on
+  __shared__ unsigned seenw[512];  // V <= 16384 bits
+  __shared__ unsigned hist[256];
+  __shared__ float red[16];
+  __shared__ int s_bin, s_k, s_cnt;
+  __shared__ float cval[MAXC];
+  __shared__ int cidx[MAXC];
+  __shared__ float cand_sc[MAXB][MAXC];  // kept candidates per beam, token-ascending, running beam score included
+  __shared__ int cand_tok[MAXB][MAXC];
+  __shared__ int cand_n[MAXB];
+  __shared__ int nxt_src[MAXB], nxt_tok[MAXB];  // new beam k continues physical row nxt_src[k] with token nxt_tok[k]
+  __shared__ float nxt_score[MAXB];
+  __shared__ int add_slot[MAXB], add_src[MAXB], n_add;  // hypotheses finished this step: copy history of add_src into slot
+  __shared__ int s_done;
+  const int bi = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+  const int nb = a.nb, V = a.V, Beff = a.B * nb, mg = a.max_gen;
+  const int k = a.len[bi * nb];  // tokens generated so far: the same for every beam (they step together)
+  if (k >= mg) return;           // graph replays past the end are no-ops
+  const int par = k & 1;
+  const int* ids_old = a.ids + (size_t)par * Beff * mg;
+  int* ids_new = a.ids + (size_t)(par ^ 1) * Beff * mg;
+  const uint8_t* anc_old = a.anc + (size_t)par * Beff * a.Smax;
+  uint8_t* anc_new = a.anc + (size_t)(par ^ 1) * Beff * a.Smax;
+  const int was_done = a.done[bi];
+  if (!was_done) {
+    for (int r = 0; r < nb; ++r) {
+      const int row = bi * nb + r;
+      const float* __restrict__ lg = a.logits + (size_t)row * V;
+      // ---- log_softmax ----
+      float mx = -INFINITY;
+      for (int i = tid; i < V; i += 1024) mx = fmaxf(mx, lg[i]);
+      mx = block_max(mx, red, tid);
+      float se = 0.f;
+      for (int i = tid; i < V; i += 1024) se += expf(lg[i] - mx);
+      se = block_sum(se, red, tid);
+      const float lse = mx + logf(se);
+      // ---- ids this beam has seen: the fake prompt ids (all 1, then start_mel: model.py:644-653) + its history ----
+      for (int i = tid; i < (V + 31) / 32; i += 1024) seenw[i] = 0u;
+      __syncthreads();
+      if (tid == 0) {
+        atomicOr(&seenw[a.fake_id >> 5], 1u << (a.fake_id & 31));
+        atomicOr(&seenw[a.start_tok >> 5], 1u << (a.start_tok & 31));
+      }
+      for (int i = tid; i < k; i += 1024) {
+        const int t = ids_old[(size_t)row * mg + i];
+        atomicOr(&seenw[t >> 5], 1u << (t & 31));
+      }
+      __syncthreads();
+      for (int i = tid; i < V; i += 1024) {
+        float v = lg[i] - lse;
+        if (a.penalty != 1.f && ((seenw[i >> 5] >> (i & 31)) & 1u)) v = v < 0.f ? v * a.penalty : v / a.penalty;
+        if (a.suppress_stop && i == a.stop) v = -INFINITY;
+        if (a.temperature != 1.f) v = v / a.temperature;
+        ssc[i] = v;
+      }
+      // ---- TopK: radix select of the kk-th largest key (kk = max(top_k, min_tokens_to_keep = 2)) ----
+      unsigned prefix = 0;
+      int kk = min(max(a.top_k, 2), V);
+      for (int pass = 3; pass >= 0; --pass) {
+        const int shift = pass * 8;
+        if (tid < 256) hist[tid] = 0;
+        __syncthreads();
+        for (int i = tid; i < V; i += 1024) {
+          const unsigned key = okey(ssc[i]);
+          if (pass == 3 || (key >> (shift + 8)) == (prefix >> (shift + 8))) atomicAdd(&hist[(key >> shift) & 255u], 1u);
+        }
+        __syncthreads();
+        if (tid < 64) {
+          const unsigned h0 = hist[4 * lane], h1 = hist[4 * lane + 1], h2 = hist[4 * lane + 2], h3 = hist[4 * lane + 3];
+          const unsigned own = h0 + h1 + h2 + h3;
+          unsigned x = own;
+#pragma unroll
+          for (int off = 1; off < 64; off <<= 1) {
+            const unsigned t = __shfl_down(x, off, 64);
+            if (lane + off < 64) x += t;
+          }
+          const unsigned above = x - own;
+          if (above < (unsigned)kk && (unsigned)kk <= x) {
+            unsigned acc = above;
+            int bin = 4 * lane + 3;
+            const unsigned hb[4] = {h0, h1, h2, h3};
+#pragma unroll
+            for (int j = 3; j >= 0; --j) {
+              if (acc + hb[j] >= (unsigned)kk) {
+                bin = 4 * lane + j;
+                break;
+              }
+              acc += hb[j];
+            }
+            s_bin = bin;
+            s_k = kk - (int)acc;
+          }
+        }
+        __syncthreads();
+        prefix |= (unsigned)s_bin << shift;
+        kk = s_k;
+      }
+      if (tid == 0) s_cnt = 0;
+      __syncthreads();
+      for (int i = tid; i < V; i += 1024) {
+        const float v = ssc[i];
+        if (okey(v) >= prefix) {
+          const int p = atomicAdd(&s_cnt, 1);
+          if (p < MAXC) {
+            cval[p] = v;
+            cidx[p] = i;
+          }
+        }
+      }
+      __syncthreads();
+      const int n = min(s_cnt, MAXC);
+      if (tid < 64) {
+        float v = lane < n ? cval[lane] : -INFINITY;
+        int ix = lane < n ? cidx[lane] : 0x7fffffff;
+        // descending score, ascending index on ties
+#pragma unroll
+        for (int kq = 2; kq <= 64; kq <<= 1) {
+#pragma unroll
+          for (int j = kq >> 1; j > 0; j >>= 1) {
+            const float ov = __shfl_xor(v, j, 64);
+            const int oi = __shfl_xor(ix, j, 64);
+            const bool up = (lane & kq) == 0, lower = (lane & j) == 0;
+            const bool other_better = ov > v || (ov == v && oi < ix);
+            if ((lower == up) ? other_better : !other_better) {
+              v = ov;
+              ix = oi;
+            }
+          }
+        }
+        cval[lane] = v;
+        cidx[lane] = ix;
+      }
+      __syncthreads();
+      if (tid == 0) {
+        // TopP (ascending cumulative probability <= 1 - top_p goes; the best min_tokens_to_keep = 2 always stay)
+        int R = n;
+        if (a.top_p < 1.f) {
+          const float m = cval[0];
+          float Z = 0.f;
+          for (int q = 0; q < n; ++q) Z += expf(cval[q] - m);
+          float tail = 0.f;
+          R = 1;
+          for (int q = n - 1; q >= 1; --q) {
+            tail += expf(cval[q] - m) / Z;
+            if (!(tail <= 1.f - a.top_p)) {
+              R = q + 1;
+              break;
+            }
+          }
+          R = min(max(R, 2), n);
+        }
+        s_cnt = R;
+      }
+      __syncthreads();
+      const int R = s_cnt;
+      if (tid < 64) {
+        // the kept ones in token order (the flat index order of next_token_scores.view(batch, beams * vocab))
+        float v = lane < R ? cval[lane] : 0.f;
+        int ix = lane < R ? cidx[lane] : 0x7fffffff;
+#pragma unroll
+        for (int kq = 2; kq <= 64; kq <<= 1) {
+#pragma unroll
+          for (int j = kq >> 1; j > 0; j >>= 1) {
+            const float ov = __shfl_xor(v, j, 64);
+            const int oi = __shfl_xor(ix, j, 64);
+            const bool up = (lane & kq) == 0, lower = (lane & j) == 0;
+            const bool other_first = oi < ix;
+            if ((lower == up) ? other_first : !other_first) {
+              v = ov;
+              ix = oi;
+            }
+          }
+        }
+        cand_sc[r][lane] = v + a.beam_scores[row];
+        cand_tok[r][lane] = ix;
+        if (lane == 0) cand_n[r] = R;
+      }
+      __syncthreads();
+    }
+  }
+  // ---- one thread: draws, sort, BeamSearchScorer.process ----
+  if (tid == 0) {
+    n_add = 0;
+    if (was_done) {
+      for (int q = 0; q < nb; ++q) {
+        nxt_src[q] = bi * nb + q;  // (HF points done batches at row 0; nothing of a done batch is read again)
+        nxt_tok[q] = a.stop;
+        nxt_score[q] = 0.f;
+      }
+      s_done = 1;
+    } else {
+      float m = -INFINITY;
+      for (int r = 0; r < nb; ++r)
+        for (int q = 0; q < cand_n[r]; ++q) m = fmaxf(m, cand_sc[r][q]);
+      bool alive[MAXB][MAXC];
+      float e[MAXB][MAXC];
+      for (int r = 0; r < nb; ++r)
+        for (int q = 0; q < cand_n[r]; ++q) {
+          alive[r][q] = true;
+          e[r][q] = expf(cand_sc[r][q] - m);
+        }
+      const int nd = 2 * nb;
+      float psc[2 * MAXB];
+      int ptok[2 * MAXB], pbeam[2 * MAXB];
+      const float* u = a.uniforms + ((size_t)k * a.B + bi) * nd;
+      for (int j = 0; j < nd; ++j) {
+        float total = 0.f;
+        for (int r = 0; r < nb; ++r)
+          for (int q = 0; q < cand_n[r]; ++q)
+            if (alive[r][q]) total += e[r][q];
+        const float target = u[j] * total;
+        float c = 0.f;
+        int pr = -1, pq = -1, lr = -1, lq = -1;
+        for (int r = 0; r < nb && pr < 0; ++r)
+          for (int q = 0; q < cand_n[r]; ++q) {
+            if (!alive[r][q]) continue;
+            lr = r;
+            lq = q;
+            c += e[r][q];
+            if (c >= target) {
+              pr = r;
+              pq = q;
+              break;
+            }
+          }
+        if (pr < 0) {
+          pr = lr;
+          pq = lq;
+        }
+        if (pr < 0) {  // fewer live candidates than draws (cannot happen with min_tokens_to_keep = 2): repeat a stop
+          psc[j] = -INFINITY;
+          ptok[j] = a.stop;
+          pbeam[j] = 0;
+          continue;
+        }
+        alive[pr][pq] = false;
+        psc[j] = cand_sc[pr][pq];
+        ptok[j] = cand_tok[pr][pq];
+        pbeam[j] = pr;
+      }
+      // torch.sort(descending): stable insertion sort (equal scores keep draw order)
+      for (int i = 1; i < nd; ++i) {
+        const float s0 = psc[i];
+        const int t0 = ptok[i], b0 = pbeam[i];
+        int j = i - 1;
+        while (j >= 0 && psc[j] < s0) {
+          psc[j + 1] = psc[j];
+          ptok[j + 1] = ptok[j];
+          pbeam[j + 1] = pbeam[j];
+          --j;
+        }
+        psc[j + 1] = s0;
+        ptok[j + 1] = t0;
+        pbeam[j + 1] = b0;
+      }
+      // BeamSearchScorer.process (beam_search.py, 4.36.2); generated_len = cur_len - decoder_prompt_len = k + 1
+      float* hs = a.hyp_score + (size_t)bi * (nb + 1);
+      int* hl = a.hyp_len + (size_t)bi * (nb + 1);
+      int* ho = a.hyp_order + (size_t)bi * (nb + 1);  // insertion counter, -1 = free slot
+      int hn = a.hyp_n[bi];
+      float worst = a.hyp_worst[bi];
+      int counter = a.hyp_counter[bi];
+      int filled = 0;
+      for (int rank = 0; rank < nd && filled < nb; ++rank) {
+        if (ptok[rank] == a.stop) {
+          if (rank >= nb) continue;
+          const float score = psc[rank];  // length_penalty 0: sum_logprobs / generated_len ** 0
+          if (hn < nb || score > worst) {
+            int slot = 0;
+            while (ho[slot] >= 0) ++slot;  // nb + 1 slots, at most nb in use here
+            hs[slot] = score;
+            hl[slot] = k;  // the hypothesis is the history WITHOUT the stop token
+            ho[slot] = counter++;
+            add_slot[n_add] = slot;
+            add_src[n_add] = bi * nb + pbeam[rank];
+            ++n_add;
+            ++hn;
+            if (hn > nb) {  // drop the lowest (score, insertion order)
+              int lo = -1;
+              for (int q = 0; q <= nb; ++q)
+                if (ho[q] >= 0 && (lo < 0 || hs[q] < hs[lo] || (hs[q] == hs[lo] && ho[q] < ho[lo]))) lo = q;
+              ho[lo] = -1;
+              --hn;
+              worst = INFINITY;
+              for (int q = 0; q <= nb; ++q)
+                if (ho[q] >= 0) worst = fminf(worst, hs[q]);
+            } else {
+              worst = fminf(score, worst);
+            }
+          }
+        } else {
+          nxt_score[filled] = psc[rank];
+          nxt_tok[filled] = ptok[rank];
+          nxt_src[filled] = bi * nb + pbeam[rank];
+          ++filled;
+        }
+      }
+      for (; filled < nb; ++filled) {  // HF raises here; keep the state well-formed
+        nxt_score[filled] = -INFINITY;
+        nxt_tok[filled] = a.stop;
+        nxt_src[filled] = bi * nb;
+      }
+      a.hyp_n[bi] = hn;
+      a.hyp_worst[bi] = worst;
+      a.hyp_counter[bi] = counter;
+      // is_done(best_sum_logprobs = the best of the 2 * nb candidates, early_stopping False, length_penalty 0)
+      s_done = (hn >= nb && worst >= psc[0]) ? 1 : 0;
+      a.done[bi] = s_done;
+    }
+  }
+  __syncthreads();
+  // ---- all threads: finished hypotheses keep a copy of their history ----
+  for (int q = 0; q < n_add; ++q) {
+    int* dst = a.hyp_tok + ((size_t)bi * (nb + 1) + add_slot[q]) * mg;
+    const int* src = ids_old + (size_t)add_src[q] * mg;
+    for (int i = tid; i < k; i += 1024) dst[i] = src[i];
+  }
+  // ---- beams swap histories: ids and cache ancestry of new beam q come from physical row nxt_src[q] ----
+  const int pos_next = a.prefix_dev[0] + k + 1;  // where the next step appends (own physical row)
+  for (int q = 0; q < nb; ++q) {
+    const int dst = bi * nb + q, src = nxt_src[q];
+    for (int i = tid; i < k; i += 1024) ids_new[(size_t)dst * mg + i] = ids_old[(size_t)src * mg + i];
+    for (int i = tid; i < a.Smax; i += 1024)
+      anc_new[(size_t)dst * a.Smax + i] = i == pos_next ? (uint8_t)q : anc_old[(size_t)src * a.Smax + i];
+    if (tid == 0) {
+      ids_new[(size_t)dst * mg + k] = nxt_tok[q];
+      a.cur_tok[dst] = nxt_tok[q];
+      a.len[dst] = k + 1;
+      a.beam_scores[dst] = nxt_score[q];
+      a.unfinished[dst] = !s_done;
+    }
+    if (a.h_next) {  // next step's input row: mel_emb[tok] + mel_pos[k + 2] (positions 0, 2, 3, ...: model.py:153-155)
+      const int tok = nxt_tok[q], p = min(k + 2, a.pos_rows - 1);
+      for (int i = tid; i < a.D; i += 1024) {
+        float v;
+        if (a.emb_bf16)
+          v = (float)((const bf16_t*)a.emb)[(size_t)tok * a.D + i] + (float)((const bf16_t*)a.pos)[(size_t)p * a.D + i];
+        else
+          v = ((const float*)a.emb)[(size_t)tok * a.D + i] + ((const float*)a.pos)[(size_t)p * a.D + i];
+        a.h_next[(size_t)dst * a.D + i] = v;
+      }
+    }
+  }
+}
+
+}  // namespace
+
+int beam_sample_step(const BeamArgs& a, hipStream_t s) {
+  ITTS_REQUIRE(a.nb >= 2 && a.nb <= MAXB, "beam_sample: 2 <= num_beams <= 4");
+  ITTS_REQUIRE(a.top_k >= 1 && a.top_k <= MAXC && a.top_p > 0.f && a.temperature > 0.f, "beam_sample: 1 <= top_k <= 64, top_p > 0, temperature > 0");
+  ITTS_REQUIRE(a.V <= 15000, "beam_sample: vocabulary too large for the LDS-resident sampler");
+  ITTS_REQUIRE(a.logits && a.uniforms && a.ids && a.anc && a.len && a.hyp_tok && a.done, "beam_sample: null state");
+  hipLaunchKernelGGL(beam_sample_kernel, dim3(a.B), dim3(1024), (size_t)a.V * 4, s, a);
+  ITTS_HIP_CHECK(hipGetLastError());
+  return OK;
+}
+
+}  // namespace itts

@@ -180,6 +180,11 @@ int itts_gpt_set_sampling(itts_engine* e, int do_sample, int top_k, float top_p,
   ENG(e);
   return e->e.gpt_set_sampling(do_sample, top_k, top_p, temperature, uniforms_host, (long)n_uniforms);
 }
+int itts_gpt_set_beam_sample(itts_engine* e, int num_beams, int top_k, float top_p, float temperature, const float* uniforms_host,
+                             int64_t n_uniforms) {
+  ENG(e);
+  return e->e.gpt_set_beam_sample(num_beams, top_k, top_p, temperature, uniforms_host, (long)n_uniforms);
+}
 int itts_gpt_set_forced(itts_engine* e, const int32_t* ids_host, int B, int n) {
   ENG(e);
   return e->e.gpt_set_forced(ids_host, B, n);

@@ -745,13 +745,19 @@ __device__ unsigned long long* g_attn_stamp = nullptr;
 // GEMV, prologue 3 - merges them while it loads its activations.  At 2 rows x 20 heads this turns 40 workgroups of 16
 // waves (4 waves per SIMD: the softmax phase is issue-bound and the last wave trails the first by 1.4 us on the phase
 // timeline) into 160 workgroups of 4 waves, one per SIMD, on 160 CUs.
-template <typename TC, typename TO, int NIT, int NT, int NSPLIT = 1>
+// ANC (beam-sample): the cache is NOT re-ordered when the beams are (HF `_reorder_cache` copies every layer's K/V by
+// beam_idx each step, model.py:194-207).  Instead every beam row b carries an ancestry row anc[b][j] = which of the nb
+// physical rows of its batch item holds position j of ITS history; the beam sampler rewrites those few KB per step
+// (ping-pong by the parity of the step count) and this kernel gathers K/V rows through it.  The row appended by this
+// step always goes to the beam's own physical row.
+template <typename TC, typename TO, int NIT, int NT, int NSPLIT = 1, bool ANC = false>
 __global__ __launch_bounds__(NT) void decode_attn2_kernel(TO* __restrict__ ctx, const float* __restrict__ qkv,
                                                           TC* __restrict__ kc, TC* __restrict__ vc,
                                                           const int* __restrict__ len, const int* __restrict__ kv_start,
                                                           const int* __restrict__ prefix, int H, int Smax, float scale,
                                                           int ctx_bt, float* __restrict__ part_o = nullptr,
-                                                          float* __restrict__ part_ml = nullptr) {
+                                                          float* __restrict__ part_ml = nullptr,
+                                                          const uint8_t* __restrict__ anc = nullptr, int nb = 1) {
   constexpr int DH = 64, VEC = CacheVec<TC>::VEC, LPK = CacheVec<TC>::LPK, NW = NT / 64, SLOTS = NT / LPK;
   constexpr int SD = NT >= 1024 ? 2 : 4;  // rows per slot in flight beyond the register window
   ATTN_STAMP(0)
@@ -763,6 +769,21 @@ __global__ __launch_bounds__(NT) void decode_attn2_kernel(TO* __restrict__ ctx, 
   TC* kb = kc + ((size_t)b * H + h) * Smax * DH;
   TC* vb = vc + ((size_t)b * H + h) * Smax * DH;
   const int slot = tid / LPK, sub = tid % LPK;
+  // cache row of key j: own row, or (ANC) the physical row the beam's ancestry names for that position
+  const uint8_t* arow = nullptr;
+  int rowbase = 0;
+  if constexpr (ANC) {
+    arow = anc + ((size_t)(len[b] & 1) * gridDim.y + b) * Smax;
+    rowbase = (b / nb) * nb;
+  }
+  auto krow = [&](int j) -> const TC* {
+    if constexpr (ANC) return kc + ((size_t)(rowbase + min((int)arow[j], nb - 1)) * H + h) * Smax * DH + (size_t)j * DH;
+    return kb + (size_t)j * DH;
+  };
+  auto vrow = [&](int j) -> const TC* {
+    if constexpr (ANC) return vc + ((size_t)(rowbase + min((int)arow[j], nb - 1)) * H + h) * Smax * DH + (size_t)j * DH;
+    return vb + (size_t)j * DH;
+  };
   // (a) the first pair of key/value rows of this slot, requested before ANYTHING else: their addresses depend on no
   //     device scalar (rows are clamped to the cache capacity; rows >= S are masked out below)
   CacheVec<TC> kr[2 * NIT], vr[2 * NIT];
@@ -773,8 +794,8 @@ __global__ __launch_bounds__(NT) void decode_attn2_kernel(TO* __restrict__ ctx, 
 #pragma unroll
   for (int u = 0; u < UNC; ++u) {
     const int j = min((u * NSPLIT + sp) * SLOTS + slot, Smax - 1);
-    kr[u].load(kb + (size_t)j * DH + sub * VEC);
-    vr[u].load(vb + (size_t)j * DH + sub * VEC);
+    kr[u].load(krow(j) + sub * VEC);
+    vr[u].load(vrow(j) + sub * VEC);
   }
   // (a') this thread's slice of the step's q / k / v (addresses depend on no device scalar either): straight to
   //      registers - no LDS round trip, no barrier between the query and the cache reads
@@ -797,8 +818,8 @@ __global__ __launch_bounds__(NT) void decode_attn2_kernel(TO* __restrict__ ctx, 
   for (int u = UNC; u < 2 * NIT; ++u)
     if ((u * NSPLIT + sp) * SLOTS < S) {  // block-uniform
       const int j = min((u * NSPLIT + sp) * SLOTS + slot, Smax - 1);
-      kr[u].load(kb + (size_t)j * DH + sub * VEC);
-      vr[u].load(vb + (size_t)j * DH + sub * VEC);
+      kr[u].load(krow(j) + sub * VEC);
+      vr[u].load(vrow(j) + sub * VEC);
     }
   ATTN_STAMP(1)
   // (d) the step's own q / k / v: scale, round as the cache does, append
@@ -894,8 +915,8 @@ __global__ __launch_bounds__(NT) void decode_attn2_kernel(TO* __restrict__ ctx, 
 #pragma unroll
     for (int u = 0; u < SD; ++u) {
       const int j = min(((cb + u) * NSPLIT + sp) * SLOTS + slot, Smax - 1);
-      k2[u].load(kb + (size_t)j * DH + sub * VEC);
-      v2[u].load(vb + (size_t)j * DH + sub * VEC);
+      k2[u].load(krow(j) + sub * VEC);
+      v2[u].load(vrow(j) + sub * VEC);
     }
 #pragma unroll
     for (int u = 0; u < SD; ++u) consume(k2[u], v2[u], ((cb + u) * NSPLIT + sp) * SLOTS + slot);
@@ -1370,13 +1391,19 @@ int gemv_bf16(const GemvArgs& g, hipStream_t s) {
 
 int decode_attn2(void* ctx, int to, const float* qkv, void* kc, void* vc, const int* len, const int* kv_start,
                  const int* prefix_dev, int B, int H, int dh, int Smax, int tc, hipStream_t s, int ctx_tiled, float* part_o,
-                 float* part_ml) {
+                 float* part_ml, const uint8_t* anc, int nb) {
   ITTS_REQUIRE(dh == 64, "decode_attn2: head dim must be 64");
+  ITTS_REQUIRE(!anc || (nb >= 1 && nb <= 8 && B % nb == 0), "decode_attn2: beam ancestry needs B to be a multiple of 1 <= nb <= 8");
   if (part_o) {  // split form: 4 workgroups of 256 threads per (row, head), partials merged by the projection GEMV
     ITTS_REQUIRE(part_ml && tc == BF16, "decode_attn2: split form needs both partial buffers and a bf16 cache");
     const float scale = 1.f / sqrtf((float)dh);
-    hipLaunchKernelGGL((decode_attn2_kernel<bf16_t, bf16_t, 3, 256, ATTN_NSPLIT>), dim3(H, B, ATTN_NSPLIT), dim3(256), 0, s, (bf16_t*)nullptr,
-                       qkv, (bf16_t*)kc, (bf16_t*)vc, len, kv_start, prefix_dev, H, Smax, scale, 0, part_o, part_ml);
+    if (anc)
+      hipLaunchKernelGGL((decode_attn2_kernel<bf16_t, bf16_t, 3, 256, ATTN_NSPLIT, true>), dim3(H, B, ATTN_NSPLIT), dim3(256), 0, s,
+                         (bf16_t*)nullptr, qkv, (bf16_t*)kc, (bf16_t*)vc, len, kv_start, prefix_dev, H, Smax, scale, 0, part_o,
+                         part_ml, anc, nb);
+    else
+      hipLaunchKernelGGL((decode_attn2_kernel<bf16_t, bf16_t, 3, 256, ATTN_NSPLIT>), dim3(H, B, ATTN_NSPLIT), dim3(256), 0, s, (bf16_t*)nullptr,
+                         qkv, (bf16_t*)kc, (bf16_t*)vc, len, kv_start, prefix_dev, H, Smax, scale, 0, part_o, part_ml);
     ITTS_HIP_CHECK(hipGetLastError());
     return OK;
   }
@@ -1389,7 +1416,13 @@ int decode_attn2(void* ctx, int to, const float* qkv, void* kc, void* vc, const 
 #define ATTN_NIT_MANY 8
 #endif
 #define LAUNCH(TCT, TOT)                                                                                                  \
-  if (many)                                                                                                               \
+  if (anc && many)                                                                                                        \
+    hipLaunchKernelGGL((decode_attn2_kernel<TCT, TOT, ATTN_NIT_MANY, 256, 1, true>), grid, dim3(256), 0, s, (TOT*)ctx, qkv, (TCT*)kc,   \
+                       (TCT*)vc, len, kv_start, prefix_dev, H, Smax, scale, bt, nullptr, nullptr, anc, nb);               \
+  else if (anc)                                                                                                           \
+    hipLaunchKernelGGL((decode_attn2_kernel<TCT, TOT, 3, 1024, 1, true>), grid, dim3(1024), 0, s, (TOT*)ctx, qkv, (TCT*)kc, (TCT*)vc,  \
+                       len, kv_start, prefix_dev, H, Smax, scale, bt, nullptr, nullptr, anc, nb);                         \
+  else if (many)                                                                                                          \
     hipLaunchKernelGGL((decode_attn2_kernel<TCT, TOT, ATTN_NIT_MANY, 256>), grid, dim3(256), 0, s, (TOT*)ctx, qkv, (TCT*)kc, (TCT*)vc, len, \
                        kv_start, prefix_dev, H, Smax, scale, bt);                                                         \
   else                                                                                                                    \

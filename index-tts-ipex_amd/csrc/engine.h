@@ -127,6 +127,15 @@ struct DecodeState {
   float top_p = 1.f, temperature = 1.f, graph_top_p = 1.f, graph_temperature = 1.f;
   float* uniforms = nullptr;
   size_t uniforms_cap = 0;
+  // beam-sample (itts_gpt_set_beam_sample): B = batch items * nb rows; state of beam.hip
+  int nb = 1, graph_nb = 1;          // beams per batch item (1 = off)
+  int* beam_ids = nullptr;           // [2][B][max_gen]
+  uint8_t* anc = nullptr;            // [2][B][Smax]
+  float* beam_scores = nullptr;      // [B]
+  int *hyp_tok = nullptr, *hyp_len = nullptr, *hyp_order = nullptr, *hyp_n = nullptr, *hyp_counter = nullptr, *beam_done = nullptr;
+  float *hyp_score = nullptr, *hyp_worst = nullptr;
+  size_t beam_cap = 0;               // bytes-independent capacity key: rows * max_gen * Smax the beam buffers were sized for
+  int beam_rows = 0, beam_gen = 0, beam_smax = 0;
   int* forced = nullptr;  // [cap_B][cap_gen] forced token per (row, step) or -1; allocated with ids
   int use_forced = 0, graph_forced = 0;
   float graph_penalty = 0.f;
@@ -184,6 +193,10 @@ struct Engine {
   int gpt_set_sampling(int do_sample, int top_k, float top_p, float temperature, const float* uniforms_host, long n);
   std::vector<float> sample_uniforms;  // host copy, uploaded by the next prefill
   int gpt_set_forced(const int32_t* ids_host, int B, int n);
+  int gpt_set_beam_sample(int num_beams, int top_k, float top_p, float temperature, const float* uniforms_host, long n);
+  int beam_beams = 1;  // requested beams for the following generations (1 = off)
+  int ensure_beam_state(int rows, int max_gen, int Smax, hipStream_t s);
+  int beam_finalize(int32_t* codes_host, hipStream_t s);
   std::vector<int32_t> forced_host;  // [forced_B][forced_n], uploaded by the next prefill
   int forced_B = 0, forced_n = 0;
   int gpt_status(int* steps, int* n_unf, hipStream_t s);

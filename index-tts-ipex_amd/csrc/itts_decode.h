@@ -65,6 +65,34 @@ struct SamplerArgs {
   const int* forced = nullptr;  // [B][max_gen]
 };
 
+// one beam-sample step for every batch item (beam.hip): HF 4.36.2 beam_sample + BeamSearchScorer.process on the device
+struct BeamArgs {
+  const float* logits = nullptr;  // [B * nb, V]
+  int V = 0, max_gen = 0, stop = 0, suppress_stop = 0, nb = 0, B = 0;  // B = batch items (rows = B * nb)
+  int top_k = 0, start_tok = 0, fake_id = 1, Smax = 0;
+  float penalty = 1.f, top_p = 1.f, temperature = 1.f;
+  const float* uniforms = nullptr;  // [max_gen][B][2 * nb]
+  int *len = nullptr, *cur_tok = nullptr, *unfinished = nullptr;  // per row
+  int* ids = nullptr;          // [2][B * nb][max_gen] id histories, ping-pong by the parity of the step count
+  uint8_t* anc = nullptr;      // [2][B * nb][Smax] cache ancestry rows (decode_attn2 ANC), same ping-pong
+  const int* prefix_dev = nullptr;
+  float* beam_scores = nullptr;  // [B * nb]
+  // finished hypotheses per batch item: nb + 1 slots (one spare while the worst is being replaced)
+  int* hyp_tok = nullptr;      // [B][nb + 1][max_gen]
+  float* hyp_score = nullptr;  // [B][nb + 1]
+  int* hyp_len = nullptr;      // [B][nb + 1]
+  int* hyp_order = nullptr;    // [B][nb + 1] insertion counter, -1 = free
+  int* hyp_n = nullptr;        // [B]
+  float* hyp_worst = nullptr;  // [B]
+  int* hyp_counter = nullptr;  // [B]
+  int* done = nullptr;         // [B]
+  float* h_next = nullptr;     // next step's input rows [B * nb][D]
+  const void* emb = nullptr;
+  const void* pos = nullptr;
+  int D = 0, pos_rows = 0, emb_bf16 = 0;
+};
+int beam_sample_step(const BeamArgs& a, hipStream_t s);
+
 int gemv(const GemvArgs& g, int tw, hipStream_t s);
 int double_ln(float* y, const float* x, const float* g1, const float* b1, const float* g2, const float* b2, int rows,
               int D, float eps, hipStream_t s);
@@ -75,7 +103,7 @@ bool gemv2_supported(const GemvArgs& g);
 int gemv2(const GemvArgs& g, int tw, hipStream_t s);
 int decode_attn2(void* ctx, int to, const float* qkv, void* kc, void* vc, const int* len, const int* kv_start,
                  const int* prefix_dev, int B, int H, int dh, int Smax, int tc, hipStream_t s, int ctx_tiled = 0,
-                 float* part_o = nullptr, float* part_ml = nullptr);
+                 float* part_o = nullptr, float* part_ml = nullptr, const uint8_t* anc = nullptr, int nb = 1);
 constexpr int ATTN_NSPLIT = 4;  // workgroups per (row, head) in the split form of decode_attn2
 bool gemv_bf16_supported(const GemvArgs& g);
 int gemv_bf16(const GemvArgs& g, hipStream_t s);

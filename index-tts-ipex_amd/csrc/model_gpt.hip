@@ -49,6 +49,24 @@ __global__ void init_decode_state_kernel(uint8_t* seen, int* unfinished, int* cu
   if (i == 0) prefix_dev[0] = prefix;
 }
 
+// beam-sample state of a fresh generation: identity cache ancestry (every beam row reads its own prefix copy), zero
+// running scores (beam_sample starts all beams at 0, unlike beam_search), no finished hypotheses
+__global__ void beam_init_kernel(uint8_t* anc, float* beam_scores, int* hyp_order, int* hyp_n, float* hyp_worst,
+                                 int* hyp_counter, int* done, int rows, int nb, int Smax) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long n = (long)rows * Smax;
+  if (i < 2 * n) anc[i] = (uint8_t)(((i % n) / Smax) % nb);
+  if (i < rows) beam_scores[i] = 0.f;
+  const int B = rows / nb;
+  if (i < (long)B * (nb + 1)) hyp_order[i] = -1;
+  if (i < B) {
+    hyp_n[i] = 0;
+    hyp_worst[i] = 1e9f;
+    hyp_counter[i] = 0;
+    done[i] = 0;
+  }
+}
+
 }  // namespace
 
 #define K(call)               \
@@ -158,8 +176,130 @@ int Engine::ensure_decode_state(int B, int Smax, int max_gen, hipStream_t s) {
   return OK;
 }
 
-int Engine::gpt_prefill(const float* cond_dev, const int32_t* text_ids, int B, int L, int max_gen, float penalty,
+int Engine::ensure_beam_state(int rows, int max_gen, int Smax, hipStream_t s) {
+  DecodeState& d = ds;
+  if (rows <= d.beam_rows && max_gen <= d.beam_gen && Smax <= d.beam_smax && d.beam_ids) return OK;
+  ITTS_HIP_CHECK(hipStreamSynchronize(s));
+  for (hipGraphExec_t* ge : {&d.graph, &d.graphK})  // captured nodes hold the old pointers
+    if (*ge) {
+      (void)hipGraphExecDestroy(*ge);
+      *ge = nullptr;
+    }
+  const int r = std::max(rows, d.beam_rows), g = std::max(max_gen, d.beam_gen), sm = std::max(Smax, d.beam_smax);
+  ITTS_TRY(dev_alloc((void**)&d.beam_ids, (size_t)2 * r * g * 4));
+  ITTS_TRY(dev_alloc((void**)&d.anc, (size_t)2 * r * sm));
+  ITTS_TRY(dev_alloc((void**)&d.beam_scores, (size_t)r * 4));
+  ITTS_TRY(dev_alloc((void**)&d.hyp_tok, (size_t)r * 2 * g * 4));  // [B][nb + 1][g] <= rows * 2 * g
+  ITTS_TRY(dev_alloc((void**)&d.hyp_score, (size_t)r * 2 * 4));
+  ITTS_TRY(dev_alloc((void**)&d.hyp_len, (size_t)r * 2 * 4));
+  ITTS_TRY(dev_alloc((void**)&d.hyp_order, (size_t)r * 2 * 4));
+  ITTS_TRY(dev_alloc((void**)&d.hyp_n, (size_t)r * 4));
+  ITTS_TRY(dev_alloc((void**)&d.hyp_worst, (size_t)r * 4));
+  ITTS_TRY(dev_alloc((void**)&d.hyp_counter, (size_t)r * 4));
+  ITTS_TRY(dev_alloc((void**)&d.beam_done, (size_t)r * 4));
+  d.beam_rows = r;
+  d.beam_gen = g;
+  d.beam_smax = sm;
+  return OK;
+}
+
+// HF beam_sample configuration for the following generations (num_beams <= 1 switches it off): the generate() mode of
+// the reference's default kwargs (infer.py:116-124).  uniforms_host: row-major [max_gen][B][2 * num_beams] draws in [0, 1).
+int Engine::gpt_set_beam_sample(int num_beams, int top_k, float top_p, float temperature, const float* uniforms_host, long n) {
+  if (num_beams <= 1) {
+    beam_beams = 1;
+    if (!ds.do_sample) sample_uniforms.clear();
+    return OK;
+  }
+  ITTS_REQUIRE(num_beams <= 4, "gpt_set_beam_sample: num_beams must be in [2, 4]");
+  ITTS_REQUIRE(top_k >= 1 && top_k <= 64, "gpt_set_beam_sample: top_k must be in [1, 64]");
+  ITTS_REQUIRE(top_p > 0.f && top_p <= 1.f && temperature > 0.f, "gpt_set_beam_sample: need 0 < top_p <= 1 and temperature > 0");
+  ITTS_REQUIRE(uniforms_host && n > 0, "gpt_set_beam_sample: uniforms missing");
+  beam_beams = num_beams;
+  ds.do_sample = 0;
+  ds.top_k = top_k;
+  ds.top_p = top_p;
+  ds.temperature = temperature;
+  sample_uniforms.assign(uniforms_host, uniforms_host + n);
+  return OK;
+}
+
+// BeamSearchScorer.finalize (beam_search.py, 4.36.2) on the host: open beams of unfinished batch items join their
+// hypotheses with the running scores, the best hypothesis (highest score, the later one on ties) is returned per batch
+// item as codes [B][max_gen] padded with the stop token (eos = pad = stop_mel_token, model.py:698-700).
+int Engine::beam_finalize(int32_t* codes, hipStream_t s) {
+  DecodeState& d = ds;
+  const int nb = d.nb, rows = d.B, B = rows / nb, mg = d.max_gen;
+  std::vector<int> len(rows), done(B), hn(B), hlen((size_t)B * (nb + 1)), hord((size_t)B * (nb + 1));
+  std::vector<float> bscore(rows), hscore((size_t)B * (nb + 1));
+  ITTS_HIP_CHECK(hipMemcpyAsync(len.data(), d.len, (size_t)rows * 4, hipMemcpyDeviceToHost, s));
+  ITTS_HIP_CHECK(hipMemcpyAsync(done.data(), d.beam_done, (size_t)B * 4, hipMemcpyDeviceToHost, s));
+  ITTS_HIP_CHECK(hipMemcpyAsync(bscore.data(), d.beam_scores, (size_t)rows * 4, hipMemcpyDeviceToHost, s));
+  ITTS_HIP_CHECK(hipMemcpyAsync(hscore.data(), d.hyp_score, hscore.size() * 4, hipMemcpyDeviceToHost, s));
+  ITTS_HIP_CHECK(hipMemcpyAsync(hlen.data(), d.hyp_len, hlen.size() * 4, hipMemcpyDeviceToHost, s));
+  ITTS_HIP_CHECK(hipMemcpyAsync(hord.data(), d.hyp_order, hord.size() * 4, hipMemcpyDeviceToHost, s));
+  ITTS_HIP_CHECK(hipStreamSynchronize(s));
+  const int k = len[0];
+  std::vector<int32_t> ids((size_t)rows * mg), htok((size_t)B * (nb + 1) * mg);
+  ITTS_HIP_CHECK(hipMemcpyAsync(ids.data(), d.beam_ids + (size_t)(k & 1) * rows * mg, ids.size() * 4, hipMemcpyDeviceToHost, s));
+  ITTS_HIP_CHECK(hipMemcpyAsync(htok.data(), d.hyp_tok, htok.size() * 4, hipMemcpyDeviceToHost, s));
+  ITTS_HIP_CHECK(hipStreamSynchronize(s));
+  for (int b = 0; b < B; ++b) {
+    struct Hyp {
+      float score;
+      int order, len;
+      const int32_t* tok;
+    };
+    std::vector<Hyp> hy;
+    for (int q = 0; q <= nb; ++q) {
+      const size_t i = (size_t)b * (nb + 1) + q;
+      if (hord[i] >= 0) hy.push_back({hscore[i], hord[i], hlen[i], htok.data() + i * mg});
+    }
+    if (!done[b]) {
+      // beam_hyp.add(final_tokens, final_score, generated_len) for every open beam, with BeamHypotheses.add's eviction
+      std::sort(hy.begin(), hy.end(), [](const Hyp& x, const Hyp& y) { return x.order < y.order; });
+      float worst = 1e9f;
+      for (const Hyp& h : hy) worst = std::min(worst, h.score);
+      int counter = 1 << 20;
+      for (int q = 0; q < nb; ++q) {
+        const int row = b * nb + q;
+        const float score = bscore[row];
+        if ((int)hy.size() < nb || score > worst) {
+          hy.push_back({score, counter++, k, ids.data() + (size_t)row * mg});
+          if ((int)hy.size() > nb) {
+            size_t lo = 0;
+            for (size_t i = 1; i < hy.size(); ++i)
+              if (hy[i].score < hy[lo].score || (hy[i].score == hy[lo].score && hy[i].order < hy[lo].order)) lo = i;
+            hy.erase(hy.begin() + lo);
+            worst = 1e9f;
+            for (const Hyp& h : hy) worst = std::min(worst, h.score);
+          } else {
+            worst = std::min(worst, score);
+          }
+        }
+      }
+    }
+    ITTS_REQUIRE(!hy.empty(), "beam_finalize: no hypothesis for a batch item");
+    size_t best = 0;  // sorted(key=score).pop(): highest score, the later insertion on ties
+    for (size_t i = 1; i < hy.size(); ++i)
+      if (hy[i].score > hy[best].score || (hy[i].score == hy[best].score && hy[i].order > hy[best].order)) best = i;
+    for (int i = 0; i < mg; ++i) codes[(size_t)b * mg + i] = i < hy[best].len ? hy[best].tok[i] : cfg.stop_mel_token;
+  }
+  return OK;
+}
+
+int Engine::gpt_prefill(const float* cond_dev, const int32_t* text_ids_in, int B_items, int L, int max_gen, float penalty,
                         int suppress, hipStream_t s) {
+  // beam-sample: every batch item becomes nb rows (HF _expand_inputs_for_generation: repeat_interleave)
+  const int nbeam = beam_beams > 1 ? beam_beams : 1;
+  const int B = B_items * nbeam;
+  std::vector<int32_t> text_exp;
+  const int32_t* text_ids = text_ids_in;
+  if (nbeam > 1 && text_ids_in && B_items > 0 && L > 0) {
+    text_exp.resize((size_t)B * L);
+    for (int b = 0; b < B; ++b) std::memcpy(text_exp.data() + (size_t)b * L, text_ids_in + (size_t)(b / nbeam) * L, (size_t)L * 4);
+    text_ids = text_exp.data();
+  }
   if (!finalized || !gpt.ok) {
     set_error("gpt_prefill: GPT weights not bound");
     return E_STATE;
@@ -178,9 +318,19 @@ int Engine::gpt_prefill(const float* cond_dev, const int32_t* text_ids, int B, i
   ds.prefix = sp;
   ds.penalty = penalty;
   ds.suppress_stop = suppress;
-  if (ds.do_sample) {
-    const size_t need_u = (size_t)max_gen * B;
-    ITTS_REQUIRE(sample_uniforms.size() >= need_u, "gpt_prefill: sampling enabled but fewer than max_gen * B uniforms were supplied");
+  ds.nb = nbeam;
+  if (nbeam > 1) {
+    ITTS_REQUIRE(forced_n == 0, "gpt_prefill: forced tokens are not supported together with beams");
+    ITTS_TRY(ensure_beam_state(B, max_gen, Smax, s));
+    const long n_init = std::max<long>(2L * B * Smax, 64);
+    hipLaunchKernelGGL(beam_init_kernel, dim3((unsigned)((n_init + 255) / 256)), dim3(256), 0, s, ds.anc, ds.beam_scores,
+                       ds.hyp_order, ds.hyp_n, ds.hyp_worst, ds.hyp_counter, ds.beam_done, B, nbeam, Smax);
+    ITTS_HIP_CHECK(hipGetLastError());
+  }
+  if (ds.do_sample || nbeam > 1) {
+    const size_t need_u = nbeam > 1 ? (size_t)max_gen * B_items * 2 * nbeam : (size_t)max_gen * B;
+    ITTS_REQUIRE(sample_uniforms.size() >= need_u,
+                 "gpt_prefill: sampling enabled but fewer uniforms than max_gen * B (* 2 * num_beams) were supplied");
     if (need_u > ds.uniforms_cap) {
       ITTS_HIP_CHECK(hipStreamSynchronize(s));
       for (hipGraphExec_t* ge : {&ds.graph, &ds.graphK})  // the captured samplers hold the old pointer
@@ -301,6 +451,46 @@ int Engine::head_and_sample(hipStream_t s) {
     ITTS_TRY(gemv(g, gpt.head.dt, s));
   }
   ITTS_TRY(tap("logits0", ds.logits, F32, (int64_t)B * V, s));
+  if (ds.nb > 1) {  // beam-sample: one workgroup per batch item over its nb rows
+    BeamArgs ba;
+    ba.logits = ds.logits;
+    ba.V = V;
+    ba.max_gen = ds.max_gen;
+    ba.stop = c.stop_mel_token;
+    ba.suppress_stop = ds.suppress_stop;
+    ba.nb = ds.nb;
+    ba.B = B / ds.nb;
+    ba.top_k = ds.top_k;
+    ba.top_p = ds.top_p;
+    ba.temperature = ds.temperature;
+    ba.penalty = ds.penalty;
+    ba.start_tok = c.start_mel_token;
+    ba.fake_id = 1;  // prepare_gpt_inputs: fake ids are all 1 with last = start_mel_token (model.py:644-653)
+    ba.Smax = ds.Smax;
+    ba.uniforms = ds.uniforms;
+    ba.len = ds.len;
+    ba.cur_tok = ds.cur_tok;
+    ba.unfinished = ds.unfinished;
+    ba.ids = ds.beam_ids;
+    ba.anc = ds.anc;
+    ba.prefix_dev = ds.prefix_dev;
+    ba.beam_scores = ds.beam_scores;
+    ba.hyp_tok = ds.hyp_tok;
+    ba.hyp_score = ds.hyp_score;
+    ba.hyp_len = ds.hyp_len;
+    ba.hyp_order = ds.hyp_order;
+    ba.hyp_n = ds.hyp_n;
+    ba.hyp_worst = ds.hyp_worst;
+    ba.hyp_counter = ds.hyp_counter;
+    ba.done = ds.beam_done;
+    ba.h_next = ds.h;
+    ba.emb = gpt.mel_emb;
+    ba.pos = gpt.mel_pos;
+    ba.D = D;
+    ba.pos_rows = c.max_mel_tokens + 3;
+    ba.emb_bf16 = adt == BF16;
+    return beam_sample_step(ba, s);
+  }
   SamplerArgs sa;
   sa.logits = ds.logits;
   sa.seen = ds.seen;
@@ -400,10 +590,11 @@ int Engine::decode_step_launch(hipStream_t s) {
     const bool split = fast && bf_ctx && !no_split && (long)B * H <= 128 && D % 64 == 0;
     if (split)
       ITTS_TRY(decode_attn2(nullptr, BF16, ds.qkv, (char*)ds.kc + lo, (char*)ds.vc + lo, ds.len, ds.kv_start, ds.prefix_dev, B, H,
-                            dh, ds.Smax, adt, s, 0, ds.attn_o, ds.attn_ml));
+                            dh, ds.Smax, adt, s, 0, ds.attn_o, ds.attn_ml, ds.nb > 1 ? ds.anc : nullptr, ds.nb));
     else
       ITTS_TRY(decode_attn2(ds.ctx, bf_ctx ? BF16 : F32, ds.qkv, (char*)ds.kc + lo, (char*)ds.vc + lo, ds.len, ds.kv_start,
-                            ds.prefix_dev, B, H, dh, ds.Smax, adt, s, skinny ? 1 : 0));
+                            ds.prefix_dev, B, H, dh, ds.Smax, adt, s, skinny ? 1 : 0, nullptr, nullptr,
+                            ds.nb > 1 ? ds.anc : nullptr, ds.nb));
     GemvArgs p;  // h += ctx Wproj + b
     p.B = B;
     p.X = ds.ctx;
@@ -503,7 +694,7 @@ int Engine::gpt_decode(int nsteps, hipStream_t s) {
     // everything SamplerArgs carries by value is baked into the captured nodes: max_gen is the ids row stride and the
     // `k < max_gen` bound, so a per-request max_mel_tokens must re-capture (same B / Smax notwithstanding)
     const bool stale = !d.graph || d.graph_B != d.B || d.graph_Smax != d.Smax || d.graph_max_gen != d.max_gen ||
-                       d.graph_forced != d.use_forced || d.graph_penalty != d.penalty || d.graph_suppress != d.suppress_stop || d.graph_sample != d.do_sample ||
+                       d.graph_forced != d.use_forced || d.graph_nb != d.nb || d.graph_penalty != d.penalty || d.graph_suppress != d.suppress_stop || d.graph_sample != d.do_sample ||
                        d.graph_top_k != d.top_k || d.graph_top_p != d.top_p || d.graph_temperature != d.temperature;
     // two executables: one step, and GK steps back to back (one launch per GK tokens: the gap between consecutive graph
     // launches is paid once per GK steps; every step reads its lengths from device memory, so any mix is valid)
@@ -536,6 +727,7 @@ int Engine::gpt_decode(int nsteps, hipStream_t s) {
       d.graph_Smax = d.Smax;
       d.graph_max_gen = d.max_gen;
       d.graph_forced = d.use_forced;
+      d.graph_nb = d.nb;
       d.graph_penalty = d.penalty;
       d.graph_suppress = d.suppress_stop;
       d.graph_sample = d.do_sample;
@@ -576,7 +768,10 @@ int Engine::gpt_fetch(int32_t* codes, float* logits, hipStream_t s) {
     set_error("gpt_fetch: no active generation");
     return E_STATE;
   }
-  if (codes) ITTS_HIP_CHECK(hipMemcpyAsync(codes, ds.ids, (size_t)ds.B * ds.max_gen * 4, hipMemcpyDeviceToHost, s));
+  if (codes && ds.nb > 1)
+    ITTS_TRY(beam_finalize(codes, s));  // [B / nb][max_gen]
+  else if (codes)
+    ITTS_HIP_CHECK(hipMemcpyAsync(codes, ds.ids, (size_t)ds.B * ds.max_gen * 4, hipMemcpyDeviceToHost, s));
   if (logits)
     ITTS_HIP_CHECK(hipMemcpyAsync(logits, ds.logits, (size_t)ds.B * cfg.number_mel_codes * 4, hipMemcpyDeviceToHost, s));
   ITTS_HIP_CHECK(hipStreamSynchronize(s));

@@ -57,25 +57,37 @@ class UnifiedVoice:
                          num_return_sequences=1, max_generate_length=None, typical_sampling=False, typical_mass=.9,
                          **hf_generate_kwargs):
         """Mel codes [b, <= max_generate_length] (model.py:655-708).  HF `generate` kwargs are accepted: greedy search
-        (do_sample=False) and multinomial sampling (do_sample=True with top_k <= 64, top_p, temperature,
-        repetition_penalty) run on the device; num_beams > 1 and typical_sampling are not implemented and fall back to
-        num_beams = 1 / plain warpers with a RuntimeWarning."""
-        if input_tokens is not None or num_return_sequences != 1:
-            raise NotImplementedError("input_tokens / num_return_sequences > 1")
-        if typical_sampling:
-            warnings.warn("itts_hip: typical sampling is not implemented; using top-k / top-p", RuntimeWarning)
+        (do_sample=False), multinomial sampling (do_sample=True) and beam-sample (do_sample=True, num_beams 2..4) with
+        top_k <= 64, top_p, temperature, repetition_penalty run on the device; beam search without sampling and
+        typical_sampling fall back (RuntimeWarning).  `input_tokens` [b or 1, n] (model.py:672-686): given mel tokens the
+        generation continues after; like the reference, the returned codes start after them."""
+        if num_return_sequences != 1:
+            raise NotImplementedError("num_return_sequences > 1")
         sample_kw = infer_core.sampling_kwargs(hf_generate_kwargs.get("do_sample", False), hf_generate_kwargs.get("num_beams", 1),
                                                hf_generate_kwargs.get("top_k", 50), hf_generate_kwargs.get("top_p", 1.0),
-                                               hf_generate_kwargs.get("temperature", 1.0))
+                                               hf_generate_kwargs.get("temperature", 1.0), typical_sampling, typical_mass)
         cond = self.get_conditioning(speech_conditioning_mel, cond_mel_lengths)
         ids = text_inputs.detach().cpu().numpy() if isinstance(text_inputs, torch.Tensor) else np.asarray(text_inputs)
         if ids.ndim == 1:
             ids = ids[None]
         max_gen = self.max_mel_tokens - 1 if max_generate_length is None else int(max_generate_length)
         rep = float(hf_generate_kwargs.get("repetition_penalty", 1.0) or 1.0)
+        n_forced = 0
         with self._eng.lock:
-            codes = self._eng.generate(cond, ids, max_gen, repetition_penalty=rep, **sample_kw)
-        return torch.from_numpy(codes).to(self._eng.device)
+            if input_tokens is not None:
+                if sample_kw.get("num_beams", 1) > 1:
+                    raise NotImplementedError("input_tokens together with num_beams > 1")
+                it = input_tokens.detach().cpu().numpy() if isinstance(input_tokens, torch.Tensor) else np.asarray(input_tokens)
+                it = np.atleast_2d(it).astype(np.int32)
+                n_forced = it.shape[1]
+                self._eng.set_forced(it)
+            try:
+                # max_length = trunc_index + max_generate_length with trunc_index counting the given tokens (model.py:687,695)
+                codes = self._eng.generate(cond, ids, max_gen + n_forced, repetition_penalty=rep, **sample_kw)
+            finally:
+                if n_forced:
+                    self._eng.set_forced(None)
+        return torch.from_numpy(codes[:, n_forced:]).to(self._eng.device)
 
     @torch.no_grad()
     def forward(self, speech_conditioning_latent, text_inputs, text_lengths, mel_codes, wav_lengths,

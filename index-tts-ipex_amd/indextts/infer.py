@@ -6,11 +6,16 @@ Same constructor and methods (`extract_features`, `infer`, `infer_fast`, `set_gr
   * `infer` accepts this fork's `prompt_mel=<tensor [1,100,F]>` AND upstream's `audio_prompt=<wav path>` (the
     reference's own cli.py:70 and tests call the latter, which this fork's signature rejects);
   * conditioning latents and the ECAPA speaker vector are computed once per prompt and reused across sentences;
-  * all sentences of a text are decoded as one batch (what `infer_fast` does per bucket);
-  * greedy search and multinomial sampling (do_sample with top_k <= 64 / top_p / temperature / repetition_penalty,
-    HF GenerationMixin.sample semantics) run on the device; beam search (num_beams > 1, the reference default of 3) is
-    not implemented and decodes with num_beams = 1 after a RuntimeWarning.  Draws come from a numpy Generator seeded from
-    torch's global RNG, so `torch.manual_seed` makes a run reproducible (the reference draws with torch.multinomial);
+  * `infer` decodes the sentences of a text in batches of up to max_batch rows (the reference loops at batch 1; rows of a
+    batch are independent), `infer_fast` in the reference's length-sorted buckets; both vocode as the reference does
+    (`infer` per sentence, `infer_fast` over time-concatenated chunks of 2 latents); `infer_batch` takes several utterances;
+  * every public call takes the engine lock: several host threads may share one IndexTTS (webui.py:441-452);
+  * generation runs on the device for the three modes the kwargs of infer.py:116-124 select: beam-sample (the default:
+    do_sample=True, num_beams=3; up to 4 beams, per-beam cache ancestry instead of HF's per-step cache copy), multinomial
+    sampling (num_beams=1) and greedy (do_sample=False) - with top_k <= 64 / top_p / temperature / repetition_penalty in HF
+    4.36.2 semantics.  Draws come from a numpy Generator seeded from torch's global RNG, so `torch.manual_seed` makes a run
+    reproducible (torch.multinomial's own stream cannot be reproduced on a device).  Beam search without sampling and
+    typical sampling are not implemented (RuntimeWarning, plain fallback);
   * `is_fp16=True` selects the bf16 throughput engine, `False` the fp32 parity engine; `use_cuda_kernel` is accepted
     and ignored (the fused HIP activation is always used).
 There is no CPU fallback: without a GPU / libitts_hip.so construction raises."""

@@ -200,6 +200,19 @@ class Engine:
         L.check(self.lib.itts_gpt_set_sampling(self.h, 1, int(top_k), float(top_p), float(temperature),
                                                u.ctypes.data_as(C.c_void_p), u.size), "gpt_set_sampling")
 
+    def set_beam_sample(self, num_beams: int, top_k: int = 30, top_p: float = 0.8, temperature: float = 1.0,
+                        uniforms: Optional[np.ndarray] = None):
+        """HF beam_sample (the reference's default generate() mode, infer.py:116-124) for the following generations;
+        uniforms [max_gen, B, 2 * num_beams] float32 in [0, 1).  num_beams <= 1 switches it off."""
+        if num_beams <= 1:
+            L.check(self.lib.itts_gpt_set_beam_sample(self.h, 1, 1, 1.0, 1.0, None, 0), "gpt_set_beam_sample")
+            self._nb = 1
+            return
+        u = np.ascontiguousarray(uniforms, dtype=np.float32)
+        L.check(self.lib.itts_gpt_set_beam_sample(self.h, int(num_beams), int(top_k), float(top_p), float(temperature),
+                                                  u.ctypes.data_as(C.c_void_p), u.size), "gpt_set_beam_sample")
+        self._nb = int(num_beams)
+
     def set_forced(self, ids: Optional[np.ndarray]):
         """Forced tokens [B or 1, n] (int, -1 = free) for the first n steps of the following generations; None clears."""
         if ids is None or np.asarray(ids).size == 0:
@@ -219,7 +232,7 @@ class Engine:
     def fetch(self, logits: bool = False):
         B, mg = self._gen
         codes = np.empty((B, mg), dtype=np.int32)
-        lg = np.empty((B, self.ccfg.number_mel_codes), dtype=np.float32) if logits else None
+        lg = np.empty((B * getattr(self, "_nb", 1), self.ccfg.number_mel_codes), dtype=np.float32) if logits else None
         L.check(self.lib.itts_gpt_fetch(self.h, codes.ctypes.data_as(C.c_void_p),
                                         lg.ctypes.data_as(C.c_void_p) if logits else None, self._s()), "gpt_fetch")
         return (codes, lg) if logits else codes
@@ -227,14 +240,21 @@ class Engine:
     def generate(self, cond: torch.Tensor, text_ids: np.ndarray, max_gen: int, repetition_penalty: float = 10.0,
                  suppress_stop: bool = False, check_every: int = 16, do_sample: bool = False, top_k: int = 30,
                  top_p: float = 0.8, temperature: float = 1.0, seed: Optional[int] = None,
-                 uniforms: Optional[np.ndarray] = None) -> np.ndarray:
+                 uniforms: Optional[np.ndarray] = None, num_beams: int = 1) -> np.ndarray:
         """Greedy decode (do_sample=False, num_beams=1 of tests/padding_test.py:35-46) or, with do_sample, HF
         GenerationMixin.sample (top-k / top-p / temperature, num_beams=1; draws from `uniforms` or a numpy Generator
         seeded with `seed`).  Returns int64 codes [B, n] with n <= max_gen: HF stops when every row has emitted stop
-        or at max length."""
-        if do_sample:
+        or at max length.  num_beams > 1 (with do_sample): HF beam_sample over num_beams beams per row, uniforms
+        [max_gen, B, 2 * num_beams]; returns the best finalized hypothesis per row."""
+        beams = do_sample and num_beams > 1
+        nrow = np.asarray(text_ids).shape[0]
+        if beams:
             if uniforms is None:
-                uniforms = np.random.default_rng(seed).random((max_gen, np.asarray(text_ids).shape[0]), dtype=np.float32)
+                uniforms = np.random.default_rng(seed).random((max_gen, nrow, 2 * num_beams), dtype=np.float32)
+            self.set_beam_sample(num_beams, top_k, top_p, temperature, uniforms)
+        elif do_sample:
+            if uniforms is None:
+                uniforms = np.random.default_rng(seed).random((max_gen, nrow), dtype=np.float32)
             self.set_sampling(True, top_k, top_p, temperature, uniforms)
         try:
             self.prefill(cond, text_ids, max_gen, repetition_penalty, suppress_stop)
@@ -252,7 +272,9 @@ class Engine:
             codes = self.fetch()[:, :step].astype(np.int64)
             self._exit()
         finally:
-            if do_sample:
+            if beams:
+                self.set_beam_sample(1)
+            elif do_sample:
                 self.set_sampling(False)
         # HF stops right after the step in which the last running row emitted stop: trim the look-ahead steps
         stop = self.ccfg.stop_mel_token

@@ -74,24 +74,31 @@ def pad_tokens_cat(tokens: Sequence[np.ndarray], stop_text_token: int) -> np.nda
 
 
 def sampling_kwargs(do_sample, num_beams, top_k, top_p, temperature, typical_sampling=False, typical_mass=0.9) -> dict:
-    """HF `generate` kwargs (infer.py:116-124) -> Engine.generate keywords.  Beam search is not implemented: num_beams > 1
-    warns and decodes with one beam.  top_k outside [1, 64] (HF: 0 / None disable the warper) is clamped to 64 with a
-    warning - the device sampler keeps at most 64 candidates.  The seed is drawn from torch's global RNG so that
-    torch.manual_seed governs the run as it does for the reference's torch.multinomial."""
+    """HF `generate` kwargs (infer.py:116-124) -> Engine.generate keywords.
+      do_sample, num_beams > 1   beam_sample (the reference default: 3 beams), up to 4 beams, on the device
+      do_sample, num_beams == 1  multinomial sampling on the device
+      not do_sample              greedy; num_beams > 1 without sampling (HF beam_search) is not implemented: warns, one beam
+    top_k outside [1, 64] (HF: 0 / None disable the warper) is clamped to 64 with a warning - the device samplers keep at
+    most 64 candidates per row.  The seed is drawn from torch's global RNG so that torch.manual_seed governs the run as it
+    does for the reference's torch.multinomial."""
     import warnings
 
     import torch
 
-    if num_beams is not None and int(num_beams) != 1:
-        warnings.warn("itts_hip: beam search is not implemented; decoding with num_beams=1", RuntimeWarning)
+    nb = 1 if num_beams is None else int(num_beams)
     if typical_sampling:
         warnings.warn("itts_hip: typical sampling is not implemented; using top-k / top-p", RuntimeWarning)
     if not do_sample:
+        if nb != 1:
+            warnings.warn("itts_hip: beam search without sampling is not implemented; decoding greedily with num_beams=1", RuntimeWarning)
         return {}
+    if nb > 4:
+        warnings.warn(f"itts_hip: num_beams={nb} > 4 is not supported; using 4", RuntimeWarning)
+        nb = 4
     k = int(top_k) if top_k else 0
     if k < 1 or k > 64:
         warnings.warn(f"itts_hip: top_k={top_k} is outside [1, 64]; using 64", RuntimeWarning)
         k = 64
     p = 1.0 if top_p is None else float(top_p)
-    return dict(do_sample=True, top_k=k, top_p=min(max(p, 1e-6), 1.0), temperature=float(temperature or 1.0),
+    return dict(do_sample=True, top_k=k, top_p=min(max(p, 1e-6), 1.0), temperature=float(temperature or 1.0), num_beams=max(nb, 1),
                 seed=int(torch.randint(0, 2 ** 31 - 1, (1,)).item()))

@@ -92,14 +92,17 @@ def test_indextts_infer_matches_oracle(tts):
 
 
 def test_indextts_default_kwargs_sample_reproducibly(tts):
-    """infer()'s defaults are do_sample=True, num_beams=3, top_k=30, top_p=0.8 (infer.py:116-124): beams warn and fall
-    back to one beam, the sampler runs on the device and torch.manual_seed fixes the draws."""
+    """infer()'s defaults are do_sample=True, num_beams=3, top_k=30, top_p=0.8 (infer.py:116-124): beam-sample with 3
+    beams runs on the device and torch.manual_seed fixes the draws."""
     mel = torch.from_numpy(synth.prompt_mel(61, seed=7))
     sents = [synth.text_ids(11, 11, CFG.gpt.number_text_tokens).astype(np.int32)]
     outs = []
     for seed in (3, 3, 4):
         torch.manual_seed(seed)
-        with pytest.warns(RuntimeWarning, match="beam search"):
+        import warnings
+
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore", RuntimeWarning)  # max_mel_tokens reached
             _, wav = tts.infer(prompt_mel=mel, text=sents, output_path=None, max_mel_tokens=24)
         outs.append(wav)
     assert outs[0].shape == outs[1].shape and np.array_equal(outs[0], outs[1])
@@ -112,6 +115,12 @@ def test_indextts_default_kwargs_sample_reproducibly(tts):
     b = tts.gpt.inference_speech(mel, torch.from_numpy(sents[0])[None], do_sample=True, top_k=30, top_p=0.8, temperature=1.0,
                                  num_beams=1, repetition_penalty=10.0, max_generate_length=16)
     assert torch.equal(a, b)
+    # input_tokens continuation (model.py:672-686): the given tokens are forced, the returned codes start after them
+    base = tts.gpt.inference_speech(mel, torch.from_numpy(sents[0])[None], do_sample=False, num_beams=1, repetition_penalty=10.0,
+                                    max_generate_length=12)
+    cont = tts.gpt.inference_speech(mel, torch.from_numpy(sents[0])[None], input_tokens=base[:, :5], do_sample=False, num_beams=1,
+                                    repetition_penalty=10.0, max_generate_length=7)
+    assert torch.equal(cont, base[:, 5:12])
 
 
 def test_padding_test_through_dropin(tts, gold):

@@ -270,3 +270,49 @@ def test_fp8_decode_weights_equal_their_dequantisation(gold):
     _, lg0 = e0.fetch(logits=True)
     e0._exit()
     print(f"fp8-e4m3 weights vs bf16 weights, first-step logits rel-RMS {rms_rel(out[0][0][1], lg0):.4f}")
+
+
+# ---- beam-sample: the reference's DEFAULT generate() mode (num_beams = 3) --------------------------------------------
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_beam_sample_ids_match_reference_fixture_fp32(eng32, gold, tag):
+    """Engine beam-sample (device sampler + BeamSearchScorer + cache ancestry + host finalize) against the fixture the
+    reference's GPT2InferenceModel / _reorder_cache produced with the same uniforms (make_golden.ref_beam_sample): the
+    finalized best hypotheses are bit-exact, graph replay == eager launches."""
+    c, g = gold("micro_conditioning"), gold(f"micro_beam_{tag}")
+    cond = torch.from_numpy(c["cond"])
+    kw = dict(do_sample=True, num_beams=int(g["num_beams"]), top_k=int(g["top_k"]), top_p=float(g["top_p"]),
+              temperature=float(g["temperature"]), uniforms=g["uniforms"])
+    codes = eng32.generate(cond, g["text"], int(g["max_gen"]), **kw)
+    assert codes.shape == g["codes"].shape, (codes.shape, g["codes"].shape)
+    assert np.array_equal(codes, g["codes"]), (codes, g["codes"])
+    eng32.debug(no_graph=True)
+    eager = eng32.generate(cond, g["text"], int(g["max_gen"]), **kw)
+    eng32.debug()
+    assert np.array_equal(eager, codes)
+    # a following greedy run on the same engine is unaffected (the decode graph is re-captured per mode)
+    g1 = gold("micro_decode_b1")
+    assert np.array_equal(eng32.generate(cond, g1["text"], 24), g1["codes"])
+
+
+def test_beam_sample_matches_oracle_more_rows_fp32(eng32, gold):
+    """4 batch items x 3 beams = 12 rows (the batched decode path) and 2 beams on one item, against the oracle."""
+    c = gold("micro_conditioning")
+    cond = torch.from_numpy(c["cond"])
+    wg = ogpt.to_torch(synth.gpt_state_dict(CFG, 1234))
+    text = np.stack([synth.text_ids(9, 300 + i, CFG.gpt.number_text_tokens) for i in range(4)]).astype(np.int32)
+    for nb, txt, n in ((3, text, 20), (2, text[:1], 16), (4, text[:2], 12)):
+        u = np.random.default_rng(nb).random((n, txt.shape[0], 2 * nb), dtype=np.float32)
+        got = eng32.generate(cond, txt, n, do_sample=True, num_beams=nb, top_k=30, top_p=0.8, temperature=1.0, uniforms=u)
+        with torch.no_grad():
+            want = ogpt.beam_sample_generate(cond, torch.from_numpy(txt).long(), wg, CFG.gpt, n, num_beams=nb, top_k=30, top_p=0.8,
+                                             temperature=1.0, uniforms=u).numpy()
+        assert got.shape == want.shape and np.array_equal(got, want), (nb, got, want)
+
+
+def test_beam_sample_bf16_runs_and_is_deterministic(eng16, gold):
+    c, g = gold("micro_conditioning"), gold("micro_beam_a")
+    cond = torch.from_numpy(c["cond"])
+    kw = dict(do_sample=True, num_beams=3, top_k=30, top_p=0.8, temperature=1.0, uniforms=g["uniforms"])
+    a = eng16.generate(cond, g["text"], int(g["max_gen"]), **kw)
+    b = eng16.generate(cond, g["text"], int(g["max_gen"]), **kw)
+    assert np.array_equal(a, b) and a.shape[0] == g["text"].shape[0] and a.shape[1] <= int(g["max_gen"])

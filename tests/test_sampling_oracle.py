@@ -59,3 +59,73 @@ def test_sample_pick_is_inverse_cdf_and_respects_repetition_penalty():
     pen = ogpt.repetition_penalty_(s.clone(), seen, 10.0)
     hf = tlp.RepetitionPenaltyLogitsProcessor(10.0)(seen, s.clone())
     assert torch.equal(pen, hf)
+
+
+# ---- beam-sample (the reference's default: num_beams = 3) -----------------------------------------------------------
+from itts_hip import config as icfg  # noqa: E402
+from itts_hip import synth  # noqa: E402
+from oracle import hf_beam  # noqa: E402
+
+
+@pytest.mark.parametrize("V", [66, 8194])
+@pytest.mark.parametrize("cfg", [(30, 0.8, 1.0), (10, 0.6, 0.9), (1, 0.3, 1.0), (64, 0.95, 1.2)])
+def test_beam_warp_row_matches_hf_warpers_min_keep_2(V, cfg):
+    """hf_beam.warp_row (Temperature -> TopK -> TopP with min_tokens_to_keep = 2, as _get_logits_warper builds them for
+    num_beams > 1) against the installed transformers classes on log-softmaxed, penalised rows."""
+    top_k, top_p, temp = cfg
+    rng = np.random.default_rng(V + top_k)
+    for trial in range(6):
+        lp = torch.log_softmax(torch.from_numpy((rng.standard_normal(V) * (1.0 + trial)).astype(np.float32)), -1)[None]
+        ids = torch.from_numpy(rng.integers(0, V, (1, 9)))
+        lp = tlp.RepetitionPenaltyLogitsProcessor(10.0)(ids, lp.clone())
+        s = lp.clone()
+        if temp != 1.0:
+            s = tlp.TemperatureLogitsWarper(temp)(ids, s)
+        s = tlp.TopKLogitsWarper(top_k=top_k, min_tokens_to_keep=2)(ids, s)
+        s = tlp.TopPLogitsWarper(top_p=top_p, min_tokens_to_keep=2)(ids, s)
+        keep = np.nonzero(np.isfinite(s[0].numpy()))[0]
+        got_ids, got_sc = hf_beam.warp_row(lp[0].numpy(), top_k, top_p, temp, 2)
+        assert np.array_equal(got_ids, keep), (trial, cfg)
+        assert np.abs(got_sc - s[0].numpy()[keep]).max() < 1e-6
+
+
+def test_draw_without_replacement_distribution():
+    """The shared-uniform sequential draw samples what torch.multinomial(replacement=False) samples: first-draw
+    frequencies follow the weights, all draws distinct."""
+    rng = np.random.default_rng(0)
+    sc = np.log(np.asarray([0.5, 0.25, 0.125, 0.0625, 0.0625], dtype=np.float32))
+    first = np.zeros(5)
+    for _ in range(4000):
+        picks = hf_beam.draw_without_replacement(sc, rng.random(4, dtype=np.float32))
+        assert len(set(picks)) == 4
+        first[picks[0]] += 1
+    assert np.abs(first / first.sum() - np.exp(sc)).max() < 0.03
+
+
+def test_beam_hypotheses_bookkeeping():
+    h = hf_beam.BeamHypotheses(2, 0.0)
+    h.add(np.arange(3), -1.0, 3)
+    assert not h.is_done(-0.5, 5, 2)
+    h.add(np.arange(4), -3.0, 4)
+    assert h.worst_score == -3.0 and h.is_done(-3.5, 5, 2) and not h.is_done(-2.0, 5, 2)
+    h.add(np.arange(5), -2.0, 5)  # evicts the -3.0 hypothesis
+    assert sorted(s for s, _ in h.beams) == [-2.0, -1.0] and h.worst_score == -2.0
+    h.add(np.arange(6), -9.0, 6)  # worse than the worst: ignored
+    assert len(h) == 2
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_beam_sample_generate_matches_reference_fixture(gold, tag):
+    """oracle.gpt.beam_sample_generate (own GPT-2 stack + own warper restatement) against the fixture produced by the
+    reference's GPT2InferenceModel.forward / _reorder_cache + the installed transformers warpers (make_golden.ref_beam_sample),
+    same uniforms: token ids bit-exact."""
+    cfg = icfg.micro()
+    g = gold(f"micro_beam_{tag}")
+    w = ogpt.to_torch(synth.gpt_state_dict(cfg, 1234))
+    mel = torch.from_numpy(synth.prompt_mel(61, seed=7))
+    with torch.no_grad():
+        cond = ogpt.get_conditioning(mel, w, cfg.gpt)
+        out = ogpt.beam_sample_generate(cond, torch.from_numpy(g["text"]).long(), w, cfg.gpt, int(g["max_gen"]), num_beams=int(g["num_beams"]),
+                                        top_k=int(g["top_k"]), top_p=float(g["top_p"]), temperature=float(g["temperature"]),
+                                        uniforms=g["uniforms"])
+    assert np.array_equal(out.numpy(), g["codes"]), (out.numpy(), g["codes"])
