@@ -173,6 +173,11 @@ int itts_bigvgan(itts_engine* e, const void* latent, const float* spk, int B, in
 /* Q1  DiscreteVAE.decode (vqvae/xtts_dvae.py:332-351): codes host int32 [B, T] -> mel [B, 4T, channels] engine dtype */
 int itts_dvae_decode(itts_engine* e, const int32_t* codes_host, int B, int T, void* mel_out, itts_stream stream);
 
+/* DiscreteVAE.get_codebook_indices (vqvae/xtts_dvae.py:325-330; Quantize.forward distance arg-min :86-92):
+ * mel [B, T, channels] engine dtype -> codes host int32 [B, T'], T' = T halved (rounding up) once per stride-2 layer.
+ * Needs the encoder tensors of the checkpoint (dvae.enc* / dvae.erb* / dvae.eout / dvae.codebook_sq). Synchronises. */
+int itts_dvae_encode(itts_engine* e, const void* mel_btc, int B, int T, int32_t* codes_host, itts_stream stream);
+
 /* Debug/testing: copy a named intermediate of the LAST call into host memory (fp32), returns element count. */
 int64_t itts_debug_fetch(itts_engine* e, const char* name, float* out_host, int64_t max_elems);
 int itts_debug_enable(itts_engine* e, int on);

@@ -222,6 +222,11 @@ int itts_dvae_decode(itts_engine* e, const int32_t* codes_host, int B, int T, vo
   return e->e.dvae_decode(codes_host, B, T, mel_out, (hipStream_t)s);
 }
 
+int itts_dvae_encode(itts_engine* e, const void* mel_btc, int B, int T, int32_t* codes_host, itts_stream s) {
+  ENG(e);
+  return e->e.dvae_encode(mel_btc, B, T, codes_host, (hipStream_t)s);
+}
+
 int itts_debug_enable(itts_engine* e, int on) {
   ENG(e);
   e->e.debug = on & 1;

@@ -103,6 +103,12 @@ struct DvaeW {
   };
   std::vector<RB> rbs;
   std::vector<Lin> ups;
+  // encoder of get_codebook_indices (optional: only when the checkpoint carries it)
+  bool enc_ok = false;
+  std::vector<Lin> enc;   // stride-2 convs as 2-tap convs over paired rows
+  std::vector<RB> erbs;
+  Lin eout, quant;        // 1x1 to the codebook dim; quant = the codebook as a [tokens, dim] projection
+  const float* codebook_sq = nullptr;
 };
 
 struct DecodeState {
@@ -207,6 +213,7 @@ struct Engine {
                        int nseq, void* latent_out, hipStream_t s);
   int bigvgan(const void* latent, const float* spk, int B, int T, float* wav, hipStream_t s);
   int dvae_decode(const int32_t* codes, int B, int T, void* mel_out, hipStream_t s);
+  int dvae_encode(const void* mel, int B, int T, int32_t* codes_host, hipStream_t s);
 
   // internals
   int gpt_layers_full(float* h, int B, int S, const int* kv_start_dev, bool write_cache, hipStream_t s);

@@ -349,6 +349,30 @@ int Engine::finalize() {
     }
     dv.out_conv = r.lin("dvae.out", wdt, c.dv_channels, ci);
     dv.ok = true;
+    if (tensors.count("dvae.enc0.weight")) {
+      int cin = c.dv_channels;
+      for (int i = 0; i < c.dv_layers; ++i) {
+        const int co = c.dv_hidden << i;
+        dv.enc.push_back(r.lin("dvae.enc" + std::to_string(i), wdt, co, 2 * cin, 2));
+        cin = co;
+      }
+      for (int i = 0; i < c.dv_resblocks; ++i) {
+        const std::string p = "dvae.erb" + std::to_string(i) + ".";
+        DvaeW::RB b;
+        b.c0 = r.lin(p + "c0", wdt, inner, inner, 3);
+        b.c2 = r.lin(p + "c2", wdt, inner, inner, 3);
+        b.c4 = r.lin(p + "c4", wdt, inner, inner, 1);
+        dv.erbs.push_back(b);
+      }
+      dv.eout = r.lin("dvae.eout", wdt, c.dv_codebook, inner);
+      dv.quant = Lin();
+      dv.quant.w = dv.codebook;
+      dv.quant.N = c.dv_tokens;
+      dv.quant.Cin = c.dv_codebook;
+      dv.quant.dt = wdt;
+      dv.codebook_sq = r.f32("dvae.codebook_sq", {c.dv_tokens});
+      dv.enc_ok = true;
+    }
   }
   if (r.nerr) {
     set_error("finalize: " + r.err.str() + (r.nerr > 12 ? "(+" + std::to_string(r.nerr - 12) + " more)" : ""));

@@ -24,6 +24,55 @@ __global__ void embed_codes_kernel(T* __restrict__ y, const T* __restrict__ tabl
   for (int i = threadIdx.x; i < D; i += blockDim.x) y[(size_t)r * D + i] = table[(size_t)c * D + i];
 }
 
+// rows paired for a stride-2 convolution: y[b, t, :] = [x[b, 2t, :], x[b, 2t + 1, :]] (zero beyond the end)
+template <typename T>
+__global__ void pair_rows_kernel(T* __restrict__ y, const T* __restrict__ x, int Tin, int Tout, int C) {
+  const int r = blockIdx.x, b = r / Tout, t = r % Tout;
+  for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) {
+    const int tt = 2 * t + i / C;
+    y[(size_t)r * 2 * C + i] = tt < Tin ? x[((size_t)b * Tin + tt) * C + (i % C)] : (T)0.f;
+  }
+}
+
+// Quantize.forward's code choice (xtts_dvae.py:86-89): argmax_n -(|x|^2 - 2 x.e_n + |e_n|^2) = argmin_n (|e_n|^2 - 2 x.e_n),
+// the first index on ties
+__global__ __launch_bounds__(256) void dvae_argmin_kernel(int* __restrict__ codes, const float* __restrict__ dots,
+                                                          const float* __restrict__ esq, int N) {
+  __shared__ float sv[4];
+  __shared__ int si[4];
+  const int r = blockIdx.x, tid = threadIdx.x;
+  float best = INFINITY;
+  int bi = 0x7fffffff;
+  for (int n = tid; n < N; n += 256) {
+    const float d = esq[n] - 2.f * dots[(size_t)r * N + n];
+    if (d < best || (d == best && n < bi)) {
+      best = d;
+      bi = n;
+    }
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(best, o, 64);
+    const int oi = __shfl_xor(bi, o, 64);
+    if (ov < best || (ov == best && oi < bi)) {
+      best = ov;
+      bi = oi;
+    }
+  }
+  if ((tid & 63) == 0) {
+    sv[tid >> 6] = best;
+    si[tid >> 6] = bi;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    for (int w = 1; w < 4; ++w)
+      if (sv[w] < best || (sv[w] == best && si[w] < bi)) {
+        best = sv[w];
+        bi = si[w];
+      }
+    codes[r] = bi;
+  }
+}
+
 }  // namespace
 
 #define K(call)               \
@@ -381,6 +430,86 @@ int Engine::dvae_decode(const int32_t* codes_host, int B, int T, void* mel_out, 
   };
   ITTS_TRY(two_pass(body, s));
   ITTS_HIP_CHECK(hipStreamSynchronize(s));
+  return OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// DVAE encoder: DiscreteVAE.get_codebook_indices (vqvae/xtts_dvae.py:325-330) = encoder (strided convs + ReLU,
+// ResBlocks, 1x1 conv, :251-291) then Quantize.forward's nearest-code search (:86-92).  mel [B, T, channels] in the
+// engine dtype -> codes int32 [B, T'] on the host, T' = ceil(ceil(T / 2) / 2) for the two stride-2 layers.
+// ------------------------------------------------------------------------------------------------
+int Engine::dvae_encode(const void* mel, int B, int T, int32_t* codes_host, hipStream_t s) {
+  if (!finalized || !dv.ok || !dv.enc_ok) {
+    set_error("dvae_encode: DVAE encoder weights not bound");
+    return E_STATE;
+  }
+  const itts_config& c = cfg;
+  ITTS_REQUIRE(mel && codes_host && B > 0 && T > 0, "dvae_encode: bad arguments");
+  const int inner = c.dv_hidden << (c.dv_layers - 1);
+  auto conv1d = [&](void* out, int tc, const void* in, const Lin& w, int Tn, int act, const void* R, int pad_left) -> int {
+    GemmArgs g;
+    g.A = in;
+    g.W = w.w;
+    g.C = out;
+    g.M = B * Tn;
+    g.N = w.N;
+    g.Cin = w.Cin;
+    g.taps = w.taps;
+    g.lda = w.Cin;
+    g.ldc = w.N;
+    g.T = Tn;
+    g.pad_left = pad_left;
+    g.bias = w.b;
+    g.act = act;
+    g.R = R;
+    g.ldr = w.N;
+    return conv(g, adt, w.dt, tc, s);
+  };
+  int Tout = T;
+  for (int i = 0; i < c.dv_layers; ++i) Tout = (Tout + 1) / 2;
+  auto body = [&]() -> int {
+    const void* cur = mel;
+    int Tn = T, C = c.dv_channels;
+    for (int i = 0; i < c.dv_layers; ++i) {
+      const int Tp = (Tn + 1) / 2;
+      void* pr = alloc((size_t)B * Tp * 2 * C * es);
+      if (!dry) {
+        if (adt == F32)
+          hipLaunchKernelGGL(pair_rows_kernel<float>, dim3(B * Tp), dim3(256), 0, s, (float*)pr, (const float*)cur, Tn, Tp, C);
+        else
+          hipLaunchKernelGGL(pair_rows_kernel<bf16_t>, dim3(B * Tp), dim3(256), 0, s, (bf16_t*)pr, (const bf16_t*)cur, Tn, Tp, C);
+        ITTS_HIP_CHECK(hipGetLastError());
+      }
+      void* o = alloc((size_t)B * Tp * dv.enc[i].N * es);
+      ITTS_TRY(conv1d(o, adt, pr, dv.enc[i], Tp, ACT_RELU, nullptr, 1));  // taps (pair t-1, pair t)
+      cur = o;
+      Tn = Tp;
+      C = dv.enc[i].N;
+    }
+    void* x = const_cast<void*>(cur);
+    void* y1 = alloc((size_t)B * Tn * inner * es);
+    void* y2 = alloc((size_t)B * Tn * inner * es);
+    for (int i = 0; i < c.dv_resblocks; ++i) {
+      const DvaeW::RB& rb = dv.erbs[i];
+      ITTS_TRY(conv1d(y1, adt, x, rb.c0, Tn, ACT_RELU, nullptr, 1));
+      ITTS_TRY(conv1d(y2, adt, y1, rb.c2, Tn, ACT_RELU, nullptr, 1));
+      ITTS_TRY(conv1d(x, adt, y2, rb.c4, Tn, ACT_NONE, x, 0));
+    }
+    void* z = alloc((size_t)B * Tn * c.dv_codebook * es);
+    ITTS_TRY(conv1d(z, adt, x, dv.eout, Tn, ACT_NONE, nullptr, 0));
+    float* dots = (float*)alloc((size_t)B * Tn * c.dv_tokens * 4);
+    ITTS_TRY(conv1d(dots, F32, z, dv.quant, Tn, ACT_NONE, nullptr, 0));
+    int* codes_dev = (int*)alloc((size_t)B * Tn * 4);
+    if (!dry) {
+      hipLaunchKernelGGL(dvae_argmin_kernel, dim3(B * Tn), dim3(256), 0, s, codes_dev, dots, dv.codebook_sq, c.dv_tokens);
+      ITTS_HIP_CHECK(hipGetLastError());
+      ITTS_HIP_CHECK(hipMemcpyAsync(codes_host, codes_dev, (size_t)B * Tn * 4, hipMemcpyDeviceToHost, s));
+    }
+    return OK;
+  };
+  ITTS_TRY(two_pass(body, s));
+  ITTS_HIP_CHECK(hipStreamSynchronize(s));
+  (void)Tout;
   return OK;
 }
 

@@ -2,7 +2,9 @@
 (/root/reference/indextts/utils/feature_extractors.py:24-50: torchaudio MelSpectrogram(24 kHz, n_fft 1024, hop 256,
 100 mels, center=True, power=1) followed by safe_log(clip 1e-7)).  torchaudio is not a dependency here: the STFT is
 torch.stft and the filterbank is the HTK-scale, un-normalised triangular bank torchaudio builds by default.
-Runs once per prompt on the host (parity is checked analytically, torchaudio being absent)."""
+`resample` restates torchaudio.transforms.Resample's published algorithm (Hann-windowed sinc polyphase bank).
+Runs once per prompt on the host (torchaudio is absent offline, so parity is pinned analytically in
+tests/test_host_logic.py - filterbank / STFT identities, resampler tone and DC tests - not against torchaudio outputs)."""
 from __future__ import annotations
 
 import math
@@ -62,11 +64,35 @@ def load_wav_mono(path: str):
     return x.unsqueeze(0), int(sr)
 
 
+def sinc_resample_kernel(orig_freq: int, new_freq: int, lowpass_filter_width: int = 6, rolloff: float = 0.99):
+    """The polyphase windowed-sinc bank of torchaudio.transforms.Resample (defaults: "sinc_interp_hann",
+    lowpass_filter_width 6, rolloff 0.99), which infer.py:88 applies to the prompt: for each of the new_freq output phases
+    a Hann-windowed sinc low-pass at rolloff * min(orig, new) / 2, evaluated in float64 and stored as float32.
+    Returns (kernels [new, 1, 2 * width + orig], width) for rates already divided by their gcd."""
+    base = min(orig_freq, new_freq) * rolloff
+    width = math.ceil(lowpass_filter_width * orig_freq / base)
+    idx = torch.arange(-width, width + orig_freq, dtype=torch.float64)[None, None] / orig_freq
+    t = torch.arange(0, -new_freq, -1, dtype=torch.float64)[:, None, None] / new_freq + idx
+    t = (t * base).clamp_(-lowpass_filter_width, lowpass_filter_width)
+    window = torch.cos(t * math.pi / lowpass_filter_width / 2) ** 2
+    t = t * math.pi
+    kernels = torch.where(t == 0, torch.ones_like(t), t.sin() / t) * window * (base / orig_freq)
+    return kernels.to(torch.float32), width
+
+
 def resample(x: torch.Tensor, sr: int, new_sr: int) -> torch.Tensor:
+    """torchaudio.transforms.Resample(sr, new_sr)(x) for x [channels, n] (infer.py:88): zero-pad by the filter half-width,
+    strided convolution with the polyphase bank, interleave the phases, cut to ceil(new * n / orig) samples."""
     if sr == new_sr:
         return x
-    from scipy.signal import resample_poly
-
-    g = math.gcd(sr, new_sr)
-    y = resample_poly(x.numpy(), new_sr // g, sr // g, axis=-1)
-    return torch.from_numpy(y.astype("float32"))
+    g = math.gcd(int(sr), int(new_sr))
+    orig, new = int(sr) // g, int(new_sr) // g
+    kernels, width = sinc_resample_kernel(orig, new)
+    shape = x.shape
+    w = x.reshape(-1, shape[-1]).float()
+    n = w.shape[-1]
+    w = torch.nn.functional.pad(w, (width, width + orig))
+    y = torch.nn.functional.conv1d(w[:, None], kernels, stride=orig)
+    y = y.transpose(1, 2).reshape(w.shape[0], -1)
+    target = int(math.ceil(new * n / orig))
+    return y[..., :target].reshape(*shape[:-1], target)

@@ -330,6 +330,17 @@ class Engine:
         spk.record_stream(self.stream)
         return out
 
+    def dvae_encode(self, mel_bct: torch.Tensor) -> np.ndarray:
+        """DiscreteVAE.get_codebook_indices: mel [B, channels, T] (reference layout) -> codes int64 [B, T']."""
+        mel = self.to_act(mel_bct.transpose(1, 2))
+        B, T, _ = mel.shape
+        Tc = _dvae_code_len(T, self.ccfg.dv_layers)
+        codes = np.empty((B, Tc), dtype=np.int32)
+        self._enter()
+        L.check(self.lib.itts_dvae_encode(self.h, mel.data_ptr(), B, T, codes.ctypes.data_as(C.c_void_p), self._s()), "dvae_encode")
+        self._exit()
+        return codes.astype(np.int64)
+
     def bigvgan_grouped(self, lats: List[torch.Tensor], spk: torch.Tensor) -> List[torch.Tensor]:
         """Vocoder over several sentences: latents [1, T_i, D] of EQUAL length share one batched launch sequence (rows of
         a batch are independent, so each result equals its batch-1 run); ragged lengths cannot be padded - the convs
@@ -358,6 +369,12 @@ class Engine:
         L.check(self.lib.itts_dvae_decode(self.h, c.ctypes.data_as(C.c_void_p), B, T, out.data_ptr(), self._s()), "dvae_decode")
         self._exit()
         return out.transpose(1, 2)
+
+
+def _dvae_code_len(T: int, layers: int) -> int:
+    for _ in range(layers):
+        T = (T + 1) // 2
+    return T
 
 
 def build_engine(cfg, dtype: str = "bf16", device: str = "cuda:0", seed: int = 1234, parts=("gpt", "bigvgan", "dvae"),

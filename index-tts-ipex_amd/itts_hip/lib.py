@@ -83,6 +83,7 @@ _PROTOS = {
     "itts_gpt_latent_batch": (i32, [vp, vp, vp, vp, vp, vp, i32, vp, vp]),
     "itts_bigvgan": (i32, [vp, vp, vp, i32, i32, vp, vp]),
     "itts_dvae_decode": (i32, [vp, vp, i32, i32, vp, vp]),
+    "itts_dvae_encode": (i32, [vp, vp, i32, i32, vp, vp]),
     "itts_debug_fetch": (i64, [vp, C.c_char_p, vp, i64]),
     "itts_debug_enable": (i32, [vp, i32]),
 }

@@ -261,6 +261,29 @@ def pack_dvae(sd: Dict[str, np.ndarray], cfg) -> Packed:
         idx += 1
     P["dvae.out.weight"] = ("w", conv_w(sd[f"decoder.{idx}.weight"]))
     P["dvae.out.bias"] = ("f", sd[f"decoder.{idx}.bias"])
+    if "encoder.0.0.weight" in sd:  # get_codebook_indices (xtts_dvae.py:325-330); absent from decoder-only checkpoints
+        assert v["kernel_size"] == 3 and v.get("stride", 2) == 2, "DVAE encoder packer: kernel 3 / stride 2 only"
+        idx = 0
+        for i in range(v["num_layers"]):
+            # Conv1d(k=3, stride=2, pad=1) == a 2-tap stride-1 conv over PAIRED input rows [x[2t], x[2t+1]] (2*Cin channels,
+            # one zero pair of left padding): out[t] = w0 x[2t-1] + w1 x[2t] + w2 x[2t+1]
+            w = sd[f"encoder.{idx}.0.weight"]
+            co, ci, _ = w.shape
+            w2 = np.zeros((co, 2, 2 * ci), dtype=np.float32)
+            w2[:, 0, ci:] = w[:, :, 0]
+            w2[:, 1, :ci] = w[:, :, 1]
+            w2[:, 1, ci:] = w[:, :, 2]
+            P[f"dvae.enc{i}.weight"] = ("w", w2.reshape(co, 4 * ci))
+            P[f"dvae.enc{i}.bias"] = ("f", sd[f"encoder.{idx}.0.bias"])
+            idx += 1
+        for i in range(v["num_resnet_blocks"]):
+            for a, b in (("c0", 0), ("c2", 2), ("c4", 4)):
+                P[f"dvae.erb{i}.{a}.weight"] = ("w", conv_w(sd[f"encoder.{idx}.net.{b}.weight"]))
+                P[f"dvae.erb{i}.{a}.bias"] = ("f", sd[f"encoder.{idx}.net.{b}.bias"])
+            idx += 1
+        P["dvae.eout.weight"] = ("w", conv_w(sd[f"encoder.{idx}.weight"]))
+        P["dvae.eout.bias"] = ("f", sd[f"encoder.{idx}.bias"])
+        P["dvae.codebook_sq"] = ("f", (sd["codebook.embed"].astype(np.float32) ** 2).sum(0))  # |e_n|^2 of Quantize.forward's distance
     return P
 
 

@@ -202,7 +202,8 @@ def bigvgan_state_dict(cfg, seed: int = 1234) -> Dict[str, np.ndarray]:
 
 
 def dvae_state_dict(cfg, seed: int = 1234) -> Dict[str, np.ndarray]:
-    """Decoder-side tensors of DiscreteVAE (xtts_dvae.py:251-291); encoder is out of scope (SURVEY 8f #4)."""
+    """DiscreteVAE tensors (xtts_dvae.py:251-291): decoder + codebook (Q1) and the encoder of get_codebook_indices
+    (SURVEY 8f #4: strided convs, ResBlocks, 1x1 to the codebook dim)."""
     v = cfg["vqvae"]
     b = _B(seed, "dvae/")
     hid, cb, nl = v["hidden_dim"], v["codebook_dim"], v["num_layers"]
@@ -223,6 +224,17 @@ def dvae_state_dict(cfg, seed: int = 1234) -> Dict[str, np.ndarray]:
         idx += 1
     b.lin(f"decoder.{idx}", v["channels"], dec[-1], extra=(1,))
     b.t("codebook.embed", (cb, v["num_tokens"]), std=1.0)
+    enc = [v["channels"]] + chans
+    idx = 0
+    for ci, co in zip(enc[:-1], enc[1:]):
+        b.lin(f"encoder.{idx}.0", co, ci, extra=(v["kernel_size"],))
+        idx += 1
+    for _ in range(v["num_resnet_blocks"]):
+        b.lin(f"encoder.{idx}.net.0", inner, inner, extra=(3,))
+        b.lin(f"encoder.{idx}.net.2", inner, inner, extra=(3,))
+        b.lin(f"encoder.{idx}.net.4", inner, inner, gain=0.5, extra=(1,))
+        idx += 1
+    b.lin(f"encoder.{idx}", cb, inner, gain=4.0, extra=(1,))  # spread the codes: |x| comparable to the codebook rows
     return b.build()
 
 

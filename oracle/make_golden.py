@@ -81,7 +81,7 @@ def build_ref_dvae(cfg, seed):
     assert not [k for k in sd if k not in ref_sd]
     for k in sd:
         assert tuple(sd[k].shape) == tuple(ref_sd[k].shape), (k, sd[k].shape, ref_sd[k].shape)
-    dec_keys = [k for k in ref_sd if k.startswith("decoder.") or k == "codebook.embed"]
+    dec_keys = [k for k in ref_sd if k.startswith("decoder.") or k.startswith("encoder.") or k == "codebook.embed"]
     assert set(dec_keys) == set(sd), sorted(set(dec_keys) ^ set(sd))[:10]
     m.load_state_dict(sd, strict=False)
     return m
@@ -297,6 +297,13 @@ def micro_fixtures():
     dcodes = torch.from_numpy(prng.randint("dvae.codes", 5, 2 * 9, 0, cfg.vqvae.num_tokens)).view(2, 9)
     out, _ = dv.decode(dcodes)
     save("micro_dvae", codes=dcodes, mel=out)
+    # get_codebook_indices (encoder + Quantize arg-min): even, odd and tiny lengths
+    enc = {}
+    for tag, (B_, T_) in {"a": (2, 36), "b": (1, 37), "c": (1, 5)}.items():
+        m = rnd(f"dvae.enc.mel.{tag}", (B_, cfg.vqvae.channels, T_), std=2.0, mean=-4.0)
+        enc[f"mel_{tag}"] = m
+        enc[f"codes_{tag}"] = dv.get_codebook_indices(m)
+    save("micro_dvae_encode", **enc)
 
     print("[micro] beam-sample (the reference's default kwargs: 3 beams, top_k 30, top_p 0.8)")
     rng = np.random.default_rng(2024)
@@ -455,8 +462,64 @@ def fast_fixtures():
          max_mel_tokens=max_mel, bucket_size=2, bucket_order=np.asarray([x["idx"] for bk in buckets for x in bk]))
 
 
+def front_fixtures():
+    """Known answers of the reference's text front end (indextts/utils/front.py, utils/common.py): sentence splitting on
+    token lists, CJK pre-tokenisation, and TextNormalizer.normalize with the third-party written-form normalisers replaced
+    by identity stubs (WeTextProcessing is absent offline) - i.e. everything the reference itself implements."""
+    import json
+    import random
+
+    from indextts.utils import common as rcommon
+    from indextts.utils.front import TextNormalizer, TextTokenizer
+
+    rnd_ = random.Random(20241004)
+    alphabet = ["▁A", "B", "C", "▁D", "E", ",", "▁,", ".", "▁.", "!", "?", "▁?", "▁...", "-", "'", "▁'", "F", "G", "▁H"]
+    weights = [6, 6, 6, 6, 6, 3, 1, 2, 1, 1, 1, 1, 1, 2, 1, 1, 6, 6, 6]
+    splits = []
+    for case in range(60):
+        n = rnd_.choice([0, 1, 3, 7, 20, 45, 90, 200])
+        toks = rnd_.choices(alphabet, weights=weights, k=n)
+        cap = rnd_.choice([4, 8, 15, 30, 120])
+        import warnings
+
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            out = TextTokenizer.split_sentences_by_token(list(toks), TextTokenizer.punctuation_marks_tokens, cap)
+        splits.append({"tokens": toks, "cap": cap, "out": out})
+
+    class Ident:
+        def normalize(self, t):
+            return t
+
+    tn = TextNormalizer()
+    tn.zh_normalizer, tn.en_normalizer = Ident(), Ident()
+    texts = ["IndexTTS 正式发布1.0版本了，效果666", "晕XUAN4是一种GAN3觉", "我爱你！", "I love you!", "what's up? it's fine: ok; (yes) [no]",
+             "“我爱你”的英语是“I love you”", "2.5平方电线", "共465篇，约315万字", "2002年的第一场雪，下在了2003年", "速度是10km/h",
+             "现在是北京时间2025年01月11日 20:00", "他这条裤子是2012年买的，花了200块钱", "电话：135-4567-8900", "1键3连",
+             "他这条视频点赞3000+，评论1000+，收藏500+", "这是1024元的手机，你要吗？", "受不liao3你了", "“衣裳”不读衣chang2，而是读衣shang5",
+             "最zhong4要的是：不要chong2蹈覆辙", "不zuo1死就不会死", "See you at 8:00 AM", "8:00 AM 开会", "Couting down 3, 2, 1, go!",
+             "数到3就开始：1、2、3", "This sales for 2.5% off, only $12.5.", "5G网络是4G网络的升级版，2G网络是3G网络的前身",
+             "苹果于2030/1/2发布新 iPhone 2X 系列手机，最低售价仅 ¥12999", "这酒...里...有毒...", "只有,,,才是最好的", "babala2是什么？",
+             "用beta1测试", "have you ever been to beta2?", "such as XTTS, CosyVoice2, Fish-Speech, and F5-TTS", "where's the money?",
+             "who's there?", "which's the best?", "how's it going?", "今天是个好日子 it's a good day", "约瑟夫·高登-莱维特（Joseph Gordon-Levitt is an American actor）",
+             "蒂莫西·唐纳德·库克（英文名：Timothy Donald Cook），通称蒂姆·库克（Tim Cook），美国商业经理、工业工程师和工业开发商，现任苹果公司首席执行官。",
+             "《盗梦空间》是由美国华纳兄弟影片公司出品的电影，由克里斯托弗·诺兰执导并编剧", "jv2 que4 xün1 ju3", "test@example.com", "   ", "a"]
+    norm = [{"text": t, "use_chinese": tn.use_chinese(t), "out": tn.normalize(t)} for t in texts]
+    pin = [{"in": p, "out": tn.correct_pinyin(p)} for p in ["ju2", "que4", "xün1", "jUan3", "qu5", "xue2", "lv3", "nü3", "zhong4", "Ju1"]]
+    cjk = [{"in": t, "tok": rcommon.tokenize_by_CJK_char(t), "tok_keep": rcommon.tokenize_by_CJK_char(t, do_upper_case=False)}
+           for t in ["你好世界是 hello world 的中文", "  a b  ", "안녕 hello こんにちは", "abc", "", "３Ｄ打印 ｶﾀｶﾅ"]]
+    detok = [{"in": t, "out": rcommon.de_tokenized_by_CJK_char(t), "out_lower": rcommon.de_tokenized_by_CJK_char(t, do_lower_case=True)}
+             for t in ["你 好 世 界 是 HELLO WORLD 的 中 文", "SEE YOU!", "A-B 你 C D", ""]]
+    os.makedirs(GOLD, exist_ok=True)
+    path = os.path.join(GOLD, "front_cases.json")
+    with open(path, "w", encoding="utf-8") as f:
+        json.dump({"splits": splits, "normalize": norm, "correct_pinyin": pin, "cjk": cjk, "detok": detok}, f, ensure_ascii=False, indent=0)
+    print(f"  wrote {path} ({os.path.getsize(path) / 1024:.1f} KiB)")
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
+    ap.add_argument("--front", action="store_true")
     ap.add_argument("--long", action="store_true")
     ap.add_argument("--fast", action="store_true")
     ap.add_argument("--full", action="store_true")
@@ -468,6 +531,8 @@ if __name__ == "__main__":
         micro_fixtures()
     if a.full:
         full_fixtures()
+    if a.front:
+        front_fixtures()
     if a.fast:
         fast_fixtures()
     if a.long:

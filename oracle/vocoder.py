@@ -203,3 +203,25 @@ def dvae_decode(codes, w: W, v):
         x = F.relu(F.conv1d(x, w[f"decoder.{idx}.0.conv.weight"], w[f"decoder.{idx}.0.conv.bias"], padding=pad))
         idx += 1
     return F.conv1d(x, w[f"decoder.{idx}.weight"], w[f"decoder.{idx}.bias"])
+
+
+def dvae_encode(mel_bct, w: W, v):
+    """vqvae/xtts_dvae.py:325-330 DiscreteVAE.get_codebook_indices (positional_dims 1, no normalization): encoder =
+    num_layers x (Conv1d(k, stride 2, pad (k-1)//2) + ReLU) -> ResBlocks -> 1x1 conv (:251-291); Quantize.forward :86-89:
+    dist = |x|^2 - 2 x E + |E|^2, codes = argmax(-dist).  mel [B,channels,T] -> codes [B,T']."""
+    x = mel_bct
+    pad = (v["kernel_size"] - 1) // 2
+    idx = 0
+    for _ in range(v["num_layers"]):
+        x = F.relu(F.conv1d(x, w[f"encoder.{idx}.0.weight"], w[f"encoder.{idx}.0.bias"], stride=2, padding=pad))
+        idx += 1
+    for _ in range(v["num_resnet_blocks"]):
+        y = F.relu(F.conv1d(x, w[f"encoder.{idx}.net.0.weight"], w[f"encoder.{idx}.net.0.bias"], padding=1))
+        y = F.relu(F.conv1d(y, w[f"encoder.{idx}.net.2.weight"], w[f"encoder.{idx}.net.2.bias"], padding=1))
+        x = F.conv1d(y, w[f"encoder.{idx}.net.4.weight"], w[f"encoder.{idx}.net.4.bias"]) + x
+        idx += 1
+    x = F.conv1d(x, w[f"encoder.{idx}.weight"], w[f"encoder.{idx}.bias"]).permute(0, 2, 1)
+    flat = x.reshape(-1, x.shape[-1])
+    E = w["codebook.embed"]
+    dist = flat.pow(2).sum(1, keepdim=True) - 2 * flat @ E + E.pow(2).sum(0, keepdim=True)
+    return (-dist).max(1)[1].view(*x.shape[:-1])

@@ -143,6 +143,10 @@ def test_dropin_misc(tts, gold, tmp_path):
     g = gold("micro_dvae")
     mel, _ = DiscreteVAE(tts.engine).decode(torch.from_numpy(g["codes"]))
     assert float((mel.float().cpu() - torch.from_numpy(g["mel"])).abs().max()) < 1e-4 * float(np.abs(g["mel"]).max())
+    ge = gold("micro_dvae_encode")
+    for tag in "abc":  # get_codebook_indices: integer-exact against the reference (even / odd / tiny lengths)
+        codes = DiscreteVAE(tts.engine).get_codebook_indices(torch.from_numpy(ge[f"mel_{tag}"]))
+        assert codes.dtype == torch.int64 and np.array_equal(codes.cpu().numpy(), ge[f"codes_{tag}"]), tag
     calls = []
     tts.set_gr_progress_callback(lambda v, d: calls.append(v))
     out = tts.infer_fast(prompt_mel=torch.from_numpy(synth.prompt_mel(61, seed=7)), text=[[5, 6, 7, 8, 9]],

@@ -85,3 +85,56 @@ def test_packed_micro_matches_engine_contract():
     B = pack.pack_bigvgan(synth.bigvgan_state_dict(cfg, 1), cfg)
     assert B["bv.ups.0.weight"][1].shape[0] == cfg.bigvgan.upsample_rates[0]
     assert B["bv.filter"][1].shape == (12,) and abs(float(B["bv.filter"][1].sum()) - 1) < 1e-6
+
+
+def test_sinc_resampler_is_torchaudio_shaped():
+    """The prompt resampler (infer.py:88 torchaudio.transforms.Resample defaults: Hann-windowed sinc, width 6, rolloff
+    0.99), pinned analytically since torchaudio is absent: output length ceil(new * n / orig), unit DC gain, a tone well
+    below both Nyquists comes out as the same tone, a tone above the new Nyquist is removed, same rate = identity."""
+    import math
+
+    import torch
+
+    from indextts.utils.feature_extractors import resample, sinc_resample_kernel
+
+    k, width = sinc_resample_kernel(2, 3)
+    assert k.shape == (3, 1, 2 * width + 2) and k.dtype == torch.float32 and width == math.ceil(6 * 2 / (2 * 0.99))
+    assert torch.allclose(k.sum(dim=(1, 2)), torch.ones(3), atol=2e-3)  # every phase has unit DC gain
+    for sr, new in ((16000, 24000), (44100, 24000), (48000, 24000), (22050, 24000)):
+        n = sr // 4 + 13
+        t = torch.arange(n, dtype=torch.float64) / sr
+        x = torch.sin(2 * math.pi * 440.0 * t).float()[None]
+        y = resample(x, sr, new)
+        assert y.shape == (1, math.ceil(new * n / sr))
+        tt = torch.arange(y.shape[1], dtype=torch.float64) / new
+        want = torch.sin(2 * math.pi * 440.0 * tt).float()
+        m = slice(200, y.shape[1] - 200)
+        assert float((y[0, m] - want[m]).abs().max()) < 2e-3, (sr, new)
+        dc = resample(torch.ones(1, n), sr, new)
+        assert float((dc[0, m] - 1).abs().max()) < 2e-3
+    hi = torch.sin(2 * math.pi * 15000.0 * torch.arange(48000, dtype=torch.float64) / 48000).float()[None]
+    assert float(resample(hi, 48000, 24000)[0, 300:-300].abs().max()) < 1e-2  # above the 12 kHz Nyquist: gone
+    x = torch.randn(2, 1000)
+    assert resample(x, 24000, 24000) is x
+
+
+def test_mel_front_end_shapes_and_bank():
+    """MelSpectrogramFeatures (feature_extractors.py:24-50): 511 frames for the 130 560-sample prompt of SURVEY 8 (center
+    padding: 1 + n // hop), HTK triangular bank with unit peaks that covers 0..12 kHz, log clip at 1e-7."""
+    import math
+
+    import torch
+
+    from indextts.utils.feature_extractors import MelSpectrogramFeatures, mel_filterbank
+
+    fe = MelSpectrogramFeatures()
+    mel = fe(torch.zeros(1, 130560))
+    assert mel.shape == (1, 100, 511) and torch.allclose(mel, torch.full_like(mel, math.log(1e-7)))
+    fb = mel_filterbank(513, 0.0, 12000.0, 100, 24000)
+    assert fb.shape == (513, 100) and float(fb.min()) >= 0.0 and float(fb.max()) <= 1.0 + 1e-6
+    peaks = fb.argmax(0)
+    assert bool((peaks[1:] > peaks[:-1]).all())  # centre frequencies increase
+    tone = torch.sin(2 * math.pi * 3000.0 * torch.arange(24000) / 24000)[None]
+    m = fe(tone)[0, :, 20]
+    f_pts = 700.0 * (10.0 ** (torch.linspace(0, 2595.0 * math.log10(1 + 12000.0 / 700.0), 102) / 2595.0) - 1.0)
+    assert abs(float(f_pts[1 + int(m.argmax())]) - 3000.0) < 150.0  # the loudest band sits on the tone

@@ -134,6 +134,14 @@ def test_dvae(gold):
     close(mel, g["mel"])
 
 
+def test_dvae_encode(gold):
+    g = gold("micro_dvae_encode")
+    w = ogpt.to_torch(synth.dvae_state_dict(CFG, 1234))
+    for tag in "abc":
+        codes = ovoc.dvae_encode(torch.from_numpy(g[f"mel_{tag}"]), w, CFG.vqvae)
+        assert np.array_equal(codes.numpy(), g[f"codes_{tag}"]), tag
+
+
 def test_remove_long_silence(gold):
     g = gold("silence_cases")
     for i in range(int(g["n"])):
