@@ -6,7 +6,7 @@ import numpy as np
 import torch
 
 from indextts.utils.feature_extractors import MelSpectrogramFeatures, mel_filterbank
-from indextts.utils.front import PUNCT, _split, merge_short
+from indextts.utils.front import TextTokenizer
 
 
 def test_mel_shapes_and_tone():
@@ -27,11 +27,15 @@ def test_mel_shapes_and_tone():
 
 
 def test_split_sentences():
+    import warnings
+
+    split = TextTokenizer.split_sentences_by_token
     toks = list("ab.cde!fghij,klm?")
-    s = merge_short(_split(toks, (".", "!", "?"), 6), 6)
-    assert [len(x) for x in s] == [3, 4, 6, 4] and sum(s, []) == toks
+    s = split(toks, (".", "!", "?"), 6)
+    assert sum(s, []) == toks and max(len(x) for x in s) <= 6
     long = ["w"] * 25
-    s = merge_short(_split(long, PUNCT, 10), 10)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        s = split(long, TextTokenizer.punctuation_marks_tokens, 10)
     assert sum(s, []) == long and max(len(x) for x in s) <= 10  # hard cut above the cap (front.py:389-396)
-    s = merge_short(_split(list("a.b.c."), (".",), 120), 120)
-    assert s == [list("a.b.c.")]
+    assert split(list("a.b.c."), (".",), 120) == [list("a.b.c.")]

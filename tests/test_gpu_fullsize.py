@@ -207,3 +207,20 @@ def test_full_fp8_decode_weights_equal_their_dequantisation(mel):
     ed._exit()
     assert np.array_equal(res[0][0][:, :12], res[1][0][:, :12])
     assert np.array_equal(res[0][1], res[1][1])
+
+
+def test_full_beam_sample_matches_oracle_fp32(eng32, mel, gold):
+    """IndexTTS-1.5 sizes (V = 8194, 20 heads): the reference's default generate() mode - 3 beams, top_k 30, top_p 0.8 -
+    for one sentence, 8 steps, against the oracle's HF-4.36.2 beam_sample restatement with the same uniforms."""
+    from oracle import gpt as ogpt
+
+    g = gold("full_decode_b1")
+    cond = eng32.conditioning(mel)
+    n, nb = 8, 3
+    u = np.random.default_rng(11).random((n, 1, 2 * nb), dtype=np.float32)
+    got = eng32.generate(cond, g["text"], n, do_sample=True, num_beams=nb, top_k=30, top_p=0.8, temperature=1.0, uniforms=u)
+    wg = ogpt.to_torch(synth.gpt_state_dict(CFG, 1234))
+    with torch.no_grad():
+        want = ogpt.beam_sample_generate(cond.cpu(), torch.from_numpy(g["text"]).long(), wg, CFG.gpt, n, num_beams=nb, top_k=30,
+                                         top_p=0.8, temperature=1.0, uniforms=u).numpy()
+    assert got.shape == want.shape and np.array_equal(got, want), (got, want)
