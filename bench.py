@@ -96,12 +96,30 @@ def cpu_baseline(cfg, a):
     from oracle import vocoder as ovoc
     from itts_hip.config import ecapa_dims
 
-    # the box's CPU share, not the host's core count (an 8-GPU host exposes >100 cores to os.cpu_count())
+    # "all cores" = the box's CPU SHARE, not the host's core count: an 8-GPU host shows 256 CPUs to os.cpu_count() and to
+    # sched_getaffinity while a one-GPU box may use 16 of them (256 torch threads on 16 CPUs took 41 s for a 0.2 s phase)
     try:
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         cores = os.cpu_count() or 1
-    cores = max(1, min(cores, int(os.environ.get("ITTS_CPU_BASELINE_THREADS", str(cores)))))  # all cores of the box's share
+    limited = False
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    cores, limited = min(cores, max(1, int(float(txt[0]) / float(txt[1]) + 0.5))), True
+            else:
+                q = float(txt[0])
+                per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    cores, limited = min(cores, max(1, int(q / per + 0.5))), True
+            break
+        except Exception:
+            continue
+    if not limited and cores > 32:
+        cores = 16  # no quota visible: the documented share of a one-GPU box
+    cores = max(1, int(os.environ.get("ITTS_CPU_BASELINE_THREADS", str(cores))))
     torch.set_num_threads(cores)
     print(f"[cpu_baseline] oracle on {cores} threads ...", file=sys.stderr, flush=True)
     g = cfg["gpt"]

@@ -136,6 +136,11 @@ int itts_gpt_set_sampling(itts_engine* e, int do_sample, int top_k, float top_p,
 int itts_gpt_set_beam_sample(itts_engine* e, int num_beams, int top_k, float top_p, float temperature, const float* uniforms_host,
                              int64_t n_uniforms);
 
+/* `typical_sampling=True` of UnifiedVoice.inference_speech (gpt/model.py:690-697): the reference's TypicalLogitsWarper
+ * (utils/typical_sampling.py:9-30, mass in (0, 1); min_tokens_to_keep 2 under beams, else 1) runs right after the repetition
+ * penalty and before Temperature / TopK / TopP in the sampling and beam-sample modes.  mass = 0 switches it off. */
+int itts_gpt_set_typical(itts_engine* e, float mass);
+
 /* Forced tokens for the first n steps of every following generation (n = 0 clears): ids_host int32 [B, n] (B = 1 is
  * broadcast to every row; -1 = leave that step free).  This is the `input_tokens` continuation of
  * UnifiedVoice.inference_speech (gpt/model.py:672-686: given mel tokens are appended to the prompt and generation

@@ -73,14 +73,17 @@ __global__ __launch_bounds__(1024) void beam_sample_kernel(BeamArgs a) {
     for (int r = 0; r < nb; ++r) {
       const int row = bi * nb + r;
       const float* __restrict__ lg = a.logits + (size_t)row * V;
-      // ---- log_softmax ----
-      float mx = -INFINITY;
-      for (int i = tid; i < V; i += 1024) mx = fmaxf(mx, lg[i]);
-      mx = block_max(mx, red, tid);
-      float se = 0.f;
-      for (int i = tid; i < V; i += 1024) se += expf(lg[i] - mx);
-      se = block_sum(se, red, tid);
-      const float lse = mx + logf(se);
+      // ---- log_softmax (a.preprocessed: the typical pre-pass already did this, the penalty and the suppression) ----
+      float lse = 0.f;
+      if (!a.preprocessed) {
+        float mx = -INFINITY;
+        for (int i = tid; i < V; i += 1024) mx = fmaxf(mx, lg[i]);
+        mx = block_max(mx, red, tid);
+        float se = 0.f;
+        for (int i = tid; i < V; i += 1024) se += expf(lg[i] - mx);
+        se = block_sum(se, red, tid);
+        lse = mx + logf(se);
+      }
       // ---- ids this beam has seen: the fake prompt ids (all 1, then start_mel: model.py:644-653) + its history ----
       for (int i = tid; i < (V + 31) / 32; i += 1024) seenw[i] = 0u;
       __syncthreads();
@@ -95,8 +98,10 @@ __global__ __launch_bounds__(1024) void beam_sample_kernel(BeamArgs a) {
       __syncthreads();
       for (int i = tid; i < V; i += 1024) {
         float v = lg[i] - lse;
-        if (a.penalty != 1.f && ((seenw[i >> 5] >> (i & 31)) & 1u)) v = v < 0.f ? v * a.penalty : v / a.penalty;
-        if (a.suppress_stop && i == a.stop) v = -INFINITY;
+        if (!a.preprocessed) {
+          if (a.penalty != 1.f && ((seenw[i >> 5] >> (i & 31)) & 1u)) v = v < 0.f ? v * a.penalty : v / a.penalty;
+          if (a.suppress_stop && i == a.stop) v = -INFINITY;
+        }
         if (a.temperature != 1.f) v = v / a.temperature;
         ssc[i] = v;
       }
@@ -390,7 +395,156 @@ __global__ __launch_bounds__(1024) void beam_sample_kernel(BeamArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// TypicalLogitsWarper as a pre-pass (the reference's optional `typical_sampling=True`, gpt/model.py:690-697 +
+// utils/typical_sampling.py:9-30): HF places it in the logits_processor list right after RepetitionPenalty, i.e. before
+// the Temperature / TopK / TopP warpers.  One 1024-thread workgroup per row: processed scores (log_softmax first under
+// beams, repetition penalty, stop suppression) -> entropy H of their softmax -> tokens sorted by |(-log p) - H| (block
+// bitonic sort in LDS) -> running probability mass in that order (block scan) -> everything behind the point where
+// the mass reaches `mass` is set to -inf (the first min_keep always stay).  The samplers then run on `out` with
+// `preprocessed` set (no second log_softmax / penalty).
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void typical_filter_kernel(TypicalArgs a) {
+  extern __shared__ unsigned char tsm[];
+  const int NP = a.npad;
+  float* keys = reinterpret_cast<float*>(tsm);                       // [NP]
+  unsigned short* idx = reinterpret_cast<unsigned short*>(tsm + (size_t)NP * 4);  // [NP]
+  __shared__ unsigned seenw[512];
+  __shared__ float red[16];
+  __shared__ float wsum[16];
+  __shared__ int s_last;
+  const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, V = a.V;
+  const float* __restrict__ lg = a.logits + (size_t)row * V;
+  float* __restrict__ out = a.out + (size_t)row * V;
+  // ---- seen set: the byte bitmap of the single-beam samplers, or (beams) the row's id history ----
+  if (a.beam_ids) {
+    const int k = a.len[row], mg = a.max_gen;
+    const int* hist = a.beam_ids + ((size_t)(k & 1) * gridDim.x + row) * mg;
+    for (int i = tid; i < (V + 31) / 32; i += 1024) seenw[i] = 0u;
+    __syncthreads();
+    if (tid == 0) {
+      atomicOr(&seenw[a.fake_id >> 5], 1u << (a.fake_id & 31));
+      atomicOr(&seenw[a.start_tok >> 5], 1u << (a.start_tok & 31));
+    }
+    for (int i = tid; i < k; i += 1024) {
+      const int t = hist[i];
+      atomicOr(&seenw[t >> 5], 1u << (t & 31));
+    }
+    __syncthreads();
+  }
+  float lse0 = 0.f;
+  if (a.log_softmax_first) {
+    float mx = -INFINITY;
+    for (int i = tid; i < V; i += 1024) mx = fmaxf(mx, lg[i]);
+    mx = block_max(mx, red, tid);
+    float se = 0.f;
+    for (int i = tid; i < V; i += 1024) se += expf(lg[i] - mx);
+    se = block_sum(se, red, tid);
+    lse0 = mx + logf(se);
+  }
+  // ---- processed scores -> out; their log-sum-exp ----
+  float mx = -INFINITY;
+  for (int i = tid; i < V; i += 1024) {
+    float v = lg[i] - lse0;
+    const bool seen = a.beam_ids ? ((seenw[i >> 5] >> (i & 31)) & 1u) != 0 : (a.seen && a.seen[(size_t)row * V + i]);
+    if (a.penalty != 1.f && seen) v = v < 0.f ? v * a.penalty : v / a.penalty;
+    if (a.suppress_stop && i == a.stop) v = -INFINITY;
+    out[i] = v;
+    mx = fmaxf(mx, v);
+  }
+  mx = block_max(mx, red, tid);
+  __syncthreads();  // out[] written by this block is read back below
+  float se = 0.f;
+  for (int i = tid; i < V; i += 1024) se += expf(out[i] - mx);
+  se = block_sum(se, red, tid);
+  const float lse = mx + logf(se);
+  float en = 0.f;
+  for (int i = tid; i < V; i += 1024) {
+    const float nl = out[i] - lse;
+    if (nl > -INFINITY) en += nl * expf(nl);  // nansum: (-inf) * 0 is skipped
+  }
+  const float ent = -block_sum(en, red, tid);
+  for (int i = tid; i < NP; i += 1024) {
+    float key = INFINITY;
+    if (i < V) {
+      const float nl = out[i] - lse;
+      key = fabsf((-nl) - ent);  // +inf for removed scores: they sort last
+    }
+    keys[i] = key;
+    idx[i] = (unsigned short)(i < V ? i : 0xFFFF);
+  }
+  __syncthreads();
+  // ---- bitonic sort, ascending (key, index) ----
+  for (int kk = 2; kk <= NP; kk <<= 1) {
+    for (int j = kk >> 1; j > 0; j >>= 1) {
+      for (int t = tid; t < NP / 2; t += 1024) {
+        const int lo = ((t & ~(j - 1)) << 1) | (t & (j - 1)), hi = lo | j;
+        const bool up = (lo & kk) == 0;
+        const float k0 = keys[lo], k1 = keys[hi];
+        const unsigned short i0 = idx[lo], i1 = idx[hi];
+        const bool gt = k0 > k1 || (k0 == k1 && i0 > i1);
+        if (gt == up) {
+          keys[lo] = k1;
+          keys[hi] = k0;
+          idx[lo] = i1;
+          idx[hi] = i0;
+        }
+      }
+      __syncthreads();
+    }
+  }
+  // ---- running mass in sorted order: per-thread runs of NP / 1024 consecutive entries, block scan of the run sums ----
+  const int per = NP / 1024;
+  float loc[16];
+  float mine = 0.f;
+  for (int e = 0; e < per; ++e) {
+    const int j = tid * per + e;
+    const unsigned short ix = idx[j];
+    const float p = (j < V && ix != 0xFFFF) ? expf(out[ix] - lse) : 0.f;
+    loc[e] = p;
+    mine += p;
+  }
+  float inc = mine;  // inclusive scan over the wave, then over the waves
+  for (int o = 1; o < 64; o <<= 1) {
+    const float t = __shfl_up(inc, o, 64);
+    if (lane >= o) inc += t;
+  }
+  if (lane == 63) wsum[wave] = inc;
+  if (tid == 0) s_last = 0;
+  __syncthreads();
+  float base = inc - mine;
+  for (int w = 0; w < wave; ++w) base += wsum[w];
+  int cnt = 0;
+  float c = base;
+  for (int e = 0; e < per; ++e) {
+    c += loc[e];
+    if (tid * per + e < V && c < a.mass) ++cnt;
+  }
+  if (cnt) atomicAdd(&s_last, cnt);
+  __syncthreads();
+  const int last = min(s_last, V - 1);
+  const float thr = keys[last];
+  for (int j = tid; j < V; j += 1024)
+    if (keys[j] > thr && j >= a.min_keep && idx[j] != 0xFFFF) out[idx[j]] = -INFINITY;
+}
+
 }  // namespace
+
+int typical_filter(const TypicalArgs& a, int rows, hipStream_t s) {
+  ITTS_REQUIRE(a.logits && a.out && a.V > 1 && a.V <= 16384 && a.mass > 0.f && a.mass < 1.f, "typical_filter: bad arguments (V <= 16384, 0 < mass < 1)");
+  TypicalArgs t = a;
+  t.npad = 1024;
+  while (t.npad < a.V) t.npad <<= 1;
+  const size_t lds = (size_t)t.npad * 6;
+  static bool attr_done = false;
+  if (!attr_done) {
+    ITTS_HIP_CHECK(hipFuncSetAttribute((const void*)typical_filter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(typical_filter_kernel, dim3(rows), dim3(1024), lds, s, t);
+  ITTS_HIP_CHECK(hipGetLastError());
+  return OK;
+}
 
 int beam_sample_step(const BeamArgs& a, hipStream_t s) {
   ITTS_REQUIRE(a.nb >= 2 && a.nb <= MAXB, "beam_sample: 2 <= num_beams <= 4");

@@ -185,6 +185,10 @@ int itts_gpt_set_beam_sample(itts_engine* e, int num_beams, int top_k, float top
   ENG(e);
   return e->e.gpt_set_beam_sample(num_beams, top_k, top_p, temperature, uniforms_host, (long)n_uniforms);
 }
+int itts_gpt_set_typical(itts_engine* e, float mass) {
+  ENG(e);
+  return e->e.gpt_set_typical(mass);
+}
 int itts_gpt_set_forced(itts_engine* e, const int32_t* ids_host, int B, int n) {
   ENG(e);
   return e->e.gpt_set_forced(ids_host, B, n);

@@ -1040,6 +1040,7 @@ __global__ __launch_bounds__(1024) void sampler2_kernel(SamplerArgs a) {
     }
   };
   auto score = [&](float v, int i) {
+    if (a.preprocessed) return v;
     if (a.penalty != 1.f && seen[i]) v = v < 0.f ? v * a.penalty : v / a.penalty;
     if (a.suppress_stop && i == a.stop) v = -INFINITY;
     return v;
@@ -1123,8 +1124,10 @@ __global__ __launch_bounds__(1024) void sampler_sample_kernel(SamplerArgs a) {
   const int k_pre = a.step[b], unf_pre = a.unfinished[b];
   for (int i = tid; i < a.V; i += 1024) {
     float v = lg[i];
-    if (a.penalty != 1.f && seen[i]) v = v < 0.f ? v * a.penalty : v / a.penalty;
-    if (a.suppress_stop && i == a.stop) v = -INFINITY;
+    if (!a.preprocessed) {
+      if (a.penalty != 1.f && seen[i]) v = v < 0.f ? v * a.penalty : v / a.penalty;
+      if (a.suppress_stop && i == a.stop) v = -INFINITY;
+    }
     if (a.temperature != 1.f) v = v / a.temperature;  // TemperatureLogitsWarper: scores / temperature
     ssc[i] = v;
   }

@@ -21,7 +21,13 @@ constexpr int SW = 8;  // waves per workgroup (K split inside the workgroup)
 // NT = 16-feature tiles per workgroup (each wave multiplies the same X fragments into NT weight tiles: X is the larger
 // L2->CU stream at B = 64, so two tiles per workgroup halve it per output); gridDim.y = K split across workgroups
 // (ksplit > 1: raw partial sums go to g.partial[split][b][n]; bias / residual are applied by ln_rows_bf16).
-template <int BT, int NT, int SU>
+// W8: the weights are OCP fp8 e4m3 bytes with one power-of-two scale per output row (BASELINE config 5: half the weight
+// stream); a lane's 8 bytes become the same bf16x8 MFMA operand through v_cvt_scalef32_pk_bf16_fp8, the row scale
+// multiplies the fp32 sum in the epilogue - bit-identical to running the bf16 dequantisation of the same weights.
+typedef unsigned int u32x2v __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
+
+template <int BT, int NT, int SU, bool W8 = false>
 __global__ __launch_bounds__(512) void skinny_mfma_kernel(GemvArgs g) {
   __shared__ float red[SW][NT * BT][256];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -34,8 +40,13 @@ __global__ __launch_bounds__(512) void skinny_mfma_kernel(GemvArgs g) {
   const int per = (nks_all + S - 1) / S;
   const int ks0 = split * per, nks = min(per, nks_all - ks0);  // this workgroup's k-steps [ks0, ks0 + nks)
   const bf16_t* wp[NT];
+  const uint8_t* wq[NT];
 #pragma unroll
-  for (int t = 0; t < NT; ++t) wp[t] = W + (size_t)min(n0 + t * 16 + fr, g.N - 1) * K + fg * 8 + (size_t)ks0 * 32;
+  for (int t = 0; t < NT; ++t) {
+    const size_t off = (size_t)min(n0 + t * 16 + fr, g.N - 1) * K + fg * 8 + (size_t)ks0 * 32;
+    wp[t] = W + off;
+    wq[t] = (const uint8_t*)g.W8 + off;
+  }
   // X either row-major [B][K] or fragment-tiled [K/32][BT][64 lanes][8] (tile_off): one MFMA operand = 1 KiB contiguous
   const int btr = (g.B + 15) >> 4;  // batch tiles that exist (the template rounds up to 1 / 2 / 4 / 8)
   const int xstep = g.x_tiled ? btr * 512 : 32;
@@ -52,13 +63,15 @@ __global__ __launch_bounds__(512) void skinny_mfma_kernel(GemvArgs g) {
   // epilogue operands (bias of the outputs this thread will finish) requested up front: the tail then has no
   // dependent memory latency
   constexpr int EPT = (NT * BT * 256 + 511) / 512;
-  float bpre[EPT];
+  float bpre[EPT], spre[EPT];
   {
-    const float* bp = g.bias ? g.bias : reinterpret_cast<const float*>(g.W);
+    const float* bp = g.bias ? g.bias : (W8 ? g.wscale : reinterpret_cast<const float*>(g.W));  // any readable address without a bias
 #pragma unroll
     for (int it = 0; it < EPT; ++it) {
       const int idx = tid + it * 512, tb = idx >> 8, t = tb / BT;
-      bpre[it] = bp[min(n0 + t * 16 + (idx & 15), g.N - 1)];
+      const int nn = min(n0 + t * 16 + (idx & 15), g.N - 1);
+      bpre[it] = bp[nn];
+      spre[it] = W8 ? g.wscale[nn] : 1.f;
     }
   }
   for (int k0 = wave; k0 < nks; k0 += SW * SU) {
@@ -67,7 +80,19 @@ __global__ __launch_bounds__(512) void skinny_mfma_kernel(GemvArgs g) {
     for (int u = 0; u < SU; ++u) {
       const int ks = min(k0 + u * SW, nks - 1);  // clamped loads, masked below: keeps the loads branch-free
 #pragma unroll
-      for (int t = 0; t < NT; ++t) wf[u][t] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(wp[t] + (size_t)ks * 32));
+      for (int t = 0; t < NT; ++t) {
+        if constexpr (W8) {
+          const u32x2v q = __builtin_nontemporal_load(reinterpret_cast<const u32x2v*>(wq[t] + (size_t)ks * 32));
+          u32x4v w4;  // bytes 0,1 | 2,3 of each dword -> one bf16 pair each (same pairing as gemv_bf16_kernel<W8>)
+          w4[0] = __builtin_bit_cast(unsigned int, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(q[0], 1.0f, false));
+          w4[1] = __builtin_bit_cast(unsigned int, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(q[0], 1.0f, true));
+          w4[2] = __builtin_bit_cast(unsigned int, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(q[1], 1.0f, false));
+          w4[3] = __builtin_bit_cast(unsigned int, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(q[1], 1.0f, true));
+          wf[u][t] = __builtin_bit_cast(bf16x8, w4);
+        } else {
+          wf[u][t] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(wp[t] + (size_t)ks * 32));
+        }
+      }
     }
 #pragma unroll
     for (int u = 0; u < SU; ++u) {
@@ -103,6 +128,7 @@ __global__ __launch_bounds__(512) void skinny_mfma_kernel(GemvArgs g) {
     float v = 0.f;
 #pragma unroll
     for (int w = 0; w < SW; ++w) v += red[w][tb][e];
+    if (W8) v *= spre[it];
     const size_t o = (size_t)b * g.ldy + n;
     if (S > 1) {
       g.partial[((size_t)split * g.B + b) * g.ldy + n] = v;
@@ -201,7 +227,8 @@ __global__ __launch_bounds__(256) void ln_rows_bf16_kernel(bf16_t* __restrict__ 
 
 bool skinny_mfma_supported(const GemvArgs& g) {
   return g.B >= 1 && g.B <= 128 && g.K % 32 == 0 && g.x_bf16 && g.prologue == 0 && !(g.accumulate && g.y_bf16) &&
-         !(((uintptr_t)g.W | (uintptr_t)g.X) & 15) && g.ksplit >= 1 && (g.ksplit == 1 || (g.partial && g.act == ACT_NONE));
+         !(((uintptr_t)g.W | (uintptr_t)g.X) & 15) && !((uintptr_t)g.W8 & 7) && (!g.W8 || g.wscale) && g.ksplit >= 1 &&
+         (g.ksplit == 1 || (g.partial && g.act == ACT_NONE));
 }
 
 template <int BT>
@@ -210,7 +237,12 @@ static int launch_skinny(const GemvArgs& g, hipStream_t s) {
   const int tiles = (g.N + 15) / 16;
   const bool nt2 = tiles * g.ksplit >= 300 && BT <= 4;
   dim3 grid(nt2 ? (tiles + 1) / 2 : tiles, g.ksplit), blk(512);
-  if (nt2)
+  if (g.W8) {
+    if (nt2)
+      hipLaunchKernelGGL((skinny_mfma_kernel<BT, 2, 5, true>), grid, blk, 0, s, g);
+    else
+      hipLaunchKernelGGL((skinny_mfma_kernel<BT, 1, 5, true>), grid, blk, 0, s, g);
+  } else if (nt2)
     hipLaunchKernelGGL((skinny_mfma_kernel<BT, 2, 5>), grid, blk, 0, s, g);
   else
     hipLaunchKernelGGL((skinny_mfma_kernel<BT, 1, 5>), grid, blk, 0, s, g);
@@ -219,7 +251,7 @@ static int launch_skinny(const GemvArgs& g, hipStream_t s) {
 }
 
 int skinny_mfma(const GemvArgs& g, hipStream_t s) {
-  ITTS_REQUIRE(g.X && g.W && (g.Y || g.ksplit > 1) && g.N > 0, "skinny_mfma: bad args");
+  ITTS_REQUIRE(g.X && (g.W || g.W8) && (g.Y || g.ksplit > 1) && g.N > 0, "skinny_mfma: bad args");
   ITTS_REQUIRE(skinny_mfma_supported(g), "skinny_mfma: unsupported shape");
   ITTS_REQUIRE(g.ksplit <= (g.K >> 5), "skinny_mfma: ksplit larger than the number of k-steps");
   const int bt = (g.B + 15) / 16;

@@ -142,6 +142,8 @@ struct DecodeState {
   float *hyp_score = nullptr, *hyp_worst = nullptr;
   size_t beam_cap = 0;               // bytes-independent capacity key: rows * max_gen * Smax the beam buffers were sized for
   int beam_rows = 0, beam_gen = 0, beam_smax = 0;
+  float typical_mass = 0.f, graph_typical = 0.f;  // TypicalLogitsWarper pre-pass (0 = off)
+  float* scores2 = nullptr;                        // [cap_B][V] its output
   int* forced = nullptr;  // [cap_B][cap_gen] forced token per (row, step) or -1; allocated with ids
   int use_forced = 0, graph_forced = 0;
   float graph_penalty = 0.f;
@@ -199,6 +201,7 @@ struct Engine {
   int gpt_set_sampling(int do_sample, int top_k, float top_p, float temperature, const float* uniforms_host, long n);
   std::vector<float> sample_uniforms;  // host copy, uploaded by the next prefill
   int gpt_set_forced(const int32_t* ids_host, int B, int n);
+  int gpt_set_typical(float mass);
   int gpt_set_beam_sample(int num_beams, int top_k, float top_p, float temperature, const float* uniforms_host, long n);
   int beam_beams = 1;  // requested beams for the following generations (1 = off)
   int ensure_beam_state(int rows, int max_gen, int Smax, hipStream_t s);

@@ -63,6 +63,7 @@ struct SamplerArgs {
   // forced tokens (HF `input_tokens` continuation, model.py:672-686 / teacher forcing): forced[b][k] >= 0 replaces the
   // choice of step k for row b; nullptr = nothing forced (the table is only read when it exists)
   const int* forced = nullptr;  // [B][max_gen]
+  int preprocessed = 0;  // logits already went through typical_filter (penalty, stop suppression done)
 };
 
 // one beam-sample step for every batch item (beam.hip): HF 4.36.2 beam_sample + BeamSearchScorer.process on the device
@@ -90,8 +91,22 @@ struct BeamArgs {
   const void* emb = nullptr;
   const void* pos = nullptr;
   int D = 0, pos_rows = 0, emb_bf16 = 0;
+  int preprocessed = 0;  // logits already went through typical_filter (log_softmax, penalty, stop suppression done)
 };
 int beam_sample_step(const BeamArgs& a, hipStream_t s);
+
+// TypicalLogitsWarper pre-pass (beam.hip): processed scores of every row -> out [rows, V] with the filtered ones at -inf
+struct TypicalArgs {
+  const float* logits = nullptr;
+  float* out = nullptr;
+  int V = 0, stop = 0, suppress_stop = 0, min_keep = 1, log_softmax_first = 0, npad = 0;
+  float penalty = 1.f, mass = 0.9f;
+  const uint8_t* seen = nullptr;   // [rows, V] byte bitmap (single-beam modes) ...
+  const int* beam_ids = nullptr;   // ... or the beam id histories [2][rows][max_gen] with len[] (beam-sample)
+  const int* len = nullptr;
+  int max_gen = 0, start_tok = 0, fake_id = 1;
+};
+int typical_filter(const TypicalArgs& a, int rows, hipStream_t s);
 
 int gemv(const GemvArgs& g, int tw, hipStream_t s);
 int double_ln(float* y, const float* x, const float* g1, const float* b1, const float* g2, const float* b2, int rows,

@@ -159,6 +159,7 @@ int Engine::ensure_decode_state(int B, int Smax, int max_gen, hipStream_t s) {
     ITTS_TRY(dev_alloc((void**)&d.attn_o, (size_t)cb * D * ATTN_NSPLIT * 4));
     ITTS_TRY(dev_alloc((void**)&d.attn_ml, (size_t)cb * H * 2 * ATTN_NSPLIT * 4));
     ITTS_TRY(dev_alloc((void**)&d.logits, (size_t)cb * V * 4));
+    ITTS_TRY(dev_alloc((void**)&d.scores2, (size_t)cb * V * 4));
     ITTS_TRY(dev_alloc((void**)&d.kv_start, (size_t)cb * 4));
     ITTS_TRY(dev_alloc((void**)&d.cur_tok, (size_t)cb * 4));
     ITTS_TRY(dev_alloc((void**)&d.unfinished, (size_t)cb * 4));
@@ -437,6 +438,8 @@ int Engine::head_and_sample(hipStream_t s) {
     g.x_bf16 = 1;
     g.x_tiled = 1;
     g.prologue = 0;
+    g.W8 = gpt.head.w8;
+    g.wscale = gpt.head.wscale;
     ITTS_TRY(skinny_mfma(g, s));
   } else if (adt == BF16 && gemv_bf16_supported(g)) {
     g.W8 = gpt.head.w8;
@@ -451,9 +454,35 @@ int Engine::head_and_sample(hipStream_t s) {
     ITTS_TRY(gemv(g, gpt.head.dt, s));
   }
   ITTS_TRY(tap("logits0", ds.logits, F32, (int64_t)B * V, s));
+  const float* lg_in = ds.logits;
+  const bool typical = ds.typical_mass > 0.f && (ds.do_sample || ds.nb > 1);
+  if (typical) {  // TypicalLogitsWarper sits in HF's logits_processor list, right after the repetition penalty
+    TypicalArgs ta;
+    ta.logits = ds.logits;
+    ta.out = ds.scores2;
+    ta.V = V;
+    ta.stop = c.stop_mel_token;
+    ta.suppress_stop = ds.suppress_stop;
+    ta.penalty = ds.penalty;
+    ta.mass = ds.typical_mass;
+    ta.min_keep = ds.nb > 1 ? 2 : 1;  // model.py:693-694
+    ta.log_softmax_first = ds.nb > 1;  // beam_sample processes log-probs, sample() raw logits
+    if (ds.nb > 1) {
+      ta.beam_ids = ds.beam_ids;
+      ta.len = ds.len;
+      ta.max_gen = ds.max_gen;
+      ta.start_tok = c.start_mel_token;
+      ta.fake_id = 1;
+    } else {
+      ta.seen = ds.seen;
+    }
+    ITTS_TRY(typical_filter(ta, B, s));
+    lg_in = ds.scores2;
+  }
   if (ds.nb > 1) {  // beam-sample: one workgroup per batch item over its nb rows
     BeamArgs ba;
-    ba.logits = ds.logits;
+    ba.logits = lg_in;
+    ba.preprocessed = typical;
     ba.V = V;
     ba.max_gen = ds.max_gen;
     ba.stop = c.stop_mel_token;
@@ -492,7 +521,8 @@ int Engine::head_and_sample(hipStream_t s) {
     return beam_sample_step(ba, s);
   }
   SamplerArgs sa;
-  sa.logits = ds.logits;
+  sa.logits = lg_in;
+  sa.preprocessed = typical;
   sa.seen = ds.seen;
   sa.ids = ds.ids;
   sa.cur_tok = ds.cur_tok;
@@ -548,6 +578,10 @@ int Engine::decode_step_launch(hipStream_t s) {
       }
       g.x_tiled = 1;           // every bf16 activation of this path (hn, ctx, act) is fragment-tiled
       g.y_tiled = g.y_bf16;
+      if (g.w8src) {  // fp8 copy of this projection (BASELINE config 5): the same weight bytes the GEMV path streams
+        g.W8 = g.w8src->w8;
+        g.wscale = g.w8src->wscale;
+      }
       return skinny_mfma(g, s);
     }
     if (fast && gemv_bf16_supported(g)) {
@@ -666,6 +700,13 @@ int Engine::gpt_set_sampling(int do_sample, int top_k, float top_p, float temper
   return OK;
 }
 
+// TypicalLogitsWarper(mass) in front of the warpers of the sampling modes (typical_sampling=True, model.py:690-697); 0 = off
+int Engine::gpt_set_typical(float mass) {
+  ITTS_REQUIRE(mass == 0.f || (mass > 0.f && mass < 1.f), "gpt_set_typical: `typical_mass` has to be a float > 0 and < 1");
+  ds.typical_mass = mass;
+  return OK;
+}
+
 // Tokens that replace the sampler's choice for the first n steps of every following generation (n = 0 clears):
 // the HF `input_tokens` continuation of inference_speech (model.py:672-686) and teacher forcing for parity tests.
 int Engine::gpt_set_forced(const int32_t* ids_host, int B, int n) {
@@ -694,7 +735,7 @@ int Engine::gpt_decode(int nsteps, hipStream_t s) {
     // everything SamplerArgs carries by value is baked into the captured nodes: max_gen is the ids row stride and the
     // `k < max_gen` bound, so a per-request max_mel_tokens must re-capture (same B / Smax notwithstanding)
     const bool stale = !d.graph || d.graph_B != d.B || d.graph_Smax != d.Smax || d.graph_max_gen != d.max_gen ||
-                       d.graph_forced != d.use_forced || d.graph_nb != d.nb || d.graph_penalty != d.penalty || d.graph_suppress != d.suppress_stop || d.graph_sample != d.do_sample ||
+                       d.graph_forced != d.use_forced || d.graph_nb != d.nb || d.graph_typical != d.typical_mass || d.graph_penalty != d.penalty || d.graph_suppress != d.suppress_stop || d.graph_sample != d.do_sample ||
                        d.graph_top_k != d.top_k || d.graph_top_p != d.top_p || d.graph_temperature != d.temperature;
     // two executables: one step, and GK steps back to back (one launch per GK tokens: the gap between consecutive graph
     // launches is paid once per GK steps; every step reads its lengths from device memory, so any mix is valid)
@@ -728,6 +769,7 @@ int Engine::gpt_decode(int nsteps, hipStream_t s) {
       d.graph_max_gen = d.max_gen;
       d.graph_forced = d.use_forced;
       d.graph_nb = d.nb;
+      d.graph_typical = d.typical_mass;
       d.graph_penalty = d.penalty;
       d.graph_suppress = d.suppress_stop;
       d.graph_sample = d.do_sample;

@@ -240,7 +240,7 @@ class Engine:
     def generate(self, cond: torch.Tensor, text_ids: np.ndarray, max_gen: int, repetition_penalty: float = 10.0,
                  suppress_stop: bool = False, check_every: int = 16, do_sample: bool = False, top_k: int = 30,
                  top_p: float = 0.8, temperature: float = 1.0, seed: Optional[int] = None,
-                 uniforms: Optional[np.ndarray] = None, num_beams: int = 1) -> np.ndarray:
+                 uniforms: Optional[np.ndarray] = None, num_beams: int = 1, typical_mass: float = 0.0) -> np.ndarray:
         """Greedy decode (do_sample=False, num_beams=1 of tests/padding_test.py:35-46) or, with do_sample, HF
         GenerationMixin.sample (top-k / top-p / temperature, num_beams=1; draws from `uniforms` or a numpy Generator
         seeded with `seed`).  Returns int64 codes [B, n] with n <= max_gen: HF stops when every row has emitted stop
@@ -248,6 +248,9 @@ class Engine:
         [max_gen, B, 2 * num_beams]; returns the best finalized hypothesis per row."""
         beams = do_sample and num_beams > 1
         nrow = np.asarray(text_ids).shape[0]
+        typical = bool(do_sample and typical_mass)
+        if typical:  # typical_sampling=True (model.py:690-697): TypicalLogitsWarper in front of the warpers
+            L.check(self.lib.itts_gpt_set_typical(self.h, float(typical_mass)), "gpt_set_typical")
         if beams:
             if uniforms is None:
                 uniforms = np.random.default_rng(seed).random((max_gen, nrow, 2 * num_beams), dtype=np.float32)
@@ -272,6 +275,8 @@ class Engine:
             codes = self.fetch()[:, :step].astype(np.int64)
             self._exit()
         finally:
+            if typical:
+                L.check(self.lib.itts_gpt_set_typical(self.h, 0.0), "gpt_set_typical")
             if beams:
                 self.set_beam_sample(1)
             elif do_sample:

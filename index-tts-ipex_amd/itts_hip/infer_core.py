@@ -78,6 +78,7 @@ def sampling_kwargs(do_sample, num_beams, top_k, top_p, temperature, typical_sam
       do_sample, num_beams > 1   beam_sample (the reference default: 3 beams), up to 4 beams, on the device
       do_sample, num_beams == 1  multinomial sampling on the device
       not do_sample              greedy; num_beams > 1 without sampling (HF beam_search) is not implemented: warns, one beam
+      typical_sampling           the reference's TypicalLogitsWarper(typical_mass) in front of the warpers (sampling modes)
     top_k outside [1, 64] (HF: 0 / None disable the warper) is clamped to 64 with a warning - the device samplers keep at
     most 64 candidates per row.  The seed is drawn from torch's global RNG so that torch.manual_seed governs the run as it
     does for the reference's torch.multinomial."""
@@ -86,8 +87,8 @@ def sampling_kwargs(do_sample, num_beams, top_k, top_p, temperature, typical_sam
     import torch
 
     nb = 1 if num_beams is None else int(num_beams)
-    if typical_sampling:
-        warnings.warn("itts_hip: typical sampling is not implemented; using top-k / top-p", RuntimeWarning)
+    if typical_sampling and not (0.0 < float(typical_mass) < 1.0):
+        raise ValueError(f"`typical_mass` has to be a float > 0 and < 1, but is {typical_mass}")  # model.py:692-693
     if not do_sample:
         if nb != 1:
             warnings.warn("itts_hip: beam search without sampling is not implemented; decoding greedily with num_beams=1", RuntimeWarning)
@@ -101,4 +102,5 @@ def sampling_kwargs(do_sample, num_beams, top_k, top_p, temperature, typical_sam
         k = 64
     p = 1.0 if top_p is None else float(top_p)
     return dict(do_sample=True, top_k=k, top_p=min(max(p, 1e-6), 1.0), temperature=float(temperature or 1.0), num_beams=max(nb, 1),
+                typical_mass=float(typical_mass) if typical_sampling else 0.0,
                 seed=int(torch.randint(0, 2 ** 31 - 1, (1,)).item()))

@@ -10,6 +10,8 @@ Only `tests/`, `__graft_entry__.smoke()` and `bench.py`'s cpu_baseline leg may i
 from __future__ import annotations
 
 import math
+
+import numpy as np
 from typing import Dict, List, Optional, Tuple
 
 import torch
@@ -308,6 +310,10 @@ def greedy_generate(cond, text_inputs, w: W, cfg_gpt, max_generate_length: int, 
             scores[:, stop] = -float("inf")
         if sampling is not None:
             k_step = ids.shape[1] - (s + 1)
+            if sampling.get("typical_mass"):
+                from . import hf_beam
+
+                scores = torch.from_numpy(np.stack([hf_beam.typical_filter(scores[r].numpy(), sampling["typical_mass"], 1) for r in range(b)]))
             nxt = torch.tensor([sample_pick(scores[r].numpy(), sampling["top_k"], sampling["top_p"], sampling["temperature"],
                                             float(sampling["uniforms"][k_step, r])) for r in range(b)], dtype=torch.long)
         else:
@@ -342,7 +348,7 @@ def latent_forward(cond, text_tokens, codes, w: W, cfg_gpt):
 
 def beam_sample_generate(cond, text_inputs, w: W, cfg_gpt, max_generate_length: int, num_beams: int = 3, top_k: int = 30,
                          top_p: float = 0.8, temperature: float = 1.0, repetition_penalty: float = 10.0,
-                         length_penalty: float = 0.0, uniforms=None, trace: Optional[dict] = None):
+                         length_penalty: float = 0.0, uniforms=None, trace: Optional[dict] = None, typical_mass: float = 0.0):
     """UnifiedVoice.inference_speech under the reference's DEFAULT kwargs (infer.py:116-124: do_sample=True, num_beams=3,
     top_k=30, top_p=0.8, length_penalty=0.0, repetition_penalty=10.0): HF 4.36.2 GenerationMixin.beam_sample +
     BeamSearchScorer, restated in oracle/hf_beam.py, over this module's GPT-2 stack with the KV cache re-ordered by
@@ -374,6 +380,8 @@ def beam_sample_generate(cond, text_inputs, w: W, cfg_gpt, max_generate_length: 
         lp = torch.log_softmax(logits, dim=-1)
         lp = repetition_penalty_(lp.clone(), ids, repetition_penalty) if repetition_penalty != 1.0 else lp
         lpn = lp.numpy()
+        if typical_mass:  # logits_processor list: RepetitionPenalty, then the reference's TypicalLogitsWarper (model.py:690-697)
+            lpn = np.stack([hf_beam.typical_filter(lpn[r], typical_mass, 2) for r in range(lpn.shape[0])])
         ns, nt, ni = [], [], []
         for bi in range(b):
             cands = [hf_beam.warp_row(lpn[bi * nb + r], top_k, top_p, temperature, 2) for r in range(nb)]

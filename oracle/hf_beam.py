@@ -196,3 +196,37 @@ def beam_sample_step(cands: List[Tuple[np.ndarray, np.ndarray]], beam_scores: np
     order = sorted(range(len(picks)), key=lambda j: -float(fs[picks[j]]))  # stable: equal scores keep draw order
     sel = [picks[j] for j in order]
     return fs[sel], ft[sel], fb[sel]
+
+
+def typical_filter(scores: np.ndarray, mass: float, min_keep: int = 1) -> np.ndarray:
+    """The reference's TypicalLogitsWarper (/root/reference/indextts/utils/typical_sampling.py:9-30) on one fp32 row:
+    entropy of softmax(scores), tokens ordered by |(-log p) - H| ascending, the shortest prefix whose probability mass
+    reaches `mass` is kept (plus at least min_keep), everything else -> -inf."""
+    s = np.asarray(scores, dtype=np.float32)
+    m = s.max()
+    z = np.exp((s - m).astype(np.float32)).astype(np.float32)
+    logz = np.float32(np.log(z.sum(dtype=np.float32)))
+    normalized = ((s - m) - logz).astype(np.float32)
+    p = np.exp(normalized).astype(np.float32)
+    with np.errstate(invalid="ignore"):
+        prod = normalized * p
+    ent = -np.nansum(prod, dtype=np.float32)  # -inf * 0 -> nan -> skipped, as torch.nansum
+    shifted = np.abs((-normalized) - ent).astype(np.float32)
+    order = np.argsort(shifted, kind="stable")
+    sp = p[order]  # (the reference re-normalises: sorted_logits.softmax)
+    del sp
+    cum = np.cumsum(_softmax32(s[order]), dtype=np.float32)
+    last = int((cum < np.float32(mass)).sum())
+    last = min(last, len(s) - 1)
+    remove_sorted = shifted[order] > shifted[order][last]
+    if min_keep > 1:
+        remove_sorted[:min_keep] = False
+    out = s.copy()
+    out[order[remove_sorted]] = -np.inf
+    return out
+
+
+def _softmax32(x: np.ndarray) -> np.ndarray:
+    x = np.asarray(x, dtype=np.float32)
+    e = np.exp((x - x.max()).astype(np.float32)).astype(np.float32)
+    return (e / e.sum(dtype=np.float32)).astype(np.float32)

@@ -134,7 +134,7 @@ def ref_greedy(gpt, cond_mel, text, max_gen, rep=10.0, n_trace=None, suppress_eo
 
 
 def ref_beam_sample(gpt, cond_mel, text, max_gen, uniforms, nb=3, top_k=30, top_p=0.8, temperature=1.0, rep=10.0,
-                    length_penalty=0.0):
+                    length_penalty=0.0, typical_mass=0.0):
     """Hand-rolled HF-4.36.2 `beam_sample` over the reference's own GPT2InferenceModel.forward / _reorder_cache with the
     INSTALLED transformers logits processors / warpers (min_tokens_to_keep = 2 under beams) and the BeamSearchScorer
     restatement of oracle/hf_beam.py; torch.multinomial is replaced by the shared-uniform sequential draw."""
@@ -154,6 +154,11 @@ def ref_beam_sample(gpt, cond_mel, text, max_gen, uniforms, nb=3, top_k=30, top_
     ids = ids.repeat_interleave(nb, 0)
     mask = mask.repeat_interleave(nb, 0)
     proc = RepetitionPenaltyLogitsProcessor(rep)
+    typical = None
+    if typical_mass:  # the reference's own subclass, placed after the default processors (model.py:690-697)
+        from indextts.utils.typical_sampling import TypicalLogitsWarper
+
+        typical = TypicalLogitsWarper(mass=typical_mass, min_tokens_to_keep=2 if nb > 1 else 1)
     warpers = []
     if temperature != 1.0:
         warpers.append(TemperatureLogitsWarper(temperature))
@@ -171,6 +176,8 @@ def ref_beam_sample(gpt, cond_mel, text, max_gen, uniforms, nb=3, top_k=30, top_
         past = out.past_key_values
         sc = torch.log_softmax(out.logits[:, -1, :], dim=-1)
         sc = proc(ids, sc.clone())
+        if typical is not None:
+            sc = typical(ids, sc)
         for wp in warpers:
             sc = wp(ids, sc)
         scn = sc.numpy()
@@ -312,6 +319,11 @@ def micro_fixtures():
         u = rng.random((n, txt.shape[0], 2 * nb), dtype=np.float32)
         codes_b = ref_beam_sample(gpt, mel, txt, n, u, nb=nb, top_k=tk, top_p=tp, temperature=tmp)
         save(f"micro_beam_{tag}", text=txt, codes=codes_b, uniforms=u, num_beams=nb, top_k=tk, top_p=tp, temperature=tmp, max_gen=n)
+    u = rng.random((20, 2, 6), dtype=np.float32)
+    txt = torch.cat([text, text2], 0)
+    codes_t = ref_beam_sample(gpt, mel, txt, 20, u, nb=3, top_k=30, top_p=0.8, temperature=1.0, typical_mass=0.6)
+    save("micro_beam_typical", text=txt, codes=codes_t, uniforms=u, num_beams=3, top_k=30, top_p=0.8, temperature=1.0, max_gen=20,
+         typical_mass=0.6)
 
     print("[int] remove_long_silence known answers")
     ref_import._stub("omegaconf", OmegaConf=object)

@@ -98,3 +98,45 @@ def test_batched_vocoder_at_bench_size_bf16(mel, accuracy):
         worst = max(worst, rms_rel(wav[b].cpu().numpy(), w1[0].cpu().numpy()))
     accuracy["bf16_bigvgan_b64x480_vs_batch1_rel_rms"] = worst
     assert worst < 2e-2, worst
+
+
+def test_config5_longform_fp8_weights_batched_and_sequential(mel, accuracy):
+    """BASELINE config 5: a 2000-char text = 20 sentences, GPT projection weights stored as fp8 e4m3 + row scales.
+    (a) all 20 sentences as ONE decode batch (MFMA path, fp8 bytes read by skinny_mfma_kernel<W8>): codes and logits are
+        bit-identical to an engine that reads the bf16 DEQUANTISATION of the same weights - the fp8 bytes really are what
+        is streamed, and the conversion is exact;
+    (b) the same sentences one at a time ("sequential chunks, fresh KV per chunk": GEMV path, gemv_bf16_kernel<W8>) agree
+        with their row of the batch within the bf16 tolerance of the two kernel families (ids until the first near-tie)."""
+    texts = np.stack([synth.text_ids(105, 900 + i, CFG.gpt.number_text_tokens) for i in range(20)]).astype(np.int32)
+    n = 24
+    res = {}
+    cond = None
+    for mode in ("fp8", "dequant"):
+        eng = ieng.build_engine(CFG, "bf16", parts=("gpt",), gpt_fp8=mode, max_batch=32)
+        cond = eng.conditioning(mel) if cond is None else cond
+        eng.prefill(cond, texts, n, 10.0, True)
+        eng.decode(n - 1)
+        res[mode] = eng.fetch(logits=True)
+        eng._exit()
+        if mode == "fp8":
+            seq = []
+            for i in range(4):  # sequential chunks
+                eng.prefill(cond, texts[i:i + 1], n, 10.0, True)
+                first = eng.fetch(logits=True)[1].copy()
+                eng.decode(n - 1)
+                seq.append((eng.fetch()[0].copy(), first))
+                eng._exit()
+            eng.prefill(cond, texts, n, 10.0, True)
+            first20 = eng.fetch(logits=True)[1].copy()
+            eng._exit()
+        del eng
+        torch.cuda.empty_cache()
+    assert np.array_equal(res["fp8"][0], res["dequant"][0]) and np.array_equal(res["fp8"][1], res["dequant"][1])
+    worst, agree = 0.0, []
+    for i, (codes1, lg1) in enumerate(seq):
+        worst = max(worst, rms_rel(first20[i], lg1[0]))
+        same = codes1 == res["fp8"][0][i, :n]
+        agree.append(int(np.argmin(same)) if not same.all() else n)
+    accuracy["config5_fp8_batched20_vs_sequential_first_logits_rel_rms"] = worst
+    accuracy["config5_fp8_batched20_vs_sequential_ids_agree_steps"] = agree
+    assert worst < 3e-2, worst

@@ -273,7 +273,7 @@ def test_fp8_decode_weights_equal_their_dequantisation(gold):
 
 
 # ---- beam-sample: the reference's DEFAULT generate() mode (num_beams = 3) --------------------------------------------
-@pytest.mark.parametrize("tag", ["a", "b", "c"])
+@pytest.mark.parametrize("tag", ["a", "b", "c", "typical"])
 def test_beam_sample_ids_match_reference_fixture_fp32(eng32, gold, tag):
     """Engine beam-sample (device sampler + BeamSearchScorer + cache ancestry + host finalize) against the fixture the
     reference's GPT2InferenceModel / _reorder_cache produced with the same uniforms (make_golden.ref_beam_sample): the
@@ -281,7 +281,8 @@ def test_beam_sample_ids_match_reference_fixture_fp32(eng32, gold, tag):
     c, g = gold("micro_conditioning"), gold(f"micro_beam_{tag}")
     cond = torch.from_numpy(c["cond"])
     kw = dict(do_sample=True, num_beams=int(g["num_beams"]), top_k=int(g["top_k"]), top_p=float(g["top_p"]),
-              temperature=float(g["temperature"]), uniforms=g["uniforms"])
+              temperature=float(g["temperature"]), uniforms=g["uniforms"],
+              typical_mass=float(g["typical_mass"]) if "typical_mass" in g else 0.0)  # the reference's TypicalLogitsWarper
     codes = eng32.generate(cond, g["text"], int(g["max_gen"]), **kw)
     assert codes.shape == g["codes"].shape, (codes.shape, g["codes"].shape)
     assert np.array_equal(codes, g["codes"]), (codes, g["codes"])
@@ -316,3 +317,20 @@ def test_beam_sample_bf16_runs_and_is_deterministic(eng16, gold):
     a = eng16.generate(cond, g["text"], int(g["max_gen"]), **kw)
     b = eng16.generate(cond, g["text"], int(g["max_gen"]), **kw)
     assert np.array_equal(a, b) and a.shape[0] == g["text"].shape[0] and a.shape[1] <= int(g["max_gen"])
+
+
+def test_typical_sampling_single_beam_matches_oracle_fp32(eng32, gold):
+    """typical_sampling=True with num_beams=1 (GenerationMixin.sample: RepetitionPenalty -> Typical(min keep 1) ->
+    Temperature -> TopK -> TopP), micro and through a long vocabulary sort at IndexTTS-1.5 size in test_gpu_fullsize."""
+    c, g = gold("micro_conditioning"), gold("micro_decode_b5")
+    cond = torch.from_numpy(c["cond"])
+    wg = ogpt.to_torch(synth.gpt_state_dict(CFG, 1234))
+    n, B = 20, g["text"].shape[0]
+    u = np.random.default_rng(9).random((n, B), dtype=np.float32)
+    got = eng32.generate(cond, g["text"], n, do_sample=True, top_k=30, top_p=0.8, temperature=0.9, uniforms=u, typical_mass=0.7)
+    with torch.no_grad():
+        want = ogpt.greedy_generate(cond, torch.from_numpy(g["text"]), wg, CFG.gpt, n,
+                                    sampling=dict(top_k=30, top_p=0.8, temperature=0.9, uniforms=u, typical_mass=0.7)).numpy()
+    assert got.shape == want.shape and np.array_equal(got, want), (got, want)
+    plain = eng32.generate(cond, g["text"], n, do_sample=True, top_k=30, top_p=0.8, temperature=0.9, uniforms=u)
+    assert not np.array_equal(plain, got)  # the filter changes the distribution

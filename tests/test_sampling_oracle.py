@@ -114,7 +114,7 @@ def test_beam_hypotheses_bookkeeping():
     assert len(h) == 2
 
 
-@pytest.mark.parametrize("tag", ["a", "b", "c"])
+@pytest.mark.parametrize("tag", ["a", "b", "c", "typical"])
 def test_beam_sample_generate_matches_reference_fixture(gold, tag):
     """oracle.gpt.beam_sample_generate (own GPT-2 stack + own warper restatement) against the fixture produced by the
     reference's GPT2InferenceModel.forward / _reorder_cache + the installed transformers warpers (make_golden.ref_beam_sample),
@@ -127,5 +127,38 @@ def test_beam_sample_generate_matches_reference_fixture(gold, tag):
         cond = ogpt.get_conditioning(mel, w, cfg.gpt)
         out = ogpt.beam_sample_generate(cond, torch.from_numpy(g["text"]).long(), w, cfg.gpt, int(g["max_gen"]), num_beams=int(g["num_beams"]),
                                         top_k=int(g["top_k"]), top_p=float(g["top_p"]), temperature=float(g["temperature"]),
-                                        uniforms=g["uniforms"])
+                                        uniforms=g["uniforms"], typical_mass=float(g["typical_mass"]) if "typical_mass" in g else 0.0)
     assert np.array_equal(out.numpy(), g["codes"]), (out.numpy(), g["codes"])
+
+
+@pytest.mark.parametrize("V", [66, 8194])
+@pytest.mark.parametrize("mass,min_keep", [(0.9, 1), (0.5, 2), (0.2, 1), (0.97, 2)])
+def test_typical_filter_matches_reference_class(V, mass, min_keep):
+    """hf_beam.typical_filter against the reference's own TypicalLogitsWarper subclass (indextts/utils/typical_sampling.py,
+    imported from /root/reference when present; the installed transformers base class otherwise - same algorithm)."""
+    from oracle import ref_import
+
+    if ref_import.available():
+        import importlib.util
+        import os
+
+        spec = importlib.util.spec_from_file_location("_ref_typical", os.path.join(ref_import.REF_ROOT, "indextts", "utils", "typical_sampling.py"))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        warper = mod.TypicalLogitsWarper(mass=mass, min_tokens_to_keep=min_keep)
+    else:
+        warper = tlp.TypicalLogitsWarper(mass=mass, min_tokens_to_keep=min_keep)
+    rng = np.random.default_rng(V)
+    for trial in range(6):
+        s = (rng.standard_normal(V) * (0.5 + trial)).astype(np.float32)
+        if trial == 4:
+            s[5] = -np.inf
+        want = warper(torch.zeros(1, 1, dtype=torch.long), torch.from_numpy(s)[None].clone())[0].numpy()
+        got = hf_beam.typical_filter(s, mass, min_keep)
+        kg, kw = np.isfinite(got), np.isfinite(want)
+        # the cut sits where an fp32 running sum over thousands of terms crosses `mass`: torch.cumsum and a sequential sum
+        # may disagree by a few tail tokens there (measure: the probability mass of the disagreement)
+        p = np.exp(s - s.max()) / np.exp(s - s.max()).sum()
+        assert (kg != kw).sum() <= 4 and float(p[kg != kw].sum()) < 1e-5, (trial, int(kg.sum()), int(kw.sum()))
+        both = kg & kw
+        assert np.array_equal(got[both], want[both])
