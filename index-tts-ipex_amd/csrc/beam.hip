@@ -151,7 +151,9 @@ __global__ __launch_bounds__(1024) void beam_sample_kernel(BeamArgs a) {
       __syncthreads();
       for (int i = tid; i < V; i += 1024) {
         const float v = ssc[i];
-        if (okey(v) >= prefix) {
+        // (-inf scores - filtered by the typical pre-pass, the suppressed stop - never count: when fewer than top_k finite
+        // scores exist the k-th largest is -inf and HF's `scores < kth` removes nothing, i.e. keeps exactly the finite ones)
+        if (okey(v) >= prefix && v > -INFINITY) {
           const int p = atomicAdd(&s_cnt, 1);
           if (p < MAXC) {
             cval[p] = v;

@@ -15,6 +15,9 @@ namespace itts {
 int gemm(const GemmArgs& g, int ta, int tw, int tc, hipStream_t s) {
   static const bool no_conv_lds = getenv("ITTS_NO_CONV_LDS") != nullptr;
   if (!no_conv_lds && conv_lds_supported(g, ta, tw, tc)) return conv_lds(g, s);
+  static const bool no_glds = getenv("ITTS_NO_GEMM_GLDS") != nullptr;  // A/B switch: the register-staged kernel everywhere
+  const bool old = no_glds || getenv("ITTS_GEMM_FORCE_OLD") != nullptr;  // (per call: the parity test runs both on one shape)
+  if (!old && gemm_glds_supported(g, ta, tw, tc)) return gemm_glds(g, ta, tw, tc, s);
   if (gemm_mfma_supported(g, ta, tw, tc)) return gemm_mfma(g, ta, tw, tc, s);
   return gemm_simple(g, ta, tw, tc, s);
 }
@@ -23,7 +26,7 @@ int gemm(const GemmArgs& g, int ta, int tw, int tc, hipStream_t s) {
 extern "C" {
 
 const char* itts_last_error(void) { return last_error(); }
-int itts_abi_version(void) { return 1; }
+int itts_abi_version(void) { return 2; }
 
 int itts_snake_aa_fwd(void* dst, const void* src, const float* up12, const float* down12, const float* log_alpha,
                       const float* log_beta, int B, int C, int T, int dtype, int layout, itts_stream stream) {

@@ -1178,7 +1178,8 @@ __global__ __launch_bounds__(1024) void sampler_sample_kernel(SamplerArgs a) {
   __syncthreads();
   for (int i = tid; i < a.V; i += 1024) {
     const float v = ssc[i];
-    if (order_key(v) >= prefix) {
+    // -inf scores never count: with fewer than top_k finite scores HF's `scores < kth` (kth = -inf) keeps exactly the finite ones
+    if (order_key(v) >= prefix && v > -INFINITY) {
       const int pos = atomicAdd(&s_cnt, 1);
       if (pos < 64) {
         cval[pos] = v;

@@ -10,6 +10,8 @@ namespace itts {
 int gemm_simple(const GemmArgs& g, int ta, int tw, int tc, hipStream_t s);
 bool gemm_mfma_supported(const GemmArgs& g, int ta, int tw, int tc);
 int gemm_mfma(const GemmArgs& g, int ta, int tw, int tc, hipStream_t s);
+bool gemm_glds_supported(const GemmArgs& g, int ta, int tw, int tc);  // LDS-DMA staged 128 x 128 / 128 x 64 tiles (gemm_glds.hip)
+int gemm_glds(const GemmArgs& g, int ta, int tw, int tc, hipStream_t s);
 bool conv_lds_supported(const GemmArgs& g, int ta, int tw, int tc);
 int conv_lds(const GemmArgs& g, hipStream_t s);
 int gemm(const GemmArgs& g, int ta, int tw, int tc, hipStream_t s);  // dispatcher

@@ -391,3 +391,61 @@ def test_attention_mfma_wide_keys(lib, case):
                                H * 128, H * 64, H * 64, 0.125, 0, None, L.BF16, stream()))
     torch.cuda.synchronize()
     assert relerr(o.float(), ref.float()) < 1.5e-2
+
+
+# ---- LDS-DMA staged GEMM (gemm_glds.hip): the large regular conv shapes of BigVGAN stages 1-3 ---------------------
+GLDS_CASES = [
+    # B, T, Cin, Cout, k, dil, mode        (tiles >= 384 so the dispatcher takes the glds kernel)
+    (2, 8192, 192, 192, 7, 3, "zeros"),    # BN = 64 tiles (N = 192), dilated taps, zero padding at both sequence ends
+    (3, 5461, 384, 384, 3, 1, "zeros"),    # BN = 128, M not a multiple of 128, batch boundaries inside tiles
+    (2, 8200, 128, 256, 11, 5, "reflect"),  # reflect padding resolved in the DMA source address
+    (1, 16384, 64, 1280, 1, 1, "zeros"),   # plain linear, one 64-channel stage
+]
+
+
+@pytest.mark.parametrize("case", GLDS_CASES)
+@pytest.mark.parametrize("out_f32", [False, True])
+def test_gemm_glds_conv(lib, case, out_f32):
+    B, T, Cin, Cout, k, dil, mode = case
+    x = rnd(f"gl.x{case}", (B, Cin, T)).to(torch.bfloat16)
+    w = rnd(f"gl.w{case}", (Cout, Cin, k), 1.0 / np.sqrt(Cin * k)).to(torch.bfloat16)
+    bias = rnd(f"gl.b{case}", (B, Cout), 0.1)
+    pad = dil * (k - 1) // 2
+    xp = F.pad(x.float(), (pad, pad), mode="reflect") if mode == "reflect" else F.pad(x.float(), (pad, pad))
+    ref = F.conv1d(xp, w.float(), None, dilation=dil) + bias[:, :, None]
+    res = rnd(f"gl.r{case}", (B, Cout, T)).to(torch.float32 if out_f32 else torch.bfloat16)
+    add = rnd(f"gl.a{case}", (B, Cout, T)).to(torch.float32 if out_f32 else torch.bfloat16)
+    ref = (ref + res.float()) * (1.0 / 3.0) + 0.5 * add.float()
+    A = x.transpose(1, 2).contiguous().to(DEV)
+    W = torch.from_numpy(pack.conv_w(w.float().numpy())).to(torch.bfloat16).to(DEV)
+    R, ADD = res.transpose(1, 2).contiguous().to(DEV), add.transpose(1, 2).contiguous().to(DEV)
+    outs = []
+    for env in (None, "1"):  # the glds kernel, then the register-staged one on the same arguments
+        import os
+
+        if env:
+            os.environ["ITTS_GEMM_FORCE_OLD"] = env
+        try:
+            outs.append(run_gemm(lib, A, W, (B, T, Cout), L.BF16, L.BF16, L.F32 if out_f32 else L.BF16, 0, M=B * T, N=Cout, Cin=Cin,
+                                 taps=k, lda=Cin, ldc=Cout, T=T, dil=dil, pad_left=pad, pad_mode=1 if mode == "reflect" else 0,
+                                 bias=bias.to(DEV), bias_bstride=Cout, R=R, ldr=Cout, alpha=1.0 / 3.0, ADD=ADD, ldadd=Cout, beta=0.5))
+        finally:
+            os.environ.pop("ITTS_GEMM_FORCE_OLD", None)
+    assert relerr(outs[0].float().transpose(1, 2), ref) < (3e-3 if out_f32 else 2e-2)
+    # both kernels accumulate the same bf16 products in fp32: they agree far inside the bf16 output rounding
+    assert relerr(outs[0].float(), outs[1].float()) < (1e-4 if out_f32 else 1e-2)
+
+
+def test_gemm_glds_transposed_conv(lib):
+    B, T, Cin, Cout, k, u = 2, 4096, 768, 384, 8, 4
+    p = (k - u) // 2
+    x = rnd("glt.x", (B, Cin, T)).to(torch.bfloat16)
+    w = rnd("glt.w", (Cin, Cout, k), 1.0 / np.sqrt(Cin * k / u)).to(torch.bfloat16)
+    bias = rnd("glt.b", (B, Cout), 0.1)
+    ref = F.conv_transpose1d(x.float(), w.float(), None, stride=u, padding=p) + bias[:, :, None]
+    A = x.transpose(1, 2).contiguous().to(DEV)
+    W = torch.from_numpy(pack.convT_w(w.float().numpy(), u, p)).to(torch.bfloat16).to(DEV)
+    out = run_gemm(lib, A, W, (B, T * u, Cout), L.BF16, L.BF16, L.BF16, 0, M=B * T, N=Cout, Cin=Cin, taps=k // u, lda=Cin,
+                   ldc=u * Cout, T=T, dil=-1, pad_left=0, nphase=u, phase_shift=[(ph + p) // u for ph in range(u)],
+                   bias=bias.to(DEV), bias_bstride=Cout)
+    assert relerr(out.float().transpose(1, 2), ref) < 2e-2
