@@ -477,6 +477,7 @@ int Engine::head_and_sample(hipStream_t s) {
       ta.seen = ds.seen;
     }
     ITTS_TRY(typical_filter(ta, B, s));
+    ITTS_TRY(tap("typical0", ds.scores2, F32, (int64_t)B * V, s));
     lg_in = ds.scores2;
   }
   if (ds.nb > 1) {  // beam-sample: one workgroup per batch item over its nb rows

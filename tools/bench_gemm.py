@@ -1,0 +1,72 @@
+#!/usr/bin/env python3
+"""A/B of the shift-GEMM kernels on the BigVGAN / GPT shapes of the bench (through the C ABI, HIP events):
+gemm_glds (LDS-DMA staged, default where supported) vs gemm_mfma (register staged, ITTS_GEMM_FORCE_OLD=1).
+    python tools/bench_gemm.py [--batch 1|32]   -> TFLOP/s per shape, both kernels"""
+import argparse
+import ctypes as C
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "index-tts-ipex_amd"))
+import torch  # noqa: E402
+
+from itts_hip import lib as L  # noqa: E402
+
+
+def run(lib, M, T, N, Cin, taps, dil, nphase=1, reps=10, old=False):
+    dev = "cuda:0"
+    A = torch.randn(M, Cin, device=dev).to(torch.bfloat16)
+    W = (torch.randn(nphase, N, taps * Cin, device=dev) / (taps * Cin) ** 0.5).to(torch.bfloat16)
+    Cout = torch.empty(M, nphase * N, device=dev, dtype=torch.bfloat16)
+    g = L.GemmArgs()
+    g.in_up, g.alpha = 1, 1.0
+    g.A, g.W, g.C = A.data_ptr(), W.data_ptr(), Cout.data_ptr()
+    g.M, g.N, g.Cin, g.taps, g.lda, g.ldc, g.T, g.dil, g.nphase = M, N, Cin, taps, Cin, nphase * N, T, dil, nphase
+    g.pad_left = (taps - 1) * dil // 2 if nphase == 1 else 0
+    g.dtype_a = g.dtype_w = g.dtype_c = L.BF16
+    if old:
+        os.environ["ITTS_GEMM_FORCE_OLD"] = "1"
+    else:
+        os.environ.pop("ITTS_GEMM_FORCE_OLD", None)
+    s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for _ in range(2):
+        L.check(lib.itts_gemm(C.byref(g), s))
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        lib.itts_gemm(C.byref(g), s)
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / reps
+    return us, 2.0 * M * N * nphase * taps * Cin / us / 1e6
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=32)
+    a = ap.parse_args()
+    lib = L.load()
+    rows = 2 * a.batch  # sentences
+    T0 = 480
+    shapes = [("conv_pre 1280->1536 k7", rows * T0, T0, 1536, 1280, 7, 1, 1)]
+    ch, Tc = 1536, T0
+    for i, (u, k) in enumerate(zip([4, 4, 4, 4], [8, 8, 4, 4])):
+        shapes.append((f"up{i} {ch}->{ch // 2} x{u}", rows * Tc, Tc, ch // 2, ch, k // u, -1, u))
+        ch //= 2
+        Tc *= u
+        if ch >= 192:
+            for kk, d in ((3, 1), (7, 3), (11, 5)):
+                shapes.append((f"amp{i} C={ch} k{kk} d{d}", rows * Tc, Tc, ch, ch, kk, d, 1))
+    n = 32 + 107 + 482
+    for nm, N, K in (("latent c_attn", 3840, 1280), ("latent c_proj", 1280, 1280), ("latent c_fc", 5120, 1280), ("latent proj2", 1280, 5120)):
+        shapes.append((nm, rows * n, rows * n, N, K, 1, 1, 1))
+    print(f"{'shape':28s} {'M':>9s}  {'glds us':>9s} {'TF/s':>7s}   {'old us':>9s} {'TF/s':>7s}  speedup")
+    for nm, M, T, N, Cin, taps, dil, nph in shapes:
+        new = run(lib, M, T, N, Cin, taps, dil, nph)
+        old = run(lib, M, T, N, Cin, taps, dil, nph, old=True)
+        print(f"{nm:28s} {M:9d}  {new[0]:9.1f} {new[1]:7.1f}   {old[0]:9.1f} {old[1]:7.1f}  {old[0] / new[0]:5.2f}x", flush=True)
+
+
+if __name__ == "__main__":
+    main()
