@@ -203,7 +203,11 @@ int launch(const GemmArgs& g, hipStream_t s) {
 
 }  // namespace
 
-// shapes this kernel takes from gemm_mfma: 64-channel stages, enough tiles to give every CU more than one
+// Shapes this kernel takes from gemm_mfma, from the A/B of tools/bench_gemm.py (profiles/r02_gemm_ab_*.txt): with two
+// stages per workgroup the DMA pipeline is shallower than gemm_mfma's register ring, so it wins where the K loop is
+// long (K = taps * Cin >= 4096: BigVGAN k = 7 / 11 convs at C >= 384, conv_pre; 1.1-1.3x) and on the 64-wide tile
+// (N = 192, BigVGAN stage 3: 1.1-1.5x), and loses on short K (k = 3, the 1280-deep GPT projections) and on the
+// polyphase transposed convs - those stay on the register-staged kernel.
 bool gemm_glds_supported(const GemmArgs& g, int ta, int tw, int tc) {
   if (ta != BF16 || tw != BF16 || (tc != BF16 && tc != F32)) return false;
   if (g.Cin % 64 != 0 || g.lda % 8 != 0 || g.in_up != 1 || g.nphase < 1 || g.nphase > 8) return false;
@@ -211,7 +215,8 @@ bool gemm_glds_supported(const GemmArgs& g, int ta, int tw, int tc) {
   if (g.N < 64 || g.M < 256) return false;
   const int bn = (g.N % 128 != 0 && g.N % 64 == 0 && g.N < 256) ? 64 : 128;
   const long tiles = (long)((g.M + BM - 1) / BM) * ((g.N + bn - 1) / bn) * g.nphase;
-  return tiles >= 384;
+  if (tiles < 384 || g.nphase != 1) return false;
+  return bn == 64 || (long)g.taps * g.Cin >= 4096;
 }
 
 int gemm_glds(const GemmArgs& g, int ta, int tw, int tc, hipStream_t s) {

@@ -395,11 +395,11 @@ def test_attention_mfma_wide_keys(lib, case):
 
 # ---- LDS-DMA staged GEMM (gemm_glds.hip): the large regular conv shapes of BigVGAN stages 1-3 ---------------------
 GLDS_CASES = [
-    # B, T, Cin, Cout, k, dil, mode        (tiles >= 384 so the dispatcher takes the glds kernel)
+    # B, T, Cin, Cout, k, dil, mode        (tiles >= 384 and K >= 4096 or N = 192, so the dispatcher takes the glds kernel)
     (2, 8192, 192, 192, 7, 3, "zeros"),    # BN = 64 tiles (N = 192), dilated taps, zero padding at both sequence ends
-    (3, 5461, 384, 384, 3, 1, "zeros"),    # BN = 128, M not a multiple of 128, batch boundaries inside tiles
-    (2, 8200, 128, 256, 11, 5, "reflect"),  # reflect padding resolved in the DMA source address
-    (1, 16384, 64, 1280, 1, 1, "zeros"),   # plain linear, one 64-channel stage
+    (3, 5461, 384, 384, 11, 1, "zeros"),   # BN = 128 (K = 4224), M not a multiple of 128, batch boundaries inside tiles
+    (2, 8200, 384, 256, 11, 5, "reflect"),  # reflect padding resolved in the DMA source address
+    (1, 16384, 4096, 1280, 1, 1, "zeros"),  # plain linear, K = 4096
 ]
 
 
