@@ -269,17 +269,20 @@ def measure(eng, cfg, a, BU, steps, warmup, rank, world):
     step_bytes = w_bytes + B * kv_per_pos * s_bar
     ms_step = dec_ms[0] / max(dec_steps[0], 1)
     achieved = step_bytes / (ms_step * 1e-3) / 1e9
-    # HBM traffic of the decode step: the committed rocprofv3 --pmc passes of THIS command (tools/round_profile.sh runs
-    # `bench.py --no-graph` at the same T, FETCH_SIZE / WRITE_SIZE in separate passes, gfx950 x2 correction) - a separate
-    # run, as counters cannot be read inside a timed run; only quoted when rows, T and dtype match it
+    # HBM traffic of the decode step: the committed rocprofv3 --pmc passes of this command (tools/round_profile.sh runs
+    # `bench.py --no-graph` with FETCH_SIZE / WRITE_SIZE in separate passes, gfx950 x2 correction, at the mean sequence
+    # length of this workload) - a separate run, as counters cannot be read inside a timed run; only quoted when rows,
+    # mean S and dtype match it
     traffic, traffic_src = None, None
     try:
         pm = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_decode.json"))
         for f in reversed(pm):
             pj = json.load(open(os.path.join(ROOT, "profiles", f)))
-            if (int(pj.get("decode_rows", -1)) == B and int(pj.get("mel_tokens", -1)) == T and a.dtype == "bf16"
+            if (int(pj.get("decode_rows", -1)) == B and abs(float(pj.get("mean_S", -1)) - s_bar) < 1.0 and a.dtype == "bf16"
                     and not a.micro and not a.gpt_fp8):
-                traffic, traffic_src = int(pj["hbm_bytes_per_step"]), f"profiles/{f} (separate --pmc passes of the same command)"
+                traffic = int(pj["hbm_bytes_per_step"])
+                traffic_src = (f"profiles/{f}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py --no-graph at this run's "
+                               f"mean sequence length (S = {s_bar:.0f}), 2 x FETCH_SIZE + WRITE_SIZE per decode step")
                 break
     except Exception:
         traffic = None

@@ -120,7 +120,7 @@ int itts_ecapa(itts_engine* e, const void* mel_bfc, int B, int F, float* spk_out
  * TemperatureLogitsWarper -> TopKLogitsWarper -> TopPLogitsWarper -> softmax -> one draw).  The draw is the inverse CDF
  * of uniforms_host[k * B + b] (step k, row b; host array of n_uniforms >= max_gen * B floats in [0, 1)) over the kept
  * tokens in descending-score order, so a caller-side RNG fixes the sequence.  do_sample = 0 returns to greedy.
- * 1 <= top_k <= 64, 0 < top_p <= 1, temperature > 0. */
+ * 1 <= top_k <= 128, 0 < top_p <= 1, temperature > 0. */
 int itts_gpt_set_sampling(itts_engine* e, int do_sample, int top_k, float top_p, float temperature, const float* uniforms_host,
                           int64_t n_uniforms);
 
@@ -132,9 +132,17 @@ int itts_gpt_set_sampling(itts_engine* e, int do_sample, int top_k, float top_p,
  * (per-beam ancestry rows).  itts_gpt_prefill then takes B batch items and runs B * num_beams rows (<= max_batch);
  * itts_gpt_fetch returns the finalized best hypothesis per batch item, codes [B, max_gen] padded with the stop token.
  * uniforms_host: [max_gen][B][2 * num_beams] floats in [0, 1): draw j of (step, item) is the inverse CDF of its uniform over
- * the not-yet-drawn candidates in flat (beam-major, token-ascending) order.  2 <= num_beams <= 4; num_beams <= 1 = off. */
+ * the not-yet-drawn candidates in flat (beam-major, token-ascending) order.  2 <= num_beams <= 10; num_beams <= 1 = off. */
 int itts_gpt_set_beam_sample(itts_engine* e, int num_beams, int top_k, float top_p, float temperature, const float* uniforms_host,
                              int64_t n_uniforms);
+
+/* The general beam entry point (itts_gpt_set_beam_sample = do_sample 1, length_penalty 0): do_sample = 0 selects HF
+ * beam_search - deterministic, per step the 2 * num_beams best of log_softmax + repetition penalty + beam score, no warpers,
+ * no uniforms - which is what `num_beams > 1, do_sample=False` means to generate(); length_penalty enters
+ * BeamHypotheses' score = sum_logprobs / generated_len ** length_penalty (infer.py:121 passes 0.0).  2 <= num_beams <= 10,
+ * top_k <= 128 (the web UI offers num_beams 1..10, top_k 0..100). */
+int itts_gpt_set_beams(itts_engine* e, int num_beams, int do_sample, int top_k, float top_p, float temperature, float length_penalty,
+                       const float* uniforms_host, int64_t n_uniforms);
 
 /* `typical_sampling=True` of UnifiedVoice.inference_speech (gpt/model.py:690-697): the reference's TypicalLogitsWarper
  * (utils/typical_sampling.py:9-30, mass in (0, 1); min_tokens_to_keep 2 under beams, else 1) runs right after the repetition

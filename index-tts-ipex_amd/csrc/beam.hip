@@ -17,8 +17,8 @@
 namespace itts {
 namespace {
 
-constexpr int MAXB = 4;    // beams per batch item
-constexpr int MAXC = 64;   // kept candidates per beam (top_k <= 64)
+constexpr int MAXB = 10;   // beams per batch item (the reference web UI offers 1..10)
+constexpr int MAXC = 128;  // kept candidates per beam (top_k <= 128; the UI offers 0..100)
 
 __device__ __forceinline__ unsigned okey(float v) {
   const unsigned u = __float_as_uint(v);
@@ -44,6 +44,29 @@ __device__ __forceinline__ float block_sum(float v, float* red, int tid) {
   return r;
 }
 
+// bitonic sort of MAXC (value, index) pairs in LDS by the whole block (every thread reaches the barriers).
+// BY_SCORE: descending value, ascending index on ties; else ascending index.
+template <bool BY_SCORE>
+__device__ __forceinline__ void sort_cands(float* cv, int* ci, int tid) {
+  for (int kq = 2; kq <= MAXC; kq <<= 1)
+    for (int j = kq >> 1; j > 0; j >>= 1) {
+      if (tid < MAXC / 2) {
+        const int lo = ((tid & ~(j - 1)) << 1) | (tid & (j - 1)), hi = lo | j;
+        const bool up = (lo & kq) == 0;
+        const float v0 = cv[lo], v1 = cv[hi];
+        const int i0 = ci[lo], i1 = ci[hi];
+        const bool second_first = BY_SCORE ? (v1 > v0 || (v1 == v0 && i1 < i0)) : (i1 < i0);
+        if (second_first == up) {
+          cv[lo] = v1;
+          cv[hi] = v0;
+          ci[lo] = i1;
+          ci[hi] = i0;
+        }
+      }
+      __syncthreads();
+    }
+}
+
 __global__ __launch_bounds__(1024) void beam_sample_kernel(BeamArgs a) {
   extern __shared__ float ssc[];  // [V] processed scores of the beam being worked on
   __shared__ unsigned seenw[512];  // V <= 16384 bits
@@ -54,6 +77,8 @@ __global__ __launch_bounds__(1024) void beam_sample_kernel(BeamArgs a) {
   __shared__ int cidx[MAXC];
   __shared__ float cand_sc[MAXB][MAXC];  // kept candidates per beam, token-ascending, running beam score included
   __shared__ int cand_tok[MAXB][MAXC];
+  __shared__ float cand_e[MAXB][MAXC];   // exp(score - max) and the not-yet-drawn flag of the draw loop
+  __shared__ unsigned char cand_alive[MAXB][MAXC];
   __shared__ int cand_n[MAXB];
   __shared__ int nxt_src[MAXB], nxt_tok[MAXB];  // new beam k continues physical row nxt_src[k] with token nxt_tok[k]
   __shared__ float nxt_score[MAXB];
@@ -69,6 +94,7 @@ __global__ __launch_bounds__(1024) void beam_sample_kernel(BeamArgs a) {
   const uint8_t* anc_old = a.anc + (size_t)par * Beff * a.Smax;
   uint8_t* anc_new = a.anc + (size_t)(par ^ 1) * Beff * a.Smax;
   const int was_done = a.done[bi];
+  const int nd = 2 * nb;
   if (!was_done) {
     for (int r = 0; r < nb; ++r) {
       const int row = bi * nb + r;
@@ -102,12 +128,13 @@ __global__ __launch_bounds__(1024) void beam_sample_kernel(BeamArgs a) {
           if (a.penalty != 1.f && ((seenw[i >> 5] >> (i & 31)) & 1u)) v = v < 0.f ? v * a.penalty : v / a.penalty;
           if (a.suppress_stop && i == a.stop) v = -INFINITY;
         }
-        if (a.temperature != 1.f) v = v / a.temperature;
+        if (a.do_sample && a.temperature != 1.f) v = v / a.temperature;  // warpers only exist in beam_sample
         ssc[i] = v;
       }
-      // ---- TopK: radix select of the kk-th largest key (kk = max(top_k, min_tokens_to_keep = 2)) ----
+      // ---- the kk largest scores by radix select: beam_sample TopK (kk = max(top_k, min_tokens_to_keep = 2));
+      //      beam_search (no warpers): the row can contribute at most the 2 * nb best of the batch item's 2 * nb ----
       unsigned prefix = 0;
-      int kk = min(max(a.top_k, 2), V);
+      int kk = a.do_sample ? min(max(a.top_k, 2), V) : min(nd, V);
       for (int pass = 3; pass >= 0; --pass) {
         const int shift = pass * 8;
         if (tid < 256) hist[tid] = 0;
@@ -148,6 +175,10 @@ __global__ __launch_bounds__(1024) void beam_sample_kernel(BeamArgs a) {
         kk = s_k;
       }
       if (tid == 0) s_cnt = 0;
+      if (tid < MAXC) {
+        cval[tid] = -INFINITY;
+        cidx[tid] = 0x7fffffff;
+      }
       __syncthreads();
       for (int i = tid; i < V; i += 1024) {
         const float v = ssc[i];
@@ -163,32 +194,11 @@ __global__ __launch_bounds__(1024) void beam_sample_kernel(BeamArgs a) {
       }
       __syncthreads();
       const int n = min(s_cnt, MAXC);
-      if (tid < 64) {
-        float v = lane < n ? cval[lane] : -INFINITY;
-        int ix = lane < n ? cidx[lane] : 0x7fffffff;
-        // descending score, ascending index on ties
-#pragma unroll
-        for (int kq = 2; kq <= 64; kq <<= 1) {
-#pragma unroll
-          for (int j = kq >> 1; j > 0; j >>= 1) {
-            const float ov = __shfl_xor(v, j, 64);
-            const int oi = __shfl_xor(ix, j, 64);
-            const bool up = (lane & kq) == 0, lower = (lane & j) == 0;
-            const bool other_better = ov > v || (ov == v && oi < ix);
-            if ((lower == up) ? other_better : !other_better) {
-              v = ov;
-              ix = oi;
-            }
-          }
-        }
-        cval[lane] = v;
-        cidx[lane] = ix;
-      }
-      __syncthreads();
+      sort_cands<true>(cval, cidx, tid);  // descending score, ascending index on ties
       if (tid == 0) {
         // TopP (ascending cumulative probability <= 1 - top_p goes; the best min_tokens_to_keep = 2 always stay)
         int R = n;
-        if (a.top_p < 1.f) {
+        if (a.do_sample && a.top_p < 1.f) {
           const float m = cval[0];
           float Z = 0.f;
           for (int q = 0; q < n; ++q) Z += expf(cval[q] - m);
@@ -207,32 +217,22 @@ __global__ __launch_bounds__(1024) void beam_sample_kernel(BeamArgs a) {
       }
       __syncthreads();
       const int R = s_cnt;
-      if (tid < 64) {
-        // the kept ones in token order (the flat index order of next_token_scores.view(batch, beams * vocab))
-        float v = lane < R ? cval[lane] : 0.f;
-        int ix = lane < R ? cidx[lane] : 0x7fffffff;
-#pragma unroll
-        for (int kq = 2; kq <= 64; kq <<= 1) {
-#pragma unroll
-          for (int j = kq >> 1; j > 0; j >>= 1) {
-            const float ov = __shfl_xor(v, j, 64);
-            const int oi = __shfl_xor(ix, j, 64);
-            const bool up = (lane & kq) == 0, lower = (lane & j) == 0;
-            const bool other_first = oi < ix;
-            if ((lower == up) ? other_first : !other_first) {
-              v = ov;
-              ix = oi;
-            }
-          }
-        }
-        cand_sc[r][lane] = v + a.beam_scores[row];
-        cand_tok[r][lane] = ix;
-        if (lane == 0) cand_n[r] = R;
+      if (tid < MAXC && tid >= R) {  // dropped by top-p (or never filled): out of the token-order sort
+        cval[tid] = 0.f;
+        cidx[tid] = 0x7fffffff;
+      }
+      __syncthreads();
+      // the kept ones in token order (the flat index order of next_token_scores.view(batch, beams * vocab))
+      sort_cands<false>(cval, cidx, tid);
+      if (tid < MAXC) {
+        cand_sc[r][tid] = cval[tid] + a.beam_scores[row];
+        cand_tok[r][tid] = cidx[tid];
+        if (tid == 0) cand_n[r] = R;
       }
       __syncthreads();
     }
   }
-  // ---- one thread: draws, sort, BeamSearchScorer.process ----
+  // ---- one thread: draws (or top-2nb), sort, BeamSearchScorer.process ----
   if (tid == 0) {
     n_add = 0;
     if (was_done) {
@@ -243,54 +243,77 @@ __global__ __launch_bounds__(1024) void beam_sample_kernel(BeamArgs a) {
       }
       s_done = 1;
     } else {
-      float m = -INFINITY;
-      for (int r = 0; r < nb; ++r)
-        for (int q = 0; q < cand_n[r]; ++q) m = fmaxf(m, cand_sc[r][q]);
-      bool alive[MAXB][MAXC];
-      float e[MAXB][MAXC];
-      for (int r = 0; r < nb; ++r)
-        for (int q = 0; q < cand_n[r]; ++q) {
-          alive[r][q] = true;
-          e[r][q] = expf(cand_sc[r][q] - m);
-        }
-      const int nd = 2 * nb;
       float psc[2 * MAXB];
       int ptok[2 * MAXB], pbeam[2 * MAXB];
-      const float* u = a.uniforms + ((size_t)k * a.B + bi) * nd;
-      for (int j = 0; j < nd; ++j) {
-        float total = 0.f;
+      if (a.do_sample) {
+        float m = -INFINITY;
         for (int r = 0; r < nb; ++r)
-          for (int q = 0; q < cand_n[r]; ++q)
-            if (alive[r][q]) total += e[r][q];
-        const float target = u[j] * total;
-        float c = 0.f;
-        int pr = -1, pq = -1, lr = -1, lq = -1;
-        for (int r = 0; r < nb && pr < 0; ++r)
+          for (int q = 0; q < cand_n[r]; ++q) m = fmaxf(m, cand_sc[r][q]);
+        for (int r = 0; r < nb; ++r)
           for (int q = 0; q < cand_n[r]; ++q) {
-            if (!alive[r][q]) continue;
-            lr = r;
-            lq = q;
-            c += e[r][q];
-            if (c >= target) {
-              pr = r;
-              pq = q;
-              break;
-            }
+            cand_alive[r][q] = 1;
+            cand_e[r][q] = expf(cand_sc[r][q] - m);
           }
-        if (pr < 0) {
-          pr = lr;
-          pq = lq;
+        const float* u = a.uniforms + ((size_t)k * a.B + bi) * nd;
+        for (int j = 0; j < nd; ++j) {
+          float total = 0.f;
+          for (int r = 0; r < nb; ++r)
+            for (int q = 0; q < cand_n[r]; ++q)
+              if (cand_alive[r][q]) total += cand_e[r][q];
+          const float target = u[j] * total;
+          float c = 0.f;
+          int pr = -1, pq = -1, lr = -1, lq = -1;
+          for (int r = 0; r < nb && pr < 0; ++r)
+            for (int q = 0; q < cand_n[r]; ++q) {
+              if (!cand_alive[r][q]) continue;
+              lr = r;
+              lq = q;
+              c += cand_e[r][q];
+              if (c >= target) {
+                pr = r;
+                pq = q;
+                break;
+              }
+            }
+          if (pr < 0) {
+            pr = lr;
+            pq = lq;
+          }
+          if (pr < 0) {  // fewer live candidates than draws (cannot happen with min_tokens_to_keep = 2): repeat a stop
+            psc[j] = -INFINITY;
+            ptok[j] = a.stop;
+            pbeam[j] = 0;
+            continue;
+          }
+          cand_alive[pr][pq] = 0;
+          psc[j] = cand_sc[pr][pq];
+          ptok[j] = cand_tok[pr][pq];
+          pbeam[j] = pr;
         }
-        if (pr < 0) {  // fewer live candidates than draws (cannot happen with min_tokens_to_keep = 2): repeat a stop
-          psc[j] = -INFINITY;
-          ptok[j] = a.stop;
-          pbeam[j] = 0;
-          continue;
+      } else {
+        // beam_search: torch.topk(next_token_scores.view(batch, beams * vocab), 2 * beams): repeatedly the best remaining
+        // candidate, the lower flat index on ties (each row holds its own best 2 * nb in token order)
+        for (int r = 0; r < nb; ++r)
+          for (int q = 0; q < cand_n[r]; ++q) cand_alive[r][q] = 1;
+        for (int j = 0; j < nd; ++j) {
+          int pr = -1, pq = -1;
+          for (int r = 0; r < nb; ++r)
+            for (int q = 0; q < cand_n[r]; ++q)
+              if (cand_alive[r][q] && (pr < 0 || cand_sc[r][q] > cand_sc[pr][pq])) {
+                pr = r;
+                pq = q;
+              }
+          if (pr < 0) {
+            psc[j] = -INFINITY;
+            ptok[j] = a.stop;
+            pbeam[j] = 0;
+            continue;
+          }
+          cand_alive[pr][pq] = 0;
+          psc[j] = cand_sc[pr][pq];
+          ptok[j] = cand_tok[pr][pq];
+          pbeam[j] = pr;
         }
-        alive[pr][pq] = false;
-        psc[j] = cand_sc[pr][pq];
-        ptok[j] = cand_tok[pr][pq];
-        pbeam[j] = pr;
       }
       // torch.sort(descending): stable insertion sort (equal scores keep draw order)
       for (int i = 1; i < nd; ++i) {
@@ -315,10 +338,11 @@ __global__ __launch_bounds__(1024) void beam_sample_kernel(BeamArgs a) {
       float worst = a.hyp_worst[bi];
       int counter = a.hyp_counter[bi];
       int filled = 0;
+      const float lpdiv = a.length_penalty == 0.f ? 1.f : powf((float)(k + 1), a.length_penalty);
       for (int rank = 0; rank < nd && filled < nb; ++rank) {
         if (ptok[rank] == a.stop) {
           if (rank >= nb) continue;
-          const float score = psc[rank];  // length_penalty 0: sum_logprobs / generated_len ** 0
+          const float score = psc[rank] / lpdiv;  // sum_logprobs / generated_len ** length_penalty
           if (hn < nb || score > worst) {
             int slot = 0;
             while (ho[slot] >= 0) ++slot;  // nb + 1 slots, at most nb in use here
@@ -357,8 +381,8 @@ __global__ __launch_bounds__(1024) void beam_sample_kernel(BeamArgs a) {
       a.hyp_n[bi] = hn;
       a.hyp_worst[bi] = worst;
       a.hyp_counter[bi] = counter;
-      // is_done(best_sum_logprobs = the best of the 2 * nb candidates, early_stopping False, length_penalty 0)
-      s_done = (hn >= nb && worst >= psc[0]) ? 1 : 0;
+      // is_done(best_sum_logprobs = the best of the 2 * nb candidates, cur_len = k + 1 generated; early_stopping False)
+      s_done = (hn >= nb && worst >= psc[0] / lpdiv) ? 1 : 0;
       a.done[bi] = s_done;
     }
   }
@@ -549,10 +573,11 @@ int typical_filter(const TypicalArgs& a, int rows, hipStream_t s) {
 }
 
 int beam_sample_step(const BeamArgs& a, hipStream_t s) {
-  ITTS_REQUIRE(a.nb >= 2 && a.nb <= MAXB, "beam_sample: 2 <= num_beams <= 4");
-  ITTS_REQUIRE(a.top_k >= 1 && a.top_k <= MAXC && a.top_p > 0.f && a.temperature > 0.f, "beam_sample: 1 <= top_k <= 64, top_p > 0, temperature > 0");
+  ITTS_REQUIRE(a.nb >= 2 && a.nb <= MAXB, "beam_sample: 2 <= num_beams <= 10");
+  ITTS_REQUIRE(!a.do_sample || (a.top_k >= 1 && a.top_k <= MAXC && a.top_p > 0.f && a.temperature > 0.f),
+               "beam_sample: 1 <= top_k <= 128, top_p > 0, temperature > 0");
   ITTS_REQUIRE(a.V <= 15000, "beam_sample: vocabulary too large for the LDS-resident sampler");
-  ITTS_REQUIRE(a.logits && a.uniforms && a.ids && a.anc && a.len && a.hyp_tok && a.done, "beam_sample: null state");
+  ITTS_REQUIRE(a.logits && (a.uniforms || !a.do_sample) && a.ids && a.anc && a.len && a.hyp_tok && a.done, "beam_sample: null state");
   hipLaunchKernelGGL(beam_sample_kernel, dim3(a.B), dim3(1024), (size_t)a.V * 4, s, a);
   ITTS_HIP_CHECK(hipGetLastError());
   return OK;

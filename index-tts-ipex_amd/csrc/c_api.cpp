@@ -188,6 +188,11 @@ int itts_gpt_set_beam_sample(itts_engine* e, int num_beams, int top_k, float top
   ENG(e);
   return e->e.gpt_set_beam_sample(num_beams, top_k, top_p, temperature, uniforms_host, (long)n_uniforms);
 }
+int itts_gpt_set_beams(itts_engine* e, int num_beams, int do_sample, int top_k, float top_p, float temperature, float length_penalty,
+                       const float* uniforms_host, int64_t n_uniforms) {
+  ENG(e);
+  return e->e.gpt_set_beams(num_beams, do_sample, top_k, top_p, temperature, length_penalty, uniforms_host, (long)n_uniforms);
+}
 int itts_gpt_set_typical(itts_engine* e, float mass) {
   ENG(e);
   return e->e.gpt_set_typical(mass);

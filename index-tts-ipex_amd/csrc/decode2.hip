@@ -1110,14 +1110,16 @@ __device__ __forceinline__ unsigned order_key(float v) {
   return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 
+constexpr int SMAXC = 128;  // kept candidates (top_k <= 128: the reference web UI offers 0..100)
+
 __global__ __launch_bounds__(1024) void sampler_sample_kernel(SamplerArgs a) {
   extern __shared__ float ssc[];  // [V] processed scores
   __shared__ unsigned hist[256];
   __shared__ int s_bin, s_k, s_cnt;
-  __shared__ float cval[64];
-  __shared__ int cidx[64];
+  __shared__ float cval[SMAXC];
+  __shared__ int cidx[SMAXC];
   __shared__ int si[2];
-  __shared__ float ce[64];
+  __shared__ float ce[SMAXC];
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
   const float* __restrict__ lg = a.logits + (size_t)b * a.V;
   const uint8_t* seen = a.seen + (size_t)b * a.V;
@@ -1173,48 +1175,45 @@ __global__ __launch_bounds__(1024) void sampler_sample_kernel(SamplerArgs a) {
     prefix |= (unsigned)s_bin << shift;
     kk = s_k;
   }
-  // ---- gather the survivors (score >= k-th largest; ties kept as HF's `scores < kth` mask keeps them, up to 64) ----
+  // ---- gather the survivors (score >= k-th largest; ties kept as HF's `scores < kth` mask keeps them, up to SMAXC) ----
   if (tid == 0) s_cnt = 0;
+  if (tid < SMAXC) {
+    cval[tid] = -INFINITY;
+    cidx[tid] = 0x7fffffff;
+  }
   __syncthreads();
   for (int i = tid; i < a.V; i += 1024) {
     const float v = ssc[i];
     // -inf scores never count: with fewer than top_k finite scores HF's `scores < kth` (kth = -inf) keeps exactly the finite ones
     if (order_key(v) >= prefix && v > -INFINITY) {
       const int pos = atomicAdd(&s_cnt, 1);
-      if (pos < 64) {
+      if (pos < SMAXC) {
         cval[pos] = v;
         cidx[pos] = i;
       }
     }
   }
   __syncthreads();
-  if (tid < 64) {
-    const int n = min(s_cnt, 64);
-    float v = lane < n ? cval[lane] : -INFINITY;
-    int ix = lane < n ? cidx[lane] : 0x7fffffff;
-    // bitonic sort across the wave: descending score, ascending index on ties
-#pragma unroll
-    for (int k = 2; k <= 64; k <<= 1) {
-#pragma unroll
-      for (int j = k >> 1; j > 0; j >>= 1) {
-        const float ov = __shfl_xor(v, j, 64);
-        const int oi = __shfl_xor(ix, j, 64);
-        const bool up = (lane & k) == 0;          // this k-block sorts "first is better"
-        const bool lower = (lane & j) == 0;       // this lane keeps the better of the pair when `up`
-        const bool other_better = ov > v || (ov == v && oi < ix);
-        const bool take = (lower == up) ? other_better : !other_better;
-        if (take) {
-          v = ov;
-          ix = oi;
+  // bitonic sort in LDS by the whole block: descending score, ascending index on ties
+  for (int kq = 2; kq <= SMAXC; kq <<= 1)
+    for (int j = kq >> 1; j > 0; j >>= 1) {
+      if (tid < SMAXC / 2) {
+        const int lo = ((tid & ~(j - 1)) << 1) | (tid & (j - 1)), hi = lo | j;
+        const bool up = (lo & kq) == 0;
+        const float v0 = cval[lo], v1 = cval[hi];
+        const int i0 = cidx[lo], i1 = cidx[hi];
+        const bool second_first = v1 > v0 || (v1 == v0 && i1 < i0);
+        if (second_first == up) {
+          cval[lo] = v1;
+          cval[hi] = v0;
+          cidx[lo] = i1;
+          cidx[hi] = i0;
         }
       }
+      __syncthreads();
     }
-    cval[lane] = v;
-    cidx[lane] = ix;
-  }
-  __syncthreads();
   if (tid == 0) {
-    const int n = min(s_cnt, 64);
+    const int n = min(s_cnt, SMAXC);
     const float m = cval[0];
     float* e = ce;
     float Z = 0.f;
@@ -1397,7 +1396,7 @@ int decode_attn2(void* ctx, int to, const float* qkv, void* kc, void* vc, const 
                  const int* prefix_dev, int B, int H, int dh, int Smax, int tc, hipStream_t s, int ctx_tiled, float* part_o,
                  float* part_ml, const uint8_t* anc, int nb) {
   ITTS_REQUIRE(dh == 64, "decode_attn2: head dim must be 64");
-  ITTS_REQUIRE(!anc || (nb >= 1 && nb <= 8 && B % nb == 0), "decode_attn2: beam ancestry needs B to be a multiple of 1 <= nb <= 8");
+  ITTS_REQUIRE(!anc || (nb >= 1 && nb <= 16 && B % nb == 0), "decode_attn2: beam ancestry needs B to be a multiple of 1 <= nb <= 16");
   if (part_o) {  // split form: 4 workgroups of 256 threads per (row, head), partials merged by the projection GEMV
     ITTS_REQUIRE(part_ml && tc == BF16, "decode_attn2: split form needs both partial buffers and a bf16 cache");
     const float scale = 1.f / sqrtf((float)dh);
@@ -1449,8 +1448,8 @@ int decode_attn2(void* ctx, int to, const float* qkv, void* kc, void* vc, const 
 
 int sampler2_step(const SamplerArgs& a, int B, hipStream_t s) {
   if (a.do_sample) {
-    ITTS_REQUIRE(a.uniforms && a.top_k >= 1 && a.top_k <= 64 && a.temperature > 0.f && a.top_p > 0.f && a.B == B,
-                 "sampler: sampling needs uniforms, 1 <= top_k <= 64, temperature > 0, top_p > 0");
+    ITTS_REQUIRE(a.uniforms && a.top_k >= 1 && a.top_k <= 128 && a.temperature > 0.f && a.top_p > 0.f && a.B == B,
+                 "sampler: sampling needs uniforms, 1 <= top_k <= 128, temperature > 0, top_p > 0");
     ITTS_REQUIRE((size_t)a.V * 4 <= 60 * 1024, "sampler: vocabulary too large for the LDS-resident sampler");
     hipLaunchKernelGGL(sampler_sample_kernel, dim3(B), dim3(1024), (size_t)a.V * 4, s, a);
     ITTS_HIP_CHECK(hipGetLastError());

@@ -135,6 +135,8 @@ struct DecodeState {
   size_t uniforms_cap = 0;
   // beam-sample (itts_gpt_set_beam_sample): B = batch items * nb rows; state of beam.hip
   int nb = 1, graph_nb = 1;          // beams per batch item (1 = off)
+  int beam_sample = 1, graph_beam_sample = 1;  // 1: beam_sample (draws), 0: beam_search (deterministic top-2nb)
+  float length_penalty = 0.f, graph_length_penalty = 0.f;
   int* beam_ids = nullptr;           // [2][B][max_gen]
   uint8_t* anc = nullptr;            // [2][B][Smax]
   float* beam_scores = nullptr;      // [B]
@@ -203,6 +205,10 @@ struct Engine {
   int gpt_set_forced(const int32_t* ids_host, int B, int n);
   int gpt_set_typical(float mass);
   int gpt_set_beam_sample(int num_beams, int top_k, float top_p, float temperature, const float* uniforms_host, long n);
+  int gpt_set_beams(int num_beams, int do_sample, int top_k, float top_p, float temperature, float length_penalty,
+                    const float* uniforms_host, long n);
+  int beam_do_sample = 1;
+  float beam_length_penalty = 0.f;
   int beam_beams = 1;  // requested beams for the following generations (1 = off)
   int ensure_beam_state(int rows, int max_gen, int Smax, hipStream_t s);
   int beam_finalize(int32_t* codes_host, hipStream_t s);

@@ -92,6 +92,8 @@ struct BeamArgs {
   const void* pos = nullptr;
   int D = 0, pos_rows = 0, emb_bf16 = 0;
   int preprocessed = 0;  // logits already went through typical_filter (log_softmax, penalty, stop suppression done)
+  int do_sample = 1;     // 1: beam_sample (warpers + draws from uniforms); 0: beam_search (top 2 * nb, no warpers)
+  float length_penalty = 0.f;  // BeamHypotheses score = sum_logprobs / generated_len ** length_penalty
 };
 int beam_sample_step(const BeamArgs& a, hipStream_t s);
 

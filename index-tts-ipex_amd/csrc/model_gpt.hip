@@ -52,11 +52,12 @@ __global__ void init_decode_state_kernel(uint8_t* seen, int* unfinished, int* cu
 // beam-sample state of a fresh generation: identity cache ancestry (every beam row reads its own prefix copy), zero
 // running scores (beam_sample starts all beams at 0, unlike beam_search), no finished hypotheses
 __global__ void beam_init_kernel(uint8_t* anc, float* beam_scores, int* hyp_order, int* hyp_n, float* hyp_worst,
-                                 int* hyp_counter, int* done, int rows, int nb, int Smax) {
+                                 int* hyp_counter, int* done, int rows, int nb, int Smax, int do_sample) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const long n = (long)rows * Smax;
   if (i < 2 * n) anc[i] = (uint8_t)(((i % n) / Smax) % nb);
-  if (i < rows) beam_scores[i] = 0.f;
+  // beam_sample starts every beam at 0; beam_search starts beams 1.. at -1e9 so that step 0 expands beam 0 only
+  if (i < rows) beam_scores[i] = (do_sample || i % nb == 0) ? 0.f : -1e9f;
   const int B = rows / nb;
   if (i < (long)B * (nb + 1)) hyp_order[i] = -1;
   if (i < B) {
@@ -207,21 +208,33 @@ int Engine::ensure_beam_state(int rows, int max_gen, int Smax, hipStream_t s) {
 // HF beam_sample configuration for the following generations (num_beams <= 1 switches it off): the generate() mode of
 // the reference's default kwargs (infer.py:116-124).  uniforms_host: row-major [max_gen][B][2 * num_beams] draws in [0, 1).
 int Engine::gpt_set_beam_sample(int num_beams, int top_k, float top_p, float temperature, const float* uniforms_host, long n) {
+  return gpt_set_beams(num_beams, 1, top_k, top_p, temperature, 0.f, uniforms_host, n);
+}
+
+// do_sample = 1: beam_sample as above; do_sample = 0: HF beam_search (deterministic: per step the 2 * num_beams best of
+// log_softmax + repetition penalty + running beam score, no warpers, no uniforms).  length_penalty as BeamHypotheses
+// uses it (score = sum_logprobs / generated_len ** length_penalty; the reference passes 0.0).
+int Engine::gpt_set_beams(int num_beams, int do_sample, int top_k, float top_p, float temperature, float length_penalty,
+                          const float* uniforms_host, long n) {
   if (num_beams <= 1) {
     beam_beams = 1;
     if (!ds.do_sample) sample_uniforms.clear();
     return OK;
   }
-  ITTS_REQUIRE(num_beams <= 4, "gpt_set_beam_sample: num_beams must be in [2, 4]");
-  ITTS_REQUIRE(top_k >= 1 && top_k <= 64, "gpt_set_beam_sample: top_k must be in [1, 64]");
-  ITTS_REQUIRE(top_p > 0.f && top_p <= 1.f && temperature > 0.f, "gpt_set_beam_sample: need 0 < top_p <= 1 and temperature > 0");
-  ITTS_REQUIRE(uniforms_host && n > 0, "gpt_set_beam_sample: uniforms missing");
+  ITTS_REQUIRE(num_beams <= 10, "gpt_set_beams: num_beams must be in [2, 10]");
+  if (do_sample) {
+    ITTS_REQUIRE(top_k >= 1 && top_k <= 128, "gpt_set_beams: top_k must be in [1, 128]");
+    ITTS_REQUIRE(top_p > 0.f && top_p <= 1.f && temperature > 0.f, "gpt_set_beams: need 0 < top_p <= 1 and temperature > 0");
+    ITTS_REQUIRE(uniforms_host && n > 0, "gpt_set_beams: uniforms missing");
+    sample_uniforms.assign(uniforms_host, uniforms_host + n);
+  }
   beam_beams = num_beams;
+  beam_do_sample = do_sample ? 1 : 0;
+  beam_length_penalty = length_penalty;
   ds.do_sample = 0;
   ds.top_k = top_k;
   ds.top_p = top_p;
   ds.temperature = temperature;
-  sample_uniforms.assign(uniforms_host, uniforms_host + n);
   return OK;
 }
 
@@ -262,9 +275,10 @@ int Engine::beam_finalize(int32_t* codes, hipStream_t s) {
       float worst = 1e9f;
       for (const Hyp& h : hy) worst = std::min(worst, h.score);
       int counter = 1 << 20;
+      const float lpdiv = d.length_penalty == 0.f ? 1.f : std::pow((float)k, d.length_penalty);  // generated_len = k here
       for (int q = 0; q < nb; ++q) {
         const int row = b * nb + q;
-        const float score = bscore[row];
+        const float score = bscore[row] / lpdiv;
         if ((int)hy.size() < nb || score > worst) {
           hy.push_back({score, counter++, k, ids.data() + (size_t)row * mg});
           if ((int)hy.size() > nb) {
@@ -320,15 +334,17 @@ int Engine::gpt_prefill(const float* cond_dev, const int32_t* text_ids_in, int B
   ds.penalty = penalty;
   ds.suppress_stop = suppress;
   ds.nb = nbeam;
+  ds.beam_sample = beam_do_sample;
+  ds.length_penalty = beam_length_penalty;
   if (nbeam > 1) {
     ITTS_REQUIRE(forced_n == 0, "gpt_prefill: forced tokens are not supported together with beams");
     ITTS_TRY(ensure_beam_state(B, max_gen, Smax, s));
     const long n_init = std::max<long>(2L * B * Smax, 64);
     hipLaunchKernelGGL(beam_init_kernel, dim3((unsigned)((n_init + 255) / 256)), dim3(256), 0, s, ds.anc, ds.beam_scores,
-                       ds.hyp_order, ds.hyp_n, ds.hyp_worst, ds.hyp_counter, ds.beam_done, B, nbeam, Smax);
+                       ds.hyp_order, ds.hyp_n, ds.hyp_worst, ds.hyp_counter, ds.beam_done, B, nbeam, Smax, beam_do_sample);
     ITTS_HIP_CHECK(hipGetLastError());
   }
-  if (ds.do_sample || nbeam > 1) {
+  if (ds.do_sample || (nbeam > 1 && beam_do_sample)) {
     const size_t need_u = nbeam > 1 ? (size_t)max_gen * B_items * 2 * nbeam : (size_t)max_gen * B;
     ITTS_REQUIRE(sample_uniforms.size() >= need_u,
                  "gpt_prefill: sampling enabled but fewer uniforms than max_gen * B (* 2 * num_beams) were supplied");
@@ -455,7 +471,7 @@ int Engine::head_and_sample(hipStream_t s) {
   }
   ITTS_TRY(tap("logits0", ds.logits, F32, (int64_t)B * V, s));
   const float* lg_in = ds.logits;
-  const bool typical = ds.typical_mass > 0.f && (ds.do_sample || ds.nb > 1);
+  const bool typical = ds.typical_mass > 0.f && (ds.do_sample || (ds.nb > 1 && ds.beam_sample));
   if (typical) {  // TypicalLogitsWarper sits in HF's logits_processor list, right after the repetition penalty
     TypicalArgs ta;
     ta.logits = ds.logits;
@@ -484,6 +500,8 @@ int Engine::head_and_sample(hipStream_t s) {
     BeamArgs ba;
     ba.logits = lg_in;
     ba.preprocessed = typical;
+    ba.do_sample = ds.beam_sample;
+    ba.length_penalty = ds.length_penalty;
     ba.V = V;
     ba.max_gen = ds.max_gen;
     ba.stop = c.stop_mel_token;
@@ -690,7 +708,7 @@ int Engine::gpt_set_sampling(int do_sample, int top_k, float top_p, float temper
     sample_uniforms.clear();
     return OK;
   }
-  ITTS_REQUIRE(top_k >= 1 && top_k <= 64, "gpt_set_sampling: top_k must be in [1, 64]");
+  ITTS_REQUIRE(top_k >= 1 && top_k <= 128, "gpt_set_sampling: top_k must be in [1, 128]");
   ITTS_REQUIRE(top_p > 0.f && top_p <= 1.f && temperature > 0.f, "gpt_set_sampling: need 0 < top_p <= 1 and temperature > 0");
   ITTS_REQUIRE(uniforms_host && n > 0, "gpt_set_sampling: uniforms missing");
   ds.do_sample = 1;
@@ -736,7 +754,8 @@ int Engine::gpt_decode(int nsteps, hipStream_t s) {
     // everything SamplerArgs carries by value is baked into the captured nodes: max_gen is the ids row stride and the
     // `k < max_gen` bound, so a per-request max_mel_tokens must re-capture (same B / Smax notwithstanding)
     const bool stale = !d.graph || d.graph_B != d.B || d.graph_Smax != d.Smax || d.graph_max_gen != d.max_gen ||
-                       d.graph_forced != d.use_forced || d.graph_nb != d.nb || d.graph_typical != d.typical_mass || d.graph_penalty != d.penalty || d.graph_suppress != d.suppress_stop || d.graph_sample != d.do_sample ||
+                       d.graph_forced != d.use_forced || d.graph_nb != d.nb || d.graph_beam_sample != d.beam_sample ||
+                       d.graph_length_penalty != d.length_penalty || d.graph_typical != d.typical_mass || d.graph_penalty != d.penalty || d.graph_suppress != d.suppress_stop || d.graph_sample != d.do_sample ||
                        d.graph_top_k != d.top_k || d.graph_top_p != d.top_p || d.graph_temperature != d.temperature;
     // two executables: one step, and GK steps back to back (one launch per GK tokens: the gap between consecutive graph
     // launches is paid once per GK steps; every step reads its lengths from device memory, so any mix is valid)
@@ -770,6 +789,8 @@ int Engine::gpt_decode(int nsteps, hipStream_t s) {
       d.graph_max_gen = d.max_gen;
       d.graph_forced = d.use_forced;
       d.graph_nb = d.nb;
+      d.graph_beam_sample = d.beam_sample;
+      d.graph_length_penalty = d.length_penalty;
       d.graph_typical = d.typical_mass;
       d.graph_penalty = d.penalty;
       d.graph_suppress = d.suppress_stop;

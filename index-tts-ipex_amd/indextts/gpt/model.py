@@ -57,15 +57,16 @@ class UnifiedVoice:
                          num_return_sequences=1, max_generate_length=None, typical_sampling=False, typical_mass=.9,
                          **hf_generate_kwargs):
         """Mel codes [b, <= max_generate_length] (model.py:655-708).  HF `generate` kwargs are accepted: greedy search
-        (do_sample=False), multinomial sampling (do_sample=True) and beam-sample (do_sample=True, num_beams 2..4) with
-        top_k <= 64, top_p, temperature, repetition_penalty run on the device; beam search without sampling and
-        typical_sampling fall back (RuntimeWarning).  `input_tokens` [b or 1, n] (model.py:672-686): given mel tokens the
+        (do_sample=False), multinomial sampling (do_sample=True), beam-sample (do_sample=True, num_beams 2..10) and beam
+        search (do_sample=False, num_beams > 1) with top_k <= 128, top_p, temperature, repetition_penalty, length_penalty
+        and typical_sampling run on the device.  `input_tokens` [b or 1, n] (model.py:672-686): given mel tokens the
         generation continues after; like the reference, the returned codes start after them."""
         if num_return_sequences != 1:
             raise NotImplementedError("num_return_sequences > 1")
         sample_kw = infer_core.sampling_kwargs(hf_generate_kwargs.get("do_sample", False), hf_generate_kwargs.get("num_beams", 1),
                                                hf_generate_kwargs.get("top_k", 50), hf_generate_kwargs.get("top_p", 1.0),
-                                               hf_generate_kwargs.get("temperature", 1.0), typical_sampling, typical_mass)
+                                               hf_generate_kwargs.get("temperature", 1.0), typical_sampling, typical_mass,
+                                               hf_generate_kwargs.get("length_penalty", 1.0))  # HF's own default is 1.0
         cond = self.get_conditioning(speech_conditioning_mel, cond_mel_lengths)
         ids = text_inputs.detach().cpu().numpy() if isinstance(text_inputs, torch.Tensor) else np.asarray(text_inputs)
         if ids.ndim == 1:

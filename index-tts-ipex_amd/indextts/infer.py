@@ -127,7 +127,7 @@ class IndexTTS:
         """Mel codes for a list of sentences: decode batches of at most `engine max_batch` rows (HF pads / stops per
         batch, so a group is exactly one `inference_speech` call of the reference)."""
         sample_kw = infer_core.sampling_kwargs(g["do_sample"], g["num_beams"], g["top_k"], g["top_p"], g["temperature"],
-                                               g["typical_sampling"], g["typical_mass"])
+                                               g["typical_sampling"], g["typical_mass"], g["length_penalty"])
         cap = max(1, self.engine.ccfg.max_batch // max(1, sample_kw.get("num_beams", 1)))
         rows = []
         for lo in range(0, len(sents), cap):

@@ -201,16 +201,18 @@ class Engine:
                                                u.ctypes.data_as(C.c_void_p), u.size), "gpt_set_sampling")
 
     def set_beam_sample(self, num_beams: int, top_k: int = 30, top_p: float = 0.8, temperature: float = 1.0,
-                        uniforms: Optional[np.ndarray] = None):
-        """HF beam_sample (the reference's default generate() mode, infer.py:116-124) for the following generations;
-        uniforms [max_gen, B, 2 * num_beams] float32 in [0, 1).  num_beams <= 1 switches it off."""
+                        uniforms: Optional[np.ndarray] = None, do_sample: bool = True, length_penalty: float = 0.0):
+        """HF beam_sample (do_sample: the reference's default generate() mode, infer.py:116-124; uniforms
+        [max_gen, B, 2 * num_beams] float32 in [0, 1)) or beam_search (not do_sample: deterministic) for the following
+        generations.  num_beams <= 1 switches beams off."""
         if num_beams <= 1:
-            L.check(self.lib.itts_gpt_set_beam_sample(self.h, 1, 1, 1.0, 1.0, None, 0), "gpt_set_beam_sample")
+            L.check(self.lib.itts_gpt_set_beams(self.h, 1, 1, 1, 1.0, 1.0, 0.0, None, 0), "gpt_set_beams")
             self._nb = 1
             return
-        u = np.ascontiguousarray(uniforms, dtype=np.float32)
-        L.check(self.lib.itts_gpt_set_beam_sample(self.h, int(num_beams), int(top_k), float(top_p), float(temperature),
-                                                  u.ctypes.data_as(C.c_void_p), u.size), "gpt_set_beam_sample")
+        u = np.ascontiguousarray(uniforms, dtype=np.float32) if do_sample else None
+        L.check(self.lib.itts_gpt_set_beams(self.h, int(num_beams), int(bool(do_sample)), int(top_k), float(top_p), float(temperature),
+                                            float(length_penalty), u.ctypes.data_as(C.c_void_p) if do_sample else None,
+                                            u.size if do_sample else 0), "gpt_set_beams")
         self._nb = int(num_beams)
 
     def set_forced(self, ids: Optional[np.ndarray]):
@@ -240,21 +242,22 @@ class Engine:
     def generate(self, cond: torch.Tensor, text_ids: np.ndarray, max_gen: int, repetition_penalty: float = 10.0,
                  suppress_stop: bool = False, check_every: int = 16, do_sample: bool = False, top_k: int = 30,
                  top_p: float = 0.8, temperature: float = 1.0, seed: Optional[int] = None,
-                 uniforms: Optional[np.ndarray] = None, num_beams: int = 1, typical_mass: float = 0.0) -> np.ndarray:
+                 uniforms: Optional[np.ndarray] = None, num_beams: int = 1, typical_mass: float = 0.0,
+                 length_penalty: float = 0.0) -> np.ndarray:
         """Greedy decode (do_sample=False, num_beams=1 of tests/padding_test.py:35-46) or, with do_sample, HF
         GenerationMixin.sample (top-k / top-p / temperature, num_beams=1; draws from `uniforms` or a numpy Generator
         seeded with `seed`).  Returns int64 codes [B, n] with n <= max_gen: HF stops when every row has emitted stop
-        or at max length.  num_beams > 1 (with do_sample): HF beam_sample over num_beams beams per row, uniforms
-        [max_gen, B, 2 * num_beams]; returns the best finalized hypothesis per row."""
-        beams = do_sample and num_beams > 1
+        or at max length.  num_beams > 1: HF beam_sample (do_sample; uniforms [max_gen, B, 2 * num_beams]) or beam_search
+        (not do_sample) over num_beams beams per row; returns the best finalized hypothesis per row."""
+        beams = num_beams > 1
         nrow = np.asarray(text_ids).shape[0]
         typical = bool(do_sample and typical_mass)
         if typical:  # typical_sampling=True (model.py:690-697): TypicalLogitsWarper in front of the warpers
             L.check(self.lib.itts_gpt_set_typical(self.h, float(typical_mass)), "gpt_set_typical")
         if beams:
-            if uniforms is None:
+            if uniforms is None and do_sample:
                 uniforms = np.random.default_rng(seed).random((max_gen, nrow, 2 * num_beams), dtype=np.float32)
-            self.set_beam_sample(num_beams, top_k, top_p, temperature, uniforms)
+            self.set_beam_sample(num_beams, top_k, top_p, temperature, uniforms, do_sample=do_sample, length_penalty=length_penalty)
         elif do_sample:
             if uniforms is None:
                 uniforms = np.random.default_rng(seed).random((max_gen, nrow), dtype=np.float32)

@@ -73,34 +73,35 @@ def pad_tokens_cat(tokens: Sequence[np.ndarray], stop_text_token: int) -> np.nda
     return out
 
 
-def sampling_kwargs(do_sample, num_beams, top_k, top_p, temperature, typical_sampling=False, typical_mass=0.9) -> dict:
-    """HF `generate` kwargs (infer.py:116-124) -> Engine.generate keywords.
-      do_sample, num_beams > 1   beam_sample (the reference default: 3 beams), up to 4 beams, on the device
-      do_sample, num_beams == 1  multinomial sampling on the device
-      not do_sample              greedy; num_beams > 1 without sampling (HF beam_search) is not implemented: warns, one beam
-      typical_sampling           the reference's TypicalLogitsWarper(typical_mass) in front of the warpers (sampling modes)
-    top_k outside [1, 64] (HF: 0 / None disable the warper) is clamped to 64 with a warning - the device samplers keep at
-    most 64 candidates per row.  The seed is drawn from torch's global RNG so that torch.manual_seed governs the run as it
-    does for the reference's torch.multinomial."""
+def sampling_kwargs(do_sample, num_beams, top_k, top_p, temperature, typical_sampling=False, typical_mass=0.9,
+                    length_penalty=0.0) -> dict:
+    """HF `generate` kwargs (infer.py:116-124) -> Engine.generate keywords; every mode runs on the device:
+      do_sample, num_beams > 1       beam_sample (the reference default: 3 beams)
+      do_sample, num_beams == 1      multinomial sampling
+      not do_sample, num_beams > 1   beam_search (deterministic)
+      not do_sample, num_beams == 1  greedy
+      typical_sampling               the reference's TypicalLogitsWarper(typical_mass) in front of the warpers (sampling modes)
+    Limits of the device samplers (the web UI offers num_beams 1..10 and top_k 0..100): num_beams <= 10; at most 128 kept
+    candidates per row, so top_k = 0 / None (HF: warper off) or > 128 is clamped to 128 with a warning.  The seed is drawn
+    from torch's global RNG so that torch.manual_seed governs the run as it does for the reference's torch.multinomial."""
     import warnings
 
     import torch
 
-    nb = 1 if num_beams is None else int(num_beams)
+    nb = 1 if num_beams is None else max(1, int(num_beams))
     if typical_sampling and not (0.0 < float(typical_mass) < 1.0):
         raise ValueError(f"`typical_mass` has to be a float > 0 and < 1, but is {typical_mass}")  # model.py:692-693
+    if nb > 10:
+        warnings.warn(f"itts_hip: num_beams={nb} > 10 is not supported; using 10", RuntimeWarning)
+        nb = 10
+    lp = float(length_penalty or 0.0)
     if not do_sample:
-        if nb != 1:
-            warnings.warn("itts_hip: beam search without sampling is not implemented; decoding greedily with num_beams=1", RuntimeWarning)
-        return {}
-    if nb > 4:
-        warnings.warn(f"itts_hip: num_beams={nb} > 4 is not supported; using 4", RuntimeWarning)
-        nb = 4
+        return dict(num_beams=nb, length_penalty=lp) if nb > 1 else {}
     k = int(top_k) if top_k else 0
-    if k < 1 or k > 64:
-        warnings.warn(f"itts_hip: top_k={top_k} is outside [1, 64]; using 64", RuntimeWarning)
-        k = 64
+    if k < 1 or k > 128:
+        warnings.warn(f"itts_hip: top_k={top_k} is outside [1, 128]; using 128", RuntimeWarning)
+        k = 128
     p = 1.0 if top_p is None else float(top_p)
-    return dict(do_sample=True, top_k=k, top_p=min(max(p, 1e-6), 1.0), temperature=float(temperature or 1.0), num_beams=max(nb, 1),
-                typical_mass=float(typical_mass) if typical_sampling else 0.0,
+    return dict(do_sample=True, top_k=k, top_p=min(max(p, 1e-6), 1.0), temperature=float(temperature or 1.0), num_beams=nb,
+                typical_mass=float(typical_mass) if typical_sampling else 0.0, length_penalty=lp,
                 seed=int(torch.randint(0, 2 ** 31 - 1, (1,)).item()))

@@ -243,7 +243,7 @@ def sample_distribution(scores, top_k: int, top_p: float, temperature: float):
     kth = np.partition(s, V - k)[V - k]  # TopK: keeps everything >= the k-th largest (ties stay)
     idx = np.nonzero(s >= kth)[0]
     order = np.lexsort((idx, -s[idx].astype(np.float64)))
-    idx = idx[order][:64]
+    idx = idx[order][:128]
     v = s[idx]
     e = np.exp((v - v[0]).astype(np.float32)).astype(np.float32)
     Z = np.float32(0)
@@ -348,7 +348,8 @@ def latent_forward(cond, text_tokens, codes, w: W, cfg_gpt):
 
 def beam_sample_generate(cond, text_inputs, w: W, cfg_gpt, max_generate_length: int, num_beams: int = 3, top_k: int = 30,
                          top_p: float = 0.8, temperature: float = 1.0, repetition_penalty: float = 10.0,
-                         length_penalty: float = 0.0, uniforms=None, trace: Optional[dict] = None, typical_mass: float = 0.0):
+                         length_penalty: float = 0.0, uniforms=None, trace: Optional[dict] = None, typical_mass: float = 0.0,
+                         do_sample: bool = True):
     """UnifiedVoice.inference_speech under the reference's DEFAULT kwargs (infer.py:116-124: do_sample=True, num_beams=3,
     top_k=30, top_p=0.8, length_penalty=0.0, repetition_penalty=10.0): HF 4.36.2 GenerationMixin.beam_sample +
     BeamSearchScorer, restated in oracle/hf_beam.py, over this module's GPT-2 stack with the KV cache re-ordered by
@@ -373,6 +374,8 @@ def beam_sample_generate(cond, text_inputs, w: W, cfg_gpt, max_generate_length: 
     prompt_len = s + 1
     scorer = hf_beam.BeamSearchScorer(b, nb, length_penalty=length_penalty, max_length=prompt_len + max_generate_length)
     beam_scores = np.zeros(b * nb, dtype=np.float32)
+    if not do_sample:  # beam_search: `beam_scores[:, 1:] = -1e9`, so that step 0 expands beam 0 only
+        beam_scores.reshape(b, nb)[:, 1:] = -1e9
     step = 0
     steps_log = []
     while True:
@@ -380,6 +383,23 @@ def beam_sample_generate(cond, text_inputs, w: W, cfg_gpt, max_generate_length: 
         lp = torch.log_softmax(logits, dim=-1)
         lp = repetition_penalty_(lp.clone(), ids, repetition_penalty) if repetition_penalty != 1.0 else lp
         lpn = lp.numpy()
+        if not do_sample:
+            # HF beam_search: processors only (no warpers), torch.topk over the flat [beams * V] scores
+            flat = (lp + torch.from_numpy(beam_scores)[:, None]).view(b, nb * V)
+            top = torch.topk(flat, 2 * nb, dim=1, largest=True, sorted=True)
+            ns, ni, nt = top.values.numpy(), (top.indices // V).numpy(), (top.indices % V).numpy()
+            ids_np = ids.numpy()
+            beam_scores, btok, bidx = scorer.process(ids_np, ns, nt, ni, stop, stop, prompt_len)
+            bidx_t = torch.from_numpy(bidx)
+            ids = torch.cat([ids[bidx_t], torch.from_numpy(btok)[:, None]], dim=1)
+            mask = torch.cat([mask, torch.ones(b * nb, 1, dtype=torch.long)], dim=1)
+            past = [(kk[bidx_t], vv[bidx_t]) for kk, vv in past]
+            step += 1
+            if scorer.is_done or ids.shape[1] >= prompt_len + max_generate_length:
+                break
+            e = mel_emb[ids[:, -1]][:, None] + mel_pos[mask.shape[1] - s][None, None]
+            h, past = gpt2_stack(e, w, cfg_gpt, key_mask=mask, past=past)
+            continue
         if typical_mass:  # logits_processor list: RepetitionPenalty, then the reference's TypicalLogitsWarper (model.py:690-697)
             lpn = np.stack([hf_beam.typical_filter(lpn[r], typical_mass, 2) for r in range(lpn.shape[0])])
         ns, nt, ni = [], [], []

@@ -133,7 +133,7 @@ def warp_row(lp: np.ndarray, top_k: int, top_p: float, temperature: float, min_k
     kth = np.partition(s, V - k)[V - k]
     idx = np.nonzero(s >= kth)[0]
     order = np.lexsort((idx, -s[idx].astype(np.float64)))  # descending score, ascending index on ties
-    idx = idx[order][:64]
+    idx = idx[order][:128]
     v = s[idx]
     R = len(idx)
     if top_p is not None and top_p < 1.0:

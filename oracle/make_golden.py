@@ -134,7 +134,7 @@ def ref_greedy(gpt, cond_mel, text, max_gen, rep=10.0, n_trace=None, suppress_eo
 
 
 def ref_beam_sample(gpt, cond_mel, text, max_gen, uniforms, nb=3, top_k=30, top_p=0.8, temperature=1.0, rep=10.0,
-                    length_penalty=0.0, typical_mass=0.0):
+                    length_penalty=0.0, typical_mass=0.0, do_sample=True):
     """Hand-rolled HF-4.36.2 `beam_sample` over the reference's own GPT2InferenceModel.forward / _reorder_cache with the
     INSTALLED transformers logits processors / warpers (min_tokens_to_keep = 2 under beams) and the BeamSearchScorer
     restatement of oracle/hf_beam.py; torch.multinomial is replaced by the shared-uniform sequential draw."""
@@ -169,6 +169,8 @@ def ref_beam_sample(gpt, cond_mel, text, max_gen, uniforms, nb=3, top_k=30, top_
     prompt_len = s + 1
     scorer = hf_beam.BeamSearchScorer(b, nb, length_penalty=length_penalty, max_length=prompt_len + max_gen)
     beam_scores = np.zeros(b * nb, dtype=np.float32)
+    if not do_sample:  # beam_search initialisation
+        beam_scores.reshape(b, nb)[:, 1:] = -1e9
     past, step = None, 0
     while True:
         inp = ids if past is None else ids[:, -1:]
@@ -178,11 +180,16 @@ def ref_beam_sample(gpt, cond_mel, text, max_gen, uniforms, nb=3, top_k=30, top_
         sc = proc(ids, sc.clone())
         if typical is not None:
             sc = typical(ids, sc)
-        for wp in warpers:
-            sc = wp(ids, sc)
+        if do_sample:
+            for wp in warpers:
+                sc = wp(ids, sc)
         scn = sc.numpy()
         ns, nt, ni = [], [], []
-        for bi in range(b):
+        if not do_sample:  # beam_search: torch.topk over [beams * V]
+            flat = (sc + torch.from_numpy(beam_scores)[:, None]).view(b, nb * V)
+            top = torch.topk(flat, 2 * nb, dim=1, largest=True, sorted=True)
+            ns, ni, nt = list(top.values.numpy()), list((top.indices // V).numpy()), list((top.indices % V).numpy())
+        for bi in range(b if do_sample else 0):
             cands = []
             for r in range(nb):
                 row = scn[bi * nb + r]
@@ -322,6 +329,12 @@ def micro_fixtures():
     u = rng.random((20, 2, 6), dtype=np.float32)
     txt = torch.cat([text, text2], 0)
     codes_t = ref_beam_sample(gpt, mel, txt, 20, u, nb=3, top_k=30, top_p=0.8, temperature=1.0, typical_mass=0.6)
+    for tag, (nb_, ds_, lp_, tk_, n_) in {"search3": (3, False, 0.0, 30, 20), "search5_lp": (5, False, 1.0, 30, 16),
+                                           "sample5_lp": (5, True, 0.7, 100, 16)}.items():
+        u5 = rng.random((n_, 2, 2 * nb_), dtype=np.float32)
+        cb = ref_beam_sample(gpt, mel, txt, n_, u5, nb=nb_, top_k=tk_, top_p=0.8, temperature=1.0, length_penalty=lp_, do_sample=ds_)
+        save(f"micro_beam_{tag}", text=txt, codes=cb, uniforms=u5, num_beams=nb_, top_k=tk_, top_p=0.8, temperature=1.0, max_gen=n_,
+             length_penalty=lp_, do_sample=int(ds_))
     save("micro_beam_typical", text=txt, codes=codes_t, uniforms=u, num_beams=3, top_k=30, top_p=0.8, temperature=1.0, max_gen=20,
          typical_mass=0.6)
 

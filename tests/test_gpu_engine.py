@@ -273,15 +273,17 @@ def test_fp8_decode_weights_equal_their_dequantisation(gold):
 
 
 # ---- beam-sample: the reference's DEFAULT generate() mode (num_beams = 3) --------------------------------------------
-@pytest.mark.parametrize("tag", ["a", "b", "c", "typical"])
+@pytest.mark.parametrize("tag", ["a", "b", "c", "typical", "search3", "search5_lp", "sample5_lp"])
 def test_beam_sample_ids_match_reference_fixture_fp32(eng32, gold, tag):
     """Engine beam-sample (device sampler + BeamSearchScorer + cache ancestry + host finalize) against the fixture the
     reference's GPT2InferenceModel / _reorder_cache produced with the same uniforms (make_golden.ref_beam_sample): the
     finalized best hypotheses are bit-exact, graph replay == eager launches."""
     c, g = gold("micro_conditioning"), gold(f"micro_beam_{tag}")
     cond = torch.from_numpy(c["cond"])
-    kw = dict(do_sample=True, num_beams=int(g["num_beams"]), top_k=int(g["top_k"]), top_p=float(g["top_p"]),
+    kw = dict(do_sample=bool(int(g["do_sample"])) if "do_sample" in g else True,  # False: HF beam_search (deterministic)
+              num_beams=int(g["num_beams"]), top_k=int(g["top_k"]), top_p=float(g["top_p"]),
               temperature=float(g["temperature"]), uniforms=g["uniforms"],
+              length_penalty=float(g["length_penalty"]) if "length_penalty" in g else 0.0,
               typical_mass=float(g["typical_mass"]) if "typical_mass" in g else 0.0)  # the reference's TypicalLogitsWarper
     codes = eng32.generate(cond, g["text"], int(g["max_gen"]), **kw)
     assert codes.shape == g["codes"].shape, (codes.shape, g["codes"].shape)

@@ -114,7 +114,7 @@ def test_beam_hypotheses_bookkeeping():
     assert len(h) == 2
 
 
-@pytest.mark.parametrize("tag", ["a", "b", "c", "typical"])
+@pytest.mark.parametrize("tag", ["a", "b", "c", "typical", "search3", "search5_lp", "sample5_lp"])
 def test_beam_sample_generate_matches_reference_fixture(gold, tag):
     """oracle.gpt.beam_sample_generate (own GPT-2 stack + own warper restatement) against the fixture produced by the
     reference's GPT2InferenceModel.forward / _reorder_cache + the installed transformers warpers (make_golden.ref_beam_sample),
@@ -127,7 +127,9 @@ def test_beam_sample_generate_matches_reference_fixture(gold, tag):
         cond = ogpt.get_conditioning(mel, w, cfg.gpt)
         out = ogpt.beam_sample_generate(cond, torch.from_numpy(g["text"]).long(), w, cfg.gpt, int(g["max_gen"]), num_beams=int(g["num_beams"]),
                                         top_k=int(g["top_k"]), top_p=float(g["top_p"]), temperature=float(g["temperature"]),
-                                        uniforms=g["uniforms"], typical_mass=float(g["typical_mass"]) if "typical_mass" in g else 0.0)
+                                        uniforms=g["uniforms"], typical_mass=float(g["typical_mass"]) if "typical_mass" in g else 0.0,
+                                        length_penalty=float(g["length_penalty"]) if "length_penalty" in g else 0.0,
+                                        do_sample=bool(int(g["do_sample"])) if "do_sample" in g else True)
     assert np.array_equal(out.numpy(), g["codes"]), (out.numpy(), g["codes"])
 
 

@@ -6,18 +6,24 @@ tag=${1:-rXX}
 out=$GRAFT_REPO_ROOT/gpurun_out/$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 > $out/bench.json 2> $out/bench.err
+if [ -z "$ONLY_PMC" ]; then
+python3 $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 1 > $out/bench.json 2> $out/bench.err
 tail -1 $out/bench.json | cut -c1-300
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $out/bench_profiled.json 2> $out/prof.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-also > $out/bench_profiled.json 2> $out/prof.err
 t=$(find $out/stats -name "*kernel_trace.csv" | head -1)
 python3 $GRAFT_REPO_ROOT/tools/trace_summary.py "$t" > $out/kernel_summary.txt
 cp $(find $out/stats -name "*kernel_stats.csv" | head -1) $out/kernel_stats.csv
 rm -rf $out/stats
 head -12 $out/kernel_summary.txt | cut -c1-200
-# PMC passes: eager launches (no hipGraph), short decode; each counter in its own pass (TCC slot limits)
-PT=48
+fi
+# PMC passes: eager launches (counters hang under hipGraph replay); each counter in its own pass (TCC slot limits),
+# --kernel-trace only beside --pmc.  rocprofv3 segfaults past ~30 k counted dispatches (T = 480 is 58 k), so the passes run
+# 48 steps at the bench's MEAN sequence length instead: text prefix lengthened to L = 320 -> S0 = 355, S_mean = 355 + 24 =
+# 379 = the bench's 140 + 480 / 2 - same kernels, same grid, same bytes per step as the average step of the timed run
+PT=${PMC_T:-48}
+PL=${PMC_L:-320}
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout -k 10 400 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $out/pmc_$c -- python3 $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --mel-tokens $PT --no-graph --no-cpu-baseline > $out/pmc_$c.json 2> $out/pmc_$c.err
+  timeout -k 10 500 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $out/pmc_$c -- python3 $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --mel-tokens $PT --text-tokens $PL --no-graph --no-cpu-baseline --no-also > $out/pmc_$c.json 2> $out/pmc_$c.err
   f=$(find $out/pmc_$c -name "*counter_collection.csv" | head -1)
   python3 $GRAFT_REPO_ROOT/tools/pmc_summary.py "$f" $c $out/pmc_${c}_step.json > $out/pmc_$c.txt
   rm -rf $out/pmc_$c
@@ -26,14 +32,15 @@ done
 python3 - <<PY
 import json
 f = json.load(open("$out/pmc_FETCH_SIZE_step.json")); w = json.load(open("$out/pmc_WRITE_SIZE_step.json"))
-D, NL, V, B, L, T = 1280, 24, 8194, 2, 105, $PT
+D, NL, V, B, L, T = 1280, 24, 8194, 2, $PL, $PT
 alg = (NL * (12 * D * D + 13 * D) + 4 * D + D * V + V) * 2 + B * 2 * NL * D * 2 * ((32 + L + 2 + 1) + T / 2.0)
 hbm = (2.0 * f["per_step_units"] + w["per_step_units"]) * 1024   # FETCH_SIZE under-reports 2x on gfx950 (MI355X_MICROARCH HBM)
-json.dump({"mel_tokens": T, "decode_rows": B, "fetch_kib_raw_per_step": f["per_step_units"], "write_kib_per_step": w["per_step_units"],
+json.dump({"mel_tokens": T, "text_tokens": L, "mean_S": (32 + L + 2 + 1) + T / 2.0, "decode_rows": B, "fetch_kib_raw_per_step": f["per_step_units"], "write_kib_per_step": w["per_step_units"],
            "hbm_bytes_per_step": hbm, "algorithmic_bytes_per_step": alg, "traffic_over_algorithmic": hbm / alg},
           open("$out/pmc_decode.json", "w"), indent=1)
 print(open("$out/pmc_decode.json").read())
 PY
+[ -n "$ONLY_PMC" ] && exit 0
 # BASELINE config 3 (32 utterances per GPU = 64 decode rows): bench line + kernel summary
 python3 $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --batch 32 --no-cpu-baseline > $out/bench_b32.json 2> $out/bench_b32.err
 tail -1 $out/bench_b32.json | cut -c1-300
