@@ -986,6 +986,523 @@ __global__ __launch_bounds__(NT) void decode_attn2_kernel(TO* __restrict__ ctx, 
   ATTN_STAMP(6)
 }
 
+// ---------------------------------------------------------------------------------------------
+// qkv_attn_fused: LN + c_attn projection AND the cache attention of the same layer in ONE launch (decode batches <= 4).
+// Of the five phase boundaries of a layer this is the only one that is not an all-to-all: an attention workgroup
+// (row, head, key split) needs 192 of the 3 * D projection outputs, written by 24 of the 480 projection workgroups.
+// The grid is [projection workgroups | attention workgroups]; the attention workgroups request their K/V cache rows at
+// once (blind pairs + the rest once the length is known) and then POLL for q / k / v, which the projection workgroups
+// publish as 8-byte {value, tag} granules (one relaxed agent-scope store each: written through, L2-served on any XCD, the
+// tag travels with the value so no fence is needed - MI355X_MICROARCH "R2's granule"; tools/ubench_handoff.hip measures
+// the hop).  tag = (generation epoch << 12) | (step + 1), read from device memory, so the captured graph never sees a
+// stale match.  All workgroups of the launch are co-resident (640 x 256 threads at 2 rows), so the spin cannot starve
+// its producers; it is bounded anyway and raises an error flag instead of hanging.  Saves the kernel boundary and
+// overlaps the cache stream with the projection: 5.2 + 4.9 us -> see DESIGN.md section 5.
+// ---------------------------------------------------------------------------------------------
+template <int NB, int RPW, int NCH>
+__device__ __forceinline__ void fused_gemv_part(const GemvArgs& g, int blk, unsigned long long* __restrict__ gran, unsigned tag) {
+  constexpr int PRO = 1, WAVES = 4;
+  constexpr bool XBF = false, W8 = false;
+  constexpr int NTHR = WAVES * 64;
+  constexpr int EPC = XBF ? 8 : 4;                                  // elements per 16-byte chunk
+  constexpr int KCH = (NCH * 512 + NTHR * EPC - 1) / (NTHR * EPC);  // chunks per row per thread
+  extern __shared__ __attribute__((aligned(16))) uint32_t sxb[];    // [NB][K/2] bf16 pairs
+  __shared__ float red[2][WAVES][2 * NB];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int K = g.K;
+  const float invK = 1.f / (float)K;  // off the critical path: the LayerNorm chain multiplies instead of dividing
+  const int n0 = (blk * WAVES + wave) * RPW;
+  // ---- 1. activations (+ LayerNorm parameters) first, weights second; all unconditional ----
+  u32x4 xr[NB][KCH];  // XBF: 8 bf16; else 4 floats
+  f32x4 pm[PRO == 3 ? NB : 1][KCH], pl[PRO == 3 ? NB : 1][KCH], po[PRO == 3 ? NB : 1][KCH][ATTN_NSPLIT][2];
+  static_assert(PRO != 3 || (XBF && ATTN_NSPLIT == 4), "prologue 3 feeds bf16 pairs and reads 4 partials as one float4");
+  f32x4 gm[PRO == 2 ? KCH : 1], bt[PRO == 2 ? KCH : 1];
+  bool xok[KCH];
+#pragma unroll
+  for (int j = 0; j < KCH; ++j) {
+    const int i = (tid + j * NTHR) * EPC;
+    xok[j] = i < K;
+    const int ic = xok[j] ? i : K - EPC;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      const size_t ro = (size_t)min(b, g.B - 1) * K + ic;
+      if constexpr (PRO == 3) {
+        // x is the attention output, still in ATTN_NSPLIT partials: this thread's 8 dims of head ic / 64
+        const size_t bh = (size_t)min(b, g.B - 1) * (K >> 6) + (ic >> 6);
+        const float* ml = g.attn_ml + bh * 2 * ATTN_NSPLIT;
+        pm[b][j] = *reinterpret_cast<const f32x4*>(ml);
+        pl[b][j] = *reinterpret_cast<const f32x4*>(ml + ATTN_NSPLIT);
+#pragma unroll
+        for (int sp = 0; sp < ATTN_NSPLIT; ++sp) {
+          const float* po_ = g.attn_o + (bh * ATTN_NSPLIT + sp) * 64 + (ic & 63);
+          po[b][j][sp][0] = *reinterpret_cast<const f32x4*>(po_);
+          po[b][j][sp][1] = *reinterpret_cast<const f32x4*>(po_ + 4);
+        }
+      } else if (XBF) {
+        xr[b][j] = *reinterpret_cast<const u32x4*>((const bf16_t*)g.X + ro);
+      } else {
+        xr[b][j] = *reinterpret_cast<const u32x4*>(g.X + ro);
+      }
+    }
+    if (PRO == 2) {
+      gm[j] = *reinterpret_cast<const f32x4*>(g.ln_gamma + ic);
+      bt[j] = *reinterpret_cast<const f32x4*>(g.ln_beta + ic);
+    }
+  }
+  float pivot[NB];
+#pragma unroll
+  for (int b = 0; b < NB; ++b) pivot[b] = (PRO == 1 || PRO == 2) ? g.X[(size_t)min(b, g.B - 1) * K] : 0.f;
+  const bf16_t* __restrict__ W = (const bf16_t*)g.W;
+  const uint8_t* __restrict__ Wq = (const uint8_t*)g.W8;
+  u32x4 w[W8 ? 1 : RPW][W8 ? 1 : NCH];
+  u32x2 w8[W8 ? RPW : 1][W8 ? NCH : 1];  // 8 fp8 weights per lane and chunk
+  const int klast = (NCH - 1) * 512 + lane * 8;
+  const bool kok = klast < K;
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int k = c == NCH - 1 ? (kok ? klast : K - 8) : c * 512 + lane * 8;
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+      if constexpr (W8)
+        w8[r][c] = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(Wq + (size_t)min(n0 + r, g.N - 1) * K + k));
+      else
+        w[r][c] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(W + (size_t)min(n0 + r, g.N - 1) * K + k));
+    }
+  }
+  // epilogue operands of the output this lane will finish, (row lane / NB, batch lane % NB): bias, fp8 row scale and the
+  // residual-stream value it accumulates into are requested now (youngest loads, unconditional), so the epilogue has no
+  // dependent memory latency of its own
+  const int er = min(lane / NB, RPW - 1), eb = lane % NB;
+  const int en = min(n0 + er, g.N - 1);
+  const float* bp = g.bias ? g.bias : reinterpret_cast<const float*>(W8 ? g.W8 : g.W);  // any readable address when there is no bias
+  const float bpre = bp[en];
+  const float spre = W8 ? g.wscale[en] : 1.f;
+  // (no residual read: the q/k/v outputs are published, not accumulated)
+  // every request of this kernel is now in flight.  The fence keeps it that way: without it the machine scheduler sinks
+  // most of the weight loads below the first wait on X (fewer live registers), i.e. two thirds of the weight stream
+  // would be requested one memory latency late
+  __builtin_amdgcn_sched_barrier(0);
+  // ---- 2. LayerNorm(s) in registers (one barrier each), bf16 pairs to LDS ----
+  if (!XBF) {
+    float xv[NB][KCH][4];
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+      for (int j = 0; j < KCH; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) xv[b][j][e] = __uint_as_float(xr[b][j][e]);
+#pragma unroll
+    for (int pass = 0; pass < PRO; ++pass) {
+      float s[NB], q[NB];
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        s[b] = q[b] = 0.f;
+        const float pv = pass == 0 ? pivot[b] : 0.f;
+#pragma unroll
+        for (int j = 0; j < KCH; ++j)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float d = xok[j] ? xv[b][j][e] - pv : 0.f;
+            s[b] += d;
+            q[b] = fmaf(d, d, q[b]);
+          }
+        s[b] = wave_sum_rl(s[b]);
+        q[b] = wave_sum_rl(q[b]);
+      }
+      if (lane == 0)
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+          red[pass][wave][2 * b] = s[b];
+          red[pass][wave][2 * b + 1] = q[b];
+        }
+      __syncthreads();
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        float S = 0.f, Q = 0.f;
+#pragma unroll
+        for (int ww = 0; ww < WAVES; ++ww) {
+          S += red[pass][ww][2 * b];
+          Q += red[pass][ww][2 * b + 1];
+        }
+        const float md = S * invK;
+        const float mean = (pass == 0 ? pivot[b] : 0.f) + md;
+        const float rstd = __builtin_amdgcn_rsqf(fmaxf(Q * invK - md * md, 0.f) + g.ln_eps);
+#pragma unroll
+        for (int j = 0; j < KCH; ++j)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float v = (xv[b][j][e] - mean) * rstd;
+            if (PRO == 2 && pass == 0) v = v * gm[j][e] + bt[j][e];
+            xv[b][j][e] = v;
+          }
+      }
+    }
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+      for (int j = 0; j < KCH; ++j)
+        if (xok[j]) {
+          const int i = (tid + j * NTHR) * 4;
+          uint2 p;
+          p.x = pack_bf16(xv[b][j][0], xv[b][j][1]);
+          p.y = pack_bf16(xv[b][j][2], xv[b][j][3]);
+          *reinterpret_cast<uint2*>(sxb + (b * K + i) / 2) = p;
+        }
+  } else {
+    if constexpr (PRO == 3) {
+      // merge the split-attention partials: weights exp(max_p - max), one division per head
+#pragma unroll
+      for (int b = 0; b < NB; ++b)
+#pragma unroll
+        for (int j = 0; j < KCH; ++j) {
+          const float M = fmaxf(fmaxf(pm[b][j][0], pm[b][j][1]), fmaxf(pm[b][j][2], pm[b][j][3]));
+          float wgt[ATTN_NSPLIT], L = 0.f;
+#pragma unroll
+          for (int sp = 0; sp < ATTN_NSPLIT; ++sp) {
+            wgt[sp] = pm[b][j][sp] > -INFINITY ? __expf(pm[b][j][sp] - M) : 0.f;
+            L = fmaf(wgt[sp], pl[b][j][sp], L);
+          }
+          const float inv = 1.f / L;
+          float xm[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            float a = 0.f;
+#pragma unroll
+            for (int sp = 0; sp < ATTN_NSPLIT; ++sp) a = fmaf(wgt[sp], po[b][j][sp][e >> 2][e & 3], a);
+            xm[e] = a * inv;
+          }
+#pragma unroll
+          for (int e = 0; e < 4; ++e) xr[b][j][e] = pack_bf16(xm[2 * e], xm[2 * e + 1]);
+        }
+    }
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+      for (int j = 0; j < KCH; ++j)
+        if (xok[j]) *reinterpret_cast<u32x4*>(sxb + (b * K + (tid + j * NTHR) * 8) / 2) = xr[b][j];
+  }
+  __syncthreads();
+  // ---- 3. dot products: 4 x v_dot2c per weight fragment and batch row ----
+  float acc[RPW][NB];
+#pragma unroll
+  for (int r = 0; r < RPW; ++r)
+#pragma unroll
+    for (int b = 0; b < NB; ++b) acc[r][b] = 0.f;
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int k = c == NCH - 1 ? (kok ? klast : K - 8) : c * 512 + lane * 8;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      u32x4 xq = *reinterpret_cast<const u32x4*>(sxb + (b * K + k) / 2);
+      if (c == NCH - 1)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) xq[e] = kok ? xq[e] : 0u;
+#pragma unroll
+      for (int r = 0; r < RPW; ++r) {
+        if constexpr (W8) {
+#pragma unroll
+          for (int h2 = 0; h2 < 2; ++h2) {
+            const uint32_t q = w8[r][c][h2];  // 4 fp8: bytes 0,1 -> pair 2*h2, bytes 2,3 -> pair 2*h2 + 1
+            acc[r][b] = dot2(__builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(q, 1.0f, false)), xq[2 * h2], acc[r][b]);
+            acc[r][b] = dot2(__builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(q, 1.0f, true)), xq[2 * h2 + 1], acc[r][b]);
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[r][b] = dot2(w[r][c][e], xq[e], acc[r][b]);
+        }
+      }
+    }
+  }
+  // wave reduction, then one lane per output: lane l < RPW * NB stores (row l / NB, batch l % NB)
+  float mine = 0.f;
+#pragma unroll
+  for (int r = 0; r < RPW; ++r)
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      const float t = wave_sum_rl(acc[r][b]);
+      mine = lane == r * NB + b ? t : mine;
+    }
+  if (lane < RPW * NB && n0 + er < g.N && eb < g.B) {
+    float v = mine * spre + (g.bias ? bpre : 0.f);
+    v = act_apply(g.act, v);
+    // publish as one 8-byte {value, tag} granule (sc1: write-through, L2-served for the polling consumer on any XCD)
+    const unsigned long long gv = ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(v);
+    __hip_atomic_store(gran + (size_t)eb * g.ldy + en, gv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+template <bool ANC>
+__device__ __forceinline__ void fused_attn_part(const unsigned long long* __restrict__ gran, unsigned tag, int* __restrict__ err,
+                                                bf16_t* __restrict__ kc, bf16_t* __restrict__ vc, const int* __restrict__ len,
+                                                const int* __restrict__ kv_start, const int* __restrict__ prefix, int H, int B,
+                                                int Smax, float scale, float* __restrict__ part_o, float* __restrict__ part_ml,
+                                                const uint8_t* __restrict__ anc, int nb, int h, int b, int sp) {
+  typedef bf16_t TC;
+  constexpr int NIT = 3, NT = 256, NSPLIT = ATTN_NSPLIT;
+  constexpr int DH = 64, VEC = CacheVec<TC>::VEC, LPK = CacheVec<TC>::LPK, NW = NT / 64, SLOTS = NT / LPK;
+  constexpr int SD = NT >= 1024 ? 2 : 4;  // rows per slot in flight beyond the register window
+  __shared__ float sm[NW], sl[NW];
+  __shared__ float so[NW][DH];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int D = H * DH;
+  TC* kb = kc + ((size_t)b * H + h) * Smax * DH;
+  TC* vb = vc + ((size_t)b * H + h) * Smax * DH;
+  const int slot = tid / LPK, sub = tid % LPK;
+  // cache row of key j: own row, or (ANC) the physical row the beam's ancestry names for that position
+  const uint8_t* arow = nullptr;
+  int rowbase = 0;
+  if constexpr (ANC) {
+    arow = anc + ((size_t)(len[b] & 1) * B + b) * Smax;
+    rowbase = (b / nb) * nb;
+  }
+  auto krow = [&](int j) -> const TC* {
+    if constexpr (ANC) return kc + ((size_t)(rowbase + min((int)arow[j], nb - 1)) * H + h) * Smax * DH + (size_t)j * DH;
+    return kb + (size_t)j * DH;
+  };
+  auto vrow = [&](int j) -> const TC* {
+    if constexpr (ANC) return vc + ((size_t)(rowbase + min((int)arow[j], nb - 1)) * H + h) * Smax * DH + (size_t)j * DH;
+    return vb + (size_t)j * DH;
+  };
+  // (a) the first pair of key/value rows of this slot, requested before ANYTHING else: their addresses depend on no
+  //     device scalar (rows are clamped to the cache capacity; rows >= S are masked out below)
+  CacheVec<TC> kr[2 * NIT], vr[2 * NIT];
+  // UNC pairs are requested blind (rows past S cost their bytes but nothing waits for the length): 2 pairs cover every
+  // prefix; with 1024 threads 4 pairs = 512 rows cover the sequence for most of a generation, so the device-scalar
+  // -> load chain (a second full memory latency) only remains for the late steps
+  constexpr int UNC = 2;  // 4 blind pairs (512 rows) measured slower: 0.602 vs 0.593 ms per step - the extra bytes cost more than the chain
+#pragma unroll
+  for (int u = 0; u < UNC; ++u) {
+    const int j = min((u * NSPLIT + sp) * SLOTS + slot, Smax - 1);
+    kr[u].load(krow(j) + sub * VEC);
+    vr[u].load(vrow(j) + sub * VEC);
+  }
+  // (a') the step's q / k / v come from the projection workgroups of THIS launch: polled below, after every cache load is in flight
+  // (b) per-row scalars and the K/V append of this step
+  const int pos = prefix[0] + len[b];
+  const int S = pos + 1;
+  const int ks = kv_start[b];
+  // (c) now that S is known: request every remaining row of the sequence at once (one more memory latency in total).
+  //     This comes BEFORE anything that consumes the q/k/v slice - vmcnt is in-order, and the K/V append below would
+  //     otherwise make the wave sit out the first loads' latency before these are even issued
+#pragma unroll
+  for (int u = UNC; u < 2 * NIT; ++u)
+    if ((u * NSPLIT + sp) * SLOTS < S) {  // block-uniform
+      const int j = min((u * NSPLIT + sp) * SLOTS + slot, Smax - 1);
+      kr[u].load(krow(j) + sub * VEC);
+      vr[u].load(vrow(j) + sub * VEC);
+    }
+  // (d) the step's own q / k / v: 8-byte {value, tag} granules published by the projection part; every thread needs its
+  //     8 q values, slot 0 of split 0 also k and v (append + own key).  One sweep = all loads in flight (sc1: L2-served,
+  //     never from this CU's L1), then the tags are checked; bounded, with an error flag instead of a hang.
+  float qr[VEC], kown[VEC], vown[VEC];
+  {
+    const unsigned long long* gq = gran + (size_t)b * 3 * D + h * DH + sub * VEC;
+    const bool need_kv = tid < LPK && sp == 0;
+    unsigned long long gv[3][VEC];
+    int spins = 0;
+    for (;;) {
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) gv[0][i] = __hip_atomic_load(gq + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (need_kv) {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+          gv[1][i] = __hip_atomic_load(gq + D + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          gv[2][i] = __hip_atomic_load(gq + 2 * D + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+      bool ok = true;
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) {
+        ok = ok && (unsigned)(gv[0][i] >> 32) == tag;
+        if (need_kv) ok = ok && (unsigned)(gv[1][i] >> 32) == tag && (unsigned)(gv[2][i] >> 32) == tag;
+      }
+      if (ok) break;
+      if (++spins > (1 << 18)) {  // ~0.3 s: the producers never take that long; flag it and go on with what is there
+        *err = 1;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(2);
+    }
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      qr[i] = __uint_as_float((unsigned)gv[0][i]) * scale;
+      kown[i] = need_kv ? (float)(TC)__uint_as_float((unsigned)gv[1][i]) : 0.f;
+      vown[i] = need_kv ? (float)(TC)__uint_as_float((unsigned)gv[2][i]) : 0.f;
+    }
+  }
+  if (tid < LPK && sp == 0) {  // slot 0 (of split 0): its LPK lanes cover the 64 dims
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      stf(kb + (size_t)pos * DH + sub * VEC + i, kown[i]);
+      stf(vb + (size_t)pos * DH + sub * VEC + i, vown[i]);
+    }
+  }
+  float m = -INFINITY, l = 0.f, acc[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
+  // score of one cached key row for this slot (the LPK lanes of the key hold VEC dims each; DPP sums them: quad swaps,
+  // half-row mirror, row mirror - no LDS crossbar trips)
+  auto score = [&](const CacheVec<TC>& kk) {
+    float sc = 0.f;
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) sc = fmaf(qr[i], kk.get(i), sc);
+    sc = dpp_add<0xB1>(sc);
+    sc = dpp_add<0x4E>(sc);
+    sc = dpp_add<0x141>(sc);
+    if (LPK == 16) sc = dpp_add<0x140>(sc);
+    return sc;
+  };
+  // (e) the register window in two phases, as torch.softmax does it: all scores, their maximum, then one exp per key and
+  //     the weighted sum - half the VALU work of a per-key online update (no rescale of the accumulator per key), and the
+  //     16 waves of a workgroup share 4 SIMDs, so this phase is issue-bound.  The row appended by this step (j == pos)
+  //     is masked out of the window and enters as one extra key of slot 0, from registers.  Rows past S multiply by
+  //     p = 0: the cache is zero-filled at allocation, so whatever they hold is finite.
+  {
+    float sc[2 * NIT + 1];
+#pragma unroll
+    for (int u = 0; u < 2 * NIT; ++u) {
+      const int j = (u * NSPLIT + sp) * SLOTS + slot;
+      const bool live = u < UNC || (u * NSPLIT + sp) * SLOTS < S;  // block-uniform: was this pair requested
+      const float t = live ? score(kr[u]) : 0.f;
+      sc[u] = (live && j < S && j >= ks && j != pos) ? t : -INFINITY;
+    }
+    {
+      float t = 0.f;
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) t = fmaf(qr[i], kown[i], t);
+      t = dpp_add<0xB1>(t);
+      t = dpp_add<0x4E>(t);
+      t = dpp_add<0x141>(t);
+      if (LPK == 16) t = dpp_add<0x140>(t);
+      sc[2 * NIT] = (slot == 0 && sp == 0) ? t : -INFINITY;
+    }
+    float mw = sc[0];
+#pragma unroll
+    for (int u = 1; u <= 2 * NIT; ++u) mw = fmaxf(mw, sc[u]);
+    if (mw > -INFINITY) {
+#pragma unroll
+      for (int u = 0; u < 2 * NIT; ++u)
+        if (u < UNC || (u * NSPLIT + sp) * SLOTS < S) {  // block-uniform: pairs that were never requested hold no data at all
+          const float p = __expf(sc[u] - mw);  // exp(-inf) = 0 for masked rows
+          l += p;
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) acc[i] = fmaf(p, vr[u].get(i), acc[i]);
+        }
+      const float p = __expf(sc[2 * NIT] - mw);
+      l += p;
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) acc[i] = fmaf(p, vown[i], acc[i]);
+      m = mw;
+    }
+  }
+  // online update for rows beyond the window (never the appended row when it lies inside the window)
+  auto consume = [&](const CacheVec<TC>& kk, const CacheVec<TC>& vv, int j) {
+    const bool ok = j < S && j >= ks && j != pos;
+    float sc = score(kk);
+    sc = ok ? sc : -INFINITY;  // also discards whatever an out-of-range row produced
+    const float mn = fmaxf(m, sc);
+    const float corr = mn > -INFINITY ? __expf(m - mn) : 1.f;
+    const float p = ok ? __expf(sc - mn) : 0.f;
+    l = l * corr + p;
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) acc[i] = fmaf(p, ok ? vv.get(i) : 0.f, acc[i] * corr);
+    m = mn;
+  };
+  // sequences longer than the register-resident window: stream the rest two rows at a time
+  for (int cb = 2 * NIT; (cb * NSPLIT + sp) * SLOTS < S; cb += SD) {  // chunk cb of this split = rows (cb*NSPLIT+sp)*SLOTS ..
+    CacheVec<TC> k2[SD], v2[SD];
+#pragma unroll
+    for (int u = 0; u < SD; ++u) {
+      const int j = min(((cb + u) * NSPLIT + sp) * SLOTS + slot, Smax - 1);
+      k2[u].load(krow(j) + sub * VEC);
+      v2[u].load(vrow(j) + sub * VEC);
+    }
+#pragma unroll
+    for (int u = 0; u < SD; ++u) consume(k2[u], v2[u], ((cb + u) * NSPLIT + sp) * SLOTS + slot);
+  }
+  // merge the 64/LPK key slots of this wave (lanes with equal `sub`)
+  // merge across the wave without the LDS crossbar: lane ^ 8 is a DPP rotate inside the 16-lane row; lane ^ 16 and
+  // lane ^ 32 are v_permlane16_swap / v_permlane32_swap (CDNA4), which hand every lane BOTH partners' values
+  // (tools/probe_permlane.hip prints the lane maps) - a sum or max of the two results is the butterfly step
+  auto bfly_max = [&](float x, int o) {
+    if (o == 8) return fmaxf(x, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x128, 0xf, 0xf, true)));
+    const u32x2 r = o == 16 ? __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false)
+                            : __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+  };
+  auto bfly_sum = [&](float x, int o) {
+    if (o == 8) return x + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x128, 0xf, 0xf, true));
+    const u32x2 r = o == 16 ? __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false)
+                            : __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+  };
+  float M = m;
+#pragma unroll
+  for (int o = LPK; o < 64; o <<= 1) M = bfly_max(M, o);
+  const float sc0 = M > -INFINITY ? __expf(m - M) : 0.f;
+  l *= sc0;
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) acc[i] *= sc0;
+#pragma unroll
+  for (int o = LPK; o < 64; o <<= 1) {
+    l = bfly_sum(l, o);
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) acc[i] = bfly_sum(acc[i], o);
+  }
+  if (lane < LPK)
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) so[wave][lane * VEC + i] = acc[i];
+  if (lane == 0) {
+    sm[wave] = M;
+    sl[wave] = l;
+  }
+  __syncthreads();
+  if (tid < DH) {
+    float MM = sm[0];
+#pragma unroll
+    for (int i = 1; i < NW; ++i) MM = fmaxf(MM, sm[i]);
+    float o = 0.f, L = 0.f;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) {
+      const float e = sm[i] > -INFINITY ? __expf(sm[i] - MM) : 0.f;
+      o = fmaf(e, so[i][tid], o);
+      L = fmaf(e, sl[i], L);
+    }
+    if constexpr (NSPLIT > 1) {
+      // partial of this split: [row][head][split][64] un-normalised, and [row][head][2][NSPLIT] = (max..., sum...)
+      part_o[(((size_t)b * H + h) * NSPLIT + sp) * DH + tid] = o;
+      if (tid == 0) {
+        part_ml[((size_t)b * H + h) * 2 * NSPLIT + sp] = MM;
+        part_ml[((size_t)b * H + h) * 2 * NSPLIT + NSPLIT + sp] = L;
+      }
+    }
+  }
+}
+struct FusedQkvAttn {
+  GemvArgs g;
+  unsigned long long* gran;  // [B][3 * D] granules of this layer
+  int* err;
+  bf16_t *kc, *vc;
+  const int *len, *kv_start, *prefix;  // prefix[0] = prefix length, prefix[1] = generation epoch
+  int H, B, Smax, n_gemv, nb;
+  float scale;
+  float *part_o, *part_ml;
+  const uint8_t* anc;
+};
+
+template <int NB, int RPW, int NCH, bool ANC>
+__global__ __launch_bounds__(256) void qkv_attn_fused_kernel(FusedQkvAttn f) {
+  const unsigned tag = ((unsigned)f.prefix[1] << 12) | (unsigned)(f.len[0] + 1);
+  if ((int)blockIdx.x < f.n_gemv) {
+    fused_gemv_part<NB, RPW, NCH>(f.g, blockIdx.x, f.gran, tag);
+  } else {
+    const int idx = blockIdx.x - f.n_gemv;
+    const int h = idx % f.H, b = (idx / f.H) % f.B, sp = idx / (f.H * f.B);
+    fused_attn_part<ANC>(f.gran, tag, f.err, f.kc, f.vc, f.len, f.kv_start, f.prefix, f.H, f.B, f.Smax, f.scale, f.part_o,
+                         f.part_ml, f.anc, f.nb, h, b, sp);
+  }
+}
+
 // bookkeeping shared by the greedy and the sampling kernels (thread 0 of the row's block)
 __device__ __forceinline__ void sampler_commit(const SamplerArgs& a, int b, int choice, int* si, int k, int unf) {
   si[1] = -1;
@@ -1442,6 +1959,52 @@ int decode_attn2(void* ctx, int to, const float* qkv, void* kc, void* vc, const 
     return E_INVALID;
   }
 #undef LAUNCH
+  ITTS_HIP_CHECK(hipGetLastError());
+  return OK;
+}
+
+bool qkv_attn_fused_supported(const GemvArgs& g, int H, int dh) {
+  const int nch = (g.K + 511) / 512;
+  return g.B >= 1 && g.B <= 4 && dh == 64 && g.N == 3 * H * dh && g.K % 8 == 0 && g.K >= 64 && (nch <= 1 || nch == 3) &&
+         g.prologue == 1 && !g.x_bf16 && !g.y_bf16 && !g.accumulate && !g.W8 && g.act == ACT_NONE;
+}
+
+int qkv_attn_fused(const GemvArgs& g, unsigned long long* gran, int* err, void* kc, void* vc, const int* len,
+                   const int* kv_start, const int* prefix_dev, int H, int dh, int Smax, float* part_o, float* part_ml,
+                   const uint8_t* anc, int nb, hipStream_t s) {
+  ITTS_REQUIRE(qkv_attn_fused_supported(g, H, dh) && gran && err && part_o && part_ml, "qkv_attn_fused: unsupported call");
+  ITTS_REQUIRE(!anc || (nb >= 1 && nb <= 16 && g.B % nb == 0), "qkv_attn_fused: beam ancestry needs B to be a multiple of nb");
+  const int nch = (g.K + 511) / 512, rpw = nch <= 1 ? 1 : 2;
+  FusedQkvAttn f;
+  f.g = g;
+  f.gran = gran;
+  f.err = err;
+  f.kc = (bf16_t*)kc;
+  f.vc = (bf16_t*)vc;
+  f.len = len;
+  f.kv_start = kv_start;
+  f.prefix = prefix_dev;
+  f.H = H;
+  f.B = g.B;
+  f.Smax = Smax;
+  f.n_gemv = (g.N + 4 * rpw - 1) / (4 * rpw);
+  f.nb = nb;
+  f.scale = 1.f / sqrtf((float)dh);
+  f.part_o = part_o;
+  f.part_ml = part_ml;
+  f.anc = anc;
+  const dim3 grid(f.n_gemv + H * g.B * ATTN_NSPLIT), blk(256);
+  const size_t lds = (size_t)(g.B <= 2 ? g.B : 4) * g.K * 2;
+#define FUSED_GO(NB, RPW, NCH)                                                                            \
+  if (anc) hipLaunchKernelGGL((qkv_attn_fused_kernel<NB, RPW, NCH, true>), grid, blk, lds, s, f);          \
+  else hipLaunchKernelGGL((qkv_attn_fused_kernel<NB, RPW, NCH, false>), grid, blk, lds, s, f);
+#define FUSED_NB(RPW, NCH)            \
+  if (g.B == 1) { FUSED_GO(1, RPW, NCH) } \
+  else if (g.B == 2) { FUSED_GO(2, RPW, NCH) } \
+  else { FUSED_GO(4, RPW, NCH) }
+  if (nch <= 1) { FUSED_NB(1, 1) } else { FUSED_NB(2, 3) }
+#undef FUSED_NB
+#undef FUSED_GO
   ITTS_HIP_CHECK(hipGetLastError());
   return OK;
 }

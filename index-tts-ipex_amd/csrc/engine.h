@@ -144,6 +144,10 @@ struct DecodeState {
   float *hyp_score = nullptr, *hyp_worst = nullptr;
   size_t beam_cap = 0;               // bytes-independent capacity key: rows * max_gen * Smax the beam buffers were sized for
   int beam_rows = 0, beam_gen = 0, beam_smax = 0;
+  // LN + c_attn + cache attention in one launch (decode2.hip qkv_attn_fused): per-layer granule buffers + error flag
+  unsigned long long* gran = nullptr;  // [layers][cap_B <= 4][3 * D]
+  int* fuse_err = nullptr;
+  int fuse = 1, graph_fuse = 1;        // 0 after ITTS_NO_FUSE_QKV_ATTN or a hand-off timeout
   float typical_mass = 0.f, graph_typical = 0.f;  // TypicalLogitsWarper pre-pass (0 = off)
   float* scores2 = nullptr;                        // [cap_B][V] its output
   int* forced = nullptr;  // [cap_B][cap_gen] forced token per (row, step) or -1; allocated with ids
@@ -209,6 +213,7 @@ struct Engine {
                     const float* uniforms_host, long n);
   int beam_do_sample = 1;
   float beam_length_penalty = 0.f;
+  int gen_epoch = 0;   // generation counter: high bits of the hand-off tags (never 0)
   int beam_beams = 1;  // requested beams for the following generations (1 = off)
   int ensure_beam_state(int rows, int max_gen, int Smax, hipStream_t s);
   int beam_finalize(int32_t* codes_host, hipStream_t s);

@@ -121,6 +121,11 @@ int gemv2(const GemvArgs& g, int tw, hipStream_t s);
 int decode_attn2(void* ctx, int to, const float* qkv, void* kc, void* vc, const int* len, const int* kv_start,
                  const int* prefix_dev, int B, int H, int dh, int Smax, int tc, hipStream_t s, int ctx_tiled = 0,
                  float* part_o = nullptr, float* part_ml = nullptr, const uint8_t* anc = nullptr, int nb = 1);
+// LN + c_attn projection and the cache attention of one layer in one launch (decode2.hip qkv_attn_fused_kernel)
+bool qkv_attn_fused_supported(const GemvArgs& g, int H, int dh);
+int qkv_attn_fused(const GemvArgs& g, unsigned long long* gran, int* err, void* kc, void* vc, const int* len,
+                   const int* kv_start, const int* prefix_dev, int H, int dh, int Smax, float* part_o, float* part_ml,
+                   const uint8_t* anc, int nb, hipStream_t s);
 constexpr int ATTN_NSPLIT = 4;  // workgroups per (row, head) in the split form of decode_attn2
 bool gemv_bf16_supported(const GemvArgs& g);
 int gemv_bf16(const GemvArgs& g, hipStream_t s);

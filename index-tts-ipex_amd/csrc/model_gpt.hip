@@ -35,7 +35,7 @@ __global__ void gpt_embed_rows_kernel(float* __restrict__ h, const RowDesc* __re
 }
 
 __global__ void init_decode_state_kernel(uint8_t* seen, int* unfinished, int* cur_tok, int* len, int* prefix_dev,
-                                         int B, int V, int fake_id, int start_tok, int prefix) {
+                                         int B, int V, int fake_id, int start_tok, int prefix, int epoch) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < (long)B * V) {
     const int v = (int)(i % V);
@@ -46,7 +46,10 @@ __global__ void init_decode_state_kernel(uint8_t* seen, int* unfinished, int* cu
     cur_tok[i] = start_tok;
     len[i] = 0;
   }
-  if (i == 0) prefix_dev[0] = prefix;
+  if (i == 0) {
+    prefix_dev[0] = prefix;
+    prefix_dev[1] = epoch;  // generation epoch: the high bits of the in-launch hand-off tags (qkv_attn_fused)
+  }
 }
 
 // beam-sample state of a fresh generation: identity cache ancestry (every beam row reads its own prefix copy), zero
@@ -166,6 +169,13 @@ int Engine::ensure_decode_state(int B, int Smax, int max_gen, hipStream_t s) {
     ITTS_TRY(dev_alloc((void**)&d.unfinished, (size_t)cb * 4));
     ITTS_TRY(dev_alloc((void**)&d.ids, (size_t)cb * cg * 4));
     ITTS_TRY(dev_alloc((void**)&d.forced, (size_t)cb * cg * 4));
+    {
+      const size_t gb = (size_t)c.layers * 4 * 3 * D * 8;
+      ITTS_TRY(dev_alloc((void**)&d.gran, gb));
+      ITTS_HIP_CHECK(hipMemsetAsync(d.gran, 0, gb, s));  // tag 0 is never issued
+      ITTS_TRY(dev_alloc((void**)&d.fuse_err, 64));
+      ITTS_HIP_CHECK(hipMemsetAsync(d.fuse_err, 0, 64, s));
+    }
     ITTS_TRY(dev_alloc((void**)&d.seen, (size_t)cb * V));
     ITTS_TRY(dev_alloc((void**)&d.len, (size_t)cb * 4));
     if (!d.prefix_dev) ITTS_TRY(dev_alloc((void**)&d.prefix_dev, 64));
@@ -333,6 +343,7 @@ int Engine::gpt_prefill(const float* cond_dev, const int32_t* text_ids_in, int B
   ds.prefix = sp;
   ds.penalty = penalty;
   ds.suppress_stop = suppress;
+  gen_epoch = (gen_epoch % 0xFFFFF) + 1;  // 1 .. 2^20 - 1
   ds.nb = nbeam;
   ds.beam_sample = beam_do_sample;
   ds.length_penalty = beam_length_penalty;
@@ -403,7 +414,7 @@ int Engine::gpt_prefill(const float* cond_dev, const int32_t* text_ids_in, int B
       ITTS_HIP_CHECK(hipMemcpyAsync(ds.kv_start, kvs.data(), B * 4, hipMemcpyHostToDevice, s));
       const long n = (long)B * V;
       hipLaunchKernelGGL(init_decode_state_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, ds.seen,
-                         ds.unfinished, ds.cur_tok, ds.len, ds.prefix_dev, B, V, 1, c.start_mel_token, sp);
+                         ds.unfinished, ds.cur_tok, ds.len, ds.prefix_dev, B, V, 1, c.start_mel_token, sp, gen_epoch);
       if (adt == F32)
         hipLaunchKernelGGL(gpt_embed_rows_kernel<float>, dim3(B * S0), dim3(256), 0, s, h, rd_dev, cond_dev,
                            (const float*)gpt.text_emb, (const float*)gpt.text_pos, (const float*)gpt.mel_emb,
@@ -636,12 +647,22 @@ int Engine::decode_step_launch(hipStream_t s) {
     g.ln_gamma = L.ln1.g;
     g.ln_beta = L.ln1.b;
     g.w8src = L.attn.w8 ? &L.attn : nullptr;
-    ITTS_TRY(run(g, L.attn.dt));
     const size_t lo = (size_t)l * B * H * ds.Smax * dh * es;
     // few (row, head) pairs: the keys of each pair go to ATTN_NSPLIT workgroups and the projection merges the partials
     static const bool no_split = getenv("ITTS_ATTN_NOSPLIT") != nullptr;
+    static const bool no_fuse = getenv("ITTS_NO_FUSE_QKV_ATTN") != nullptr;
     const bool split = fast && bf_ctx && !no_split && (long)B * H <= 128 && D % 64 == 0;
-    if (split)
+    // projection + attention of the layer as ONE launch (the attention workgroups poll for q / k / v): bf16 weights only
+    const bool fused = split && ds.fuse && !no_fuse && !g.w8src && gemv_bf16_supported(g) && qkv_attn_fused_supported(g, H, dh);
+    if (fused) {
+      ITTS_TRY(qkv_attn_fused(g, ds.gran + (size_t)l * 4 * 3 * D, ds.fuse_err, (char*)ds.kc + lo, (char*)ds.vc + lo, ds.len,
+                              ds.kv_start, ds.prefix_dev, H, dh, ds.Smax, ds.attn_o, ds.attn_ml, ds.nb > 1 ? ds.anc : nullptr,
+                              ds.nb, s));
+    } else {
+      ITTS_TRY(run(g, L.attn.dt));
+    }
+    if (fused) {
+    } else if (split)
       ITTS_TRY(decode_attn2(nullptr, BF16, ds.qkv, (char*)ds.kc + lo, (char*)ds.vc + lo, ds.len, ds.kv_start, ds.prefix_dev, B, H,
                             dh, ds.Smax, adt, s, 0, ds.attn_o, ds.attn_ml, ds.nb > 1 ? ds.anc : nullptr, ds.nb));
     else
@@ -754,7 +775,7 @@ int Engine::gpt_decode(int nsteps, hipStream_t s) {
     // everything SamplerArgs carries by value is baked into the captured nodes: max_gen is the ids row stride and the
     // `k < max_gen` bound, so a per-request max_mel_tokens must re-capture (same B / Smax notwithstanding)
     const bool stale = !d.graph || d.graph_B != d.B || d.graph_Smax != d.Smax || d.graph_max_gen != d.max_gen ||
-                       d.graph_forced != d.use_forced || d.graph_nb != d.nb || d.graph_beam_sample != d.beam_sample ||
+                       d.graph_forced != d.use_forced || d.graph_fuse != d.fuse || d.graph_nb != d.nb || d.graph_beam_sample != d.beam_sample ||
                        d.graph_length_penalty != d.length_penalty || d.graph_typical != d.typical_mass || d.graph_penalty != d.penalty || d.graph_suppress != d.suppress_stop || d.graph_sample != d.do_sample ||
                        d.graph_top_k != d.top_k || d.graph_top_p != d.top_p || d.graph_temperature != d.temperature;
     // two executables: one step, and GK steps back to back (one launch per GK tokens: the gap between consecutive graph
@@ -788,6 +809,7 @@ int Engine::gpt_decode(int nsteps, hipStream_t s) {
       d.graph_Smax = d.Smax;
       d.graph_max_gen = d.max_gen;
       d.graph_forced = d.use_forced;
+      d.graph_fuse = d.fuse;
       d.graph_nb = d.nb;
       d.graph_beam_sample = d.beam_sample;
       d.graph_length_penalty = d.length_penalty;
@@ -815,9 +837,17 @@ int Engine::gpt_status(int* steps, int* n_unf, hipStream_t s) {
     return E_STATE;
   }
   std::vector<int> host(ds.B + 1);
+  int ferr = 0;
+  if (ds.fuse_err) ITTS_HIP_CHECK(hipMemcpyAsync(&ferr, ds.fuse_err, 4, hipMemcpyDeviceToHost, s));
   ITTS_HIP_CHECK(hipMemcpyAsync(host.data(), ds.len, 4, hipMemcpyDeviceToHost, s));
   ITTS_HIP_CHECK(hipMemcpyAsync(host.data() + 1, ds.unfinished, (size_t)ds.B * 4, hipMemcpyDeviceToHost, s));
   ITTS_HIP_CHECK(hipStreamSynchronize(s));
+  if (ferr) {  // an attention workgroup gave up waiting for its q / k / v: the codes of this generation are not valid
+    ds.fuse = 0;  // later generations take the two-launch path
+    ITTS_HIP_CHECK(hipMemsetAsync(ds.fuse_err, 0, 4, s));
+    set_error("gpt_status: in-launch q/k/v hand-off timed out (fused projection + attention disabled for this engine)");
+    return E_HIP;
+  }
   if (steps) *steps = host[0];
   if (n_unf) {
     int n = 0;
