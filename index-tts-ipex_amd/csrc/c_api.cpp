@@ -244,7 +244,7 @@ int itts_debug_enable(itts_engine* e, int on) {
   e->e.debug = on & 1;
   e->e.force_simple = (on & 2) != 0;
   e->e.use_graph = (on & 4) == 0;
-  e->e.ds.fuse = (on & 8) == 0;  // bit 3: two-launch projection + attention instead of the fused launch (A/B, parity tests)
+  e->e.ds.fuse = (on & 8) != 0;  // bit 3: the fused projection + attention launch instead of two launches (A/B, parity tests)
   return OK;
 }
 

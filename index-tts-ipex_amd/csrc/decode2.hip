@@ -1000,7 +1000,8 @@ __global__ __launch_bounds__(NT) void decode_attn2_kernel(TO* __restrict__ ctx, 
 // overlaps the cache stream with the projection: 5.2 + 4.9 us -> see DESIGN.md section 5.
 // ---------------------------------------------------------------------------------------------
 template <int NB, int RPW, int NCH>
-__device__ __forceinline__ void fused_gemv_part(const GemvArgs& g, int blk, unsigned long long* __restrict__ gran, unsigned tag) {
+__device__ __forceinline__ void fused_gemv_part(const GemvArgs& g, int blk, unsigned long long* __restrict__ gran,
+                                                const int* __restrict__ len, const int* __restrict__ prefix) {
   constexpr int PRO = 1, WAVES = 4;
   constexpr bool XBF = false, W8 = false;
   constexpr int NTHR = WAVES * 64;
@@ -1225,7 +1226,9 @@ __device__ __forceinline__ void fused_gemv_part(const GemvArgs& g, int blk, unsi
   if (lane < RPW * NB && n0 + er < g.N && eb < g.B) {
     float v = mine * spre + (g.bias ? bpre : 0.f);
     v = act_apply(g.act, v);
-    // publish as one 8-byte {value, tag} granule (sc1: write-through, L2-served for the polling consumer on any XCD)
+    // publish as one 8-byte {value, tag} granule (sc1: write-through, L2-served for the polling consumer on any XCD); the
+    // tag's two scalars are read here, at the end: nothing in front of the weight requests waits for them
+    const unsigned tag = ((unsigned)prefix[1] << 12) | (unsigned)(len[0] + 1);
     const unsigned long long gv = ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(v);
     __hip_atomic_store(gran + (size_t)eb * g.ldy + en, gv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
@@ -1236,7 +1239,7 @@ __device__ __forceinline__ void fused_attn_part(const unsigned long long* __rest
                                                 bf16_t* __restrict__ kc, bf16_t* __restrict__ vc, const int* __restrict__ len,
                                                 const int* __restrict__ kv_start, const int* __restrict__ prefix, int H, int B,
                                                 int Smax, float scale, float* __restrict__ part_o, float* __restrict__ part_ml,
-                                                const uint8_t* __restrict__ anc, int nb, int h, int b, int sp) {
+                                                const uint8_t* __restrict__ anc, int nb, int h, int b, int sp, int sleep0, int sleep1) {
   typedef bf16_t TC;
   constexpr int NIT = 3, NT = 256, NSPLIT = ATTN_NSPLIT;
   constexpr int DH = 64, VEC = CacheVec<TC>::VEC, LPK = CacheVec<TC>::LPK, NW = NT / 64, SLOTS = NT / LPK;
@@ -1300,6 +1303,9 @@ __device__ __forceinline__ void fused_attn_part(const unsigned long long* __rest
     const bool need_kv = tid < LPK && sp == 0;
     unsigned long long gv[3][VEC];
     int spins = 0;
+    // the projection part needs >= 2 us for its weight stream: do not poll (and load the L2 it streams through) before
+    // that; afterwards sweep with pauses (MI355X_MICROARCH "polling-cost": pollers next to a weight stream slow it down)
+    for (int z = 0; z < sleep0; ++z) __builtin_amdgcn_s_sleep(4);
     for (;;) {
 #pragma unroll
       for (int i = 0; i < VEC; ++i) gv[0][i] = __hip_atomic_load(gq + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1321,7 +1327,7 @@ __device__ __forceinline__ void fused_attn_part(const unsigned long long* __rest
         *err = 1;
         break;
       }
-      __builtin_amdgcn_s_sleep(2);
+      for (int z = 0; z < sleep1; ++z) __builtin_amdgcn_s_sleep(1);
     }
 #pragma unroll
     for (int i = 0; i < VEC; ++i) {
@@ -1484,7 +1490,7 @@ struct FusedQkvAttn {
   int* err;
   bf16_t *kc, *vc;
   const int *len, *kv_start, *prefix;  // prefix[0] = prefix length, prefix[1] = generation epoch
-  int H, B, Smax, n_gemv, nb;
+  int H, B, Smax, n_gemv, nb, sleep0, sleep1, attn_first;
   float scale;
   float *part_o, *part_ml;
   const uint8_t* anc;
@@ -1492,14 +1498,16 @@ struct FusedQkvAttn {
 
 template <int NB, int RPW, int NCH, bool ANC>
 __global__ __launch_bounds__(256) void qkv_attn_fused_kernel(FusedQkvAttn f) {
-  const unsigned tag = ((unsigned)f.prefix[1] << 12) | (unsigned)(f.len[0] + 1);
-  if ((int)blockIdx.x < f.n_gemv) {
-    fused_gemv_part<NB, RPW, NCH>(f.g, blockIdx.x, f.gran, tag);
+  const int n_attn = f.H * f.B * ATTN_NSPLIT;
+  const int gblk = f.attn_first ? (int)blockIdx.x - n_attn : (int)blockIdx.x;  // projection block id (negative: attention)
+  if (gblk >= 0 && gblk < f.n_gemv) {
+    fused_gemv_part<NB, RPW, NCH>(f.g, gblk, f.gran, f.len, f.prefix);
   } else {
-    const int idx = blockIdx.x - f.n_gemv;
+    const unsigned tag = ((unsigned)f.prefix[1] << 12) | (unsigned)(f.len[0] + 1);
+    const int idx = f.attn_first ? (int)blockIdx.x : (int)blockIdx.x - f.n_gemv;
     const int h = idx % f.H, b = (idx / f.H) % f.B, sp = idx / (f.H * f.B);
     fused_attn_part<ANC>(f.gran, tag, f.err, f.kc, f.vc, f.len, f.kv_start, f.prefix, f.H, f.B, f.Smax, f.scale, f.part_o,
-                         f.part_ml, f.anc, f.nb, h, b, sp);
+                         f.part_ml, f.anc, f.nb, h, b, sp, f.sleep0, f.sleep1);
   }
 }
 
@@ -1993,6 +2001,12 @@ int qkv_attn_fused(const GemvArgs& g, unsigned long long* gran, int* err, void* 
   f.part_o = part_o;
   f.part_ml = part_ml;
   f.anc = anc;
+  static const int e_s0 = getenv("ITTS_FUSE_SLEEP0") ? atoi(getenv("ITTS_FUSE_SLEEP0")) : 24;  // x 256 clocks before the first poll (best of tools/fuse_sweep.sh)
+  static const int e_s1 = getenv("ITTS_FUSE_SLEEP1") ? atoi(getenv("ITTS_FUSE_SLEEP1")) : 4;   // x 64 clocks between sweeps
+  static const int e_af = getenv("ITTS_FUSE_ATTN_FIRST") ? atoi(getenv("ITTS_FUSE_ATTN_FIRST")) : 0;
+  f.sleep0 = e_s0;
+  f.sleep1 = e_s1;
+  f.attn_first = e_af;
   const dim3 grid(f.n_gemv + H * g.B * ATTN_NSPLIT), blk(256);
   const size_t lds = (size_t)(g.B <= 2 ? g.B : 4) * g.K * 2;
 #define FUSED_GO(NB, RPW, NCH)                                                                            \

@@ -147,7 +147,8 @@ struct DecodeState {
   // LN + c_attn + cache attention in one launch (decode2.hip qkv_attn_fused): per-layer granule buffers + error flag
   unsigned long long* gran = nullptr;  // [layers][cap_B <= 4][3 * D]
   int* fuse_err = nullptr;
-  int fuse = 1, graph_fuse = 1;        // 0 after ITTS_NO_FUSE_QKV_ATTN or a hand-off timeout
+  int fuse_failed = 0;                 // a hand-off timed out: two launches from then on
+  int fuse = 0, graph_fuse = 0;        // opt-in (ITTS_FUSE_QKV_ATTN=1 / debug bit 3): measured 1.5 % slower than two launches; 0 again after a hand-off timeout
   float typical_mass = 0.f, graph_typical = 0.f;  // TypicalLogitsWarper pre-pass (0 = off)
   float* scores2 = nullptr;                        // [cap_B][V] its output
   int* forced = nullptr;  // [cap_B][cap_gen] forced token per (row, step) or -1; allocated with ids

@@ -650,10 +650,10 @@ int Engine::decode_step_launch(hipStream_t s) {
     const size_t lo = (size_t)l * B * H * ds.Smax * dh * es;
     // few (row, head) pairs: the keys of each pair go to ATTN_NSPLIT workgroups and the projection merges the partials
     static const bool no_split = getenv("ITTS_ATTN_NOSPLIT") != nullptr;
-    static const bool no_fuse = getenv("ITTS_NO_FUSE_QKV_ATTN") != nullptr;
+    static const bool env_fuse = getenv("ITTS_FUSE_QKV_ATTN") != nullptr && atoi(getenv("ITTS_FUSE_QKV_ATTN")) != 0;
     const bool split = fast && bf_ctx && !no_split && (long)B * H <= 128 && D % 64 == 0;
     // projection + attention of the layer as ONE launch (the attention workgroups poll for q / k / v): bf16 weights only
-    const bool fused = split && ds.fuse && !no_fuse && !g.w8src && gemv_bf16_supported(g) && qkv_attn_fused_supported(g, H, dh);
+    const bool fused = split && (ds.fuse || env_fuse) && !ds.fuse_failed && !g.w8src && gemv_bf16_supported(g) && qkv_attn_fused_supported(g, H, dh);
     if (fused) {
       ITTS_TRY(qkv_attn_fused(g, ds.gran + (size_t)l * 4 * 3 * D, ds.fuse_err, (char*)ds.kc + lo, (char*)ds.vc + lo, ds.len,
                               ds.kv_start, ds.prefix_dev, H, dh, ds.Smax, ds.attn_o, ds.attn_ml, ds.nb > 1 ? ds.anc : nullptr,
@@ -775,7 +775,7 @@ int Engine::gpt_decode(int nsteps, hipStream_t s) {
     // everything SamplerArgs carries by value is baked into the captured nodes: max_gen is the ids row stride and the
     // `k < max_gen` bound, so a per-request max_mel_tokens must re-capture (same B / Smax notwithstanding)
     const bool stale = !d.graph || d.graph_B != d.B || d.graph_Smax != d.Smax || d.graph_max_gen != d.max_gen ||
-                       d.graph_forced != d.use_forced || d.graph_fuse != d.fuse || d.graph_nb != d.nb || d.graph_beam_sample != d.beam_sample ||
+                       d.graph_forced != d.use_forced || d.graph_fuse != (d.fuse && !d.fuse_failed) || d.graph_nb != d.nb || d.graph_beam_sample != d.beam_sample ||
                        d.graph_length_penalty != d.length_penalty || d.graph_typical != d.typical_mass || d.graph_penalty != d.penalty || d.graph_suppress != d.suppress_stop || d.graph_sample != d.do_sample ||
                        d.graph_top_k != d.top_k || d.graph_top_p != d.top_p || d.graph_temperature != d.temperature;
     // two executables: one step, and GK steps back to back (one launch per GK tokens: the gap between consecutive graph
@@ -809,7 +809,7 @@ int Engine::gpt_decode(int nsteps, hipStream_t s) {
       d.graph_Smax = d.Smax;
       d.graph_max_gen = d.max_gen;
       d.graph_forced = d.use_forced;
-      d.graph_fuse = d.fuse;
+      d.graph_fuse = d.fuse && !d.fuse_failed;
       d.graph_nb = d.nb;
       d.graph_beam_sample = d.beam_sample;
       d.graph_length_penalty = d.length_penalty;
@@ -843,7 +843,7 @@ int Engine::gpt_status(int* steps, int* n_unf, hipStream_t s) {
   ITTS_HIP_CHECK(hipMemcpyAsync(host.data() + 1, ds.unfinished, (size_t)ds.B * 4, hipMemcpyDeviceToHost, s));
   ITTS_HIP_CHECK(hipStreamSynchronize(s));
   if (ferr) {  // an attention workgroup gave up waiting for its q / k / v: the codes of this generation are not valid
-    ds.fuse = 0;  // later generations take the two-launch path
+    ds.fuse_failed = 1;  // later generations take the two-launch path
     ITTS_HIP_CHECK(hipMemsetAsync(ds.fuse_err, 0, 4, s));
     set_error("gpt_status: in-launch q/k/v hand-off timed out (fused projection + attention disabled for this engine)");
     return E_HIP;

@@ -130,8 +130,8 @@ class Engine:
     def finalize(self):
         L.check(self.lib.itts_engine_finalize(self.h), "finalize")
 
-    def debug(self, taps: bool = False, force_simple: bool = False, no_graph: bool = False, no_fuse: bool = False):
-        L.check(self.lib.itts_debug_enable(self.h, int(taps) | (int(force_simple) << 1) | (int(no_graph) << 2) | (int(no_fuse) << 3)))
+    def debug(self, taps: bool = False, force_simple: bool = False, no_graph: bool = False, fuse: bool = False):
+        L.check(self.lib.itts_debug_enable(self.h, int(taps) | (int(force_simple) << 1) | (int(no_graph) << 2) | (int(fuse) << 3)))
 
     def fetch_tap(self, name: str) -> np.ndarray:
         n = self.lib.itts_debug_fetch(self.h, name.encode(), None, 0)
