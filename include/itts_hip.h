@@ -72,9 +72,15 @@ int itts_gemv(float* Y, const float* X, const void* W, const float* bias, int B,
  * ksplit > 1 splits K over workgroups: raw sums go to partial[ksplit][B][N] (no bias / act / Y), to be absorbed by
  * itts_ln_rows_bf16 (deterministic two-stage reduction, no atomics).
  * layout bit 0: X is MFMA-fragment tiled, bit 1: bf16 Y is written tiled - element (b, k) at
- * ((k/32) * ceil(B/16) + b/16) * 512 + ((k%32)/8 * 16 + b%16) * 8 + k%8 (csrc/itts_decode.h tile_off). */
+ * ((k/32) * ceil(B/16) + b/16) * 512 + ((k%32)/8 * 16 + b%16) * 8 + k%8 (csrc/itts_decode.h tile_off).
+ * layout bit 2: W is the fragment-tiled copy made by itts_retile_weights (same bits out, 1.3x faster weight stream). */
 int itts_skinny_gemm(void* Y, int y_bf16, const void* X, const void* W, const float* bias, int B, int N, int K, int act,
                      int accumulate, int ksplit, float* partial, int layout, itts_stream stream);
+
+/* dst[16*ceil(N/16)*K] <- bf16 W[N, K] in MFMA-fragment tiles: element (n, k) at
+ * ((n/16) * (K/32) + k/32) * 512 + ((k%32)/8 * 16 + n%16) * 8 + k%8, rows past N zero (csrc/itts_decode.h wtile_off).
+ * The engine makes these copies of the GPT projections itself on the first batched generation. */
+int itts_retile_weights(void* dst, const void* src, int N, int K, itts_stream stream);
 
 /* y (bf16) = LayerNorm(x fp32) [passes == 2: LayerNorm again without affine], GPT-2 ln_1 / ln_2 / ln_f o final_norm.
  * nsplit > 0: first x += partial_bias + sum_s partial[s] (the residual add of a split-K projection), written back. */

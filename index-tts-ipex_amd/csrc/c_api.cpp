@@ -89,7 +89,16 @@ int itts_skinny_gemm(void* Y, int y_bf16, const void* X, const void* W, const fl
   g.X = (const float*)X; g.x_bf16 = 1; g.W = W; g.Y = (float*)Y; g.y_bf16 = y_bf16; g.bias = bias; g.B = B; g.N = N; g.K = K;
   g.ldy = N; g.act = act; g.accumulate = accumulate; g.ksplit = ksplit; g.partial = partial;
   g.x_tiled = layout & 1; g.y_tiled = (layout >> 1) & 1;
+  if (layout & 4) {
+    g.Wt = W;
+    g.W = nullptr;
+  }
   return skinny_mfma(g, (hipStream_t)stream);
+}
+
+int itts_retile_weights(void* dst, const void* src, int N, int K, itts_stream stream) {
+  (void)hipGetLastError();
+  return retile_weights_bf16(dst, src, N, K, (hipStream_t)stream);
 }
 
 int itts_ln_rows_bf16(void* y, float* x, const float* gamma, const float* beta, int rows, int D, float eps, int passes,

@@ -27,15 +27,16 @@ constexpr int SW = 8;  // waves per workgroup (K split inside the workgroup)
 typedef unsigned int u32x2v __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
 
-template <int BT, int NT, int SU, bool W8 = false>
+template <int BT, int NT, int SU, bool W8 = false, bool WT = false>
 __global__ __launch_bounds__(512) void skinny_mfma_kernel(GemvArgs g) {
   __shared__ float red[SW][NT * BT][256];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int fr = lane & 15, fg = lane >> 4;
   const int n0 = blockIdx.x * (16 * NT);
-  const bf16_t* __restrict__ W = (const bf16_t*)g.W;
+  const bf16_t* __restrict__ W = (const bf16_t*)(WT ? g.Wt : g.W);
   const bf16_t* __restrict__ X = (const bf16_t*)g.X;
   const int K = g.K, nks_all = K >> 5;
+  constexpr int WSTEP = WT ? 512 : 32;  // elements from one k-step's fragment to the next
   const int S = gridDim.y, split = blockIdx.y;
   const int per = (nks_all + S - 1) / S;
   const int ks0 = split * per, nks = min(per, nks_all - ks0);  // this workgroup's k-steps [ks0, ks0 + nks)
@@ -44,7 +45,8 @@ __global__ __launch_bounds__(512) void skinny_mfma_kernel(GemvArgs g) {
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
     const size_t off = (size_t)min(n0 + t * 16 + fr, g.N - 1) * K + fg * 8 + (size_t)ks0 * 32;
-    wp[t] = W + off;
+    // tiled: tile (n0/16 + t) clamped to the last one (a workgroup's surplus tile re-reads it; its outputs are masked)
+    wp[t] = WT ? W + (((size_t)min(n0 / 16 + t, (g.N + 15) / 16 - 1) * nks_all + ks0) * 64 + lane) * 8 : W + off;
     wq[t] = (const uint8_t*)g.W8 + off;
   }
   // X either row-major [B][K] or fragment-tiled [K/32][BT][64 lanes][8] (tile_off): one MFMA operand = 1 KiB contiguous
@@ -65,7 +67,7 @@ __global__ __launch_bounds__(512) void skinny_mfma_kernel(GemvArgs g) {
   constexpr int EPT = (NT * BT * 256 + 511) / 512;
   float bpre[EPT], spre[EPT];
   {
-    const float* bp = g.bias ? g.bias : (W8 ? g.wscale : reinterpret_cast<const float*>(g.W));  // any readable address without a bias
+    const float* bp = g.bias ? g.bias : (W8 ? g.wscale : reinterpret_cast<const float*>(W));  // any readable address without a bias
 #pragma unroll
     for (int it = 0; it < EPT; ++it) {
       const int idx = tid + it * 512, tb = idx >> 8, t = tb / BT;
@@ -90,7 +92,7 @@ __global__ __launch_bounds__(512) void skinny_mfma_kernel(GemvArgs g) {
           w4[3] = __builtin_bit_cast(unsigned int, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(q[1], 1.0f, true));
           wf[u][t] = __builtin_bit_cast(bf16x8, w4);
         } else {
-          wf[u][t] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(wp[t] + (size_t)ks * 32));
+          wf[u][t] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(wp[t] + (size_t)ks * WSTEP));
         }
       }
     }
@@ -223,7 +225,29 @@ __global__ __launch_bounds__(256) void ln_rows_bf16_kernel(bf16_t* __restrict__ 
     }
 }
 
+// one thread per 16-byte group of the tiled copy: (tile, k-step, lane) <- W[tile*16 + lane%16][k-step*32 + lane/16*8 .. +8]
+__global__ __launch_bounds__(256) void retile_weights_kernel(u32x4v* __restrict__ dst, const bf16_t* __restrict__ src, int N, int K,
+                                                             size_t groups) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= groups) return;
+  const int lane = (int)(i & 63), nks = K >> 5;
+  const size_t tk = i >> 6;
+  const int ks = (int)(tk % nks), tile = (int)(tk / nks);
+  const int n = tile * 16 + (lane & 15), k = ks * 32 + (lane >> 4) * 8;
+  dst[i] = n < N ? *reinterpret_cast<const u32x4v*>(src + (size_t)n * K + k) : u32x4v{0u, 0u, 0u, 0u};
+}
+
 }  // namespace
+
+int retile_weights_bf16(void* dst, const void* src, int N, int K, hipStream_t s) {
+  ITTS_REQUIRE(dst && src && N > 0 && K > 0 && K % 32 == 0, "retile_weights_bf16: K must be a multiple of 32");
+  ITTS_REQUIRE(!(((uintptr_t)dst | (uintptr_t)src) & 15), "retile_weights_bf16: pointers must be 16-byte aligned");
+  const size_t groups = (size_t)((N + 15) / 16) * (K / 32) * 64;
+  hipLaunchKernelGGL(retile_weights_kernel, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, s, (u32x4v*)dst, (const bf16_t*)src, N, K,
+                     groups);
+  ITTS_HIP_CHECK(hipGetLastError());
+  return OK;
+}
 
 bool skinny_mfma_supported(const GemvArgs& g) {
   return g.B >= 1 && g.B <= 128 && g.K % 32 == 0 && g.x_bf16 && g.prologue == 0 && !(g.accumulate && g.y_bf16) &&
@@ -242,6 +266,11 @@ static int launch_skinny(const GemvArgs& g, hipStream_t s) {
       hipLaunchKernelGGL((skinny_mfma_kernel<BT, 2, 5, true>), grid, blk, 0, s, g);
     else
       hipLaunchKernelGGL((skinny_mfma_kernel<BT, 1, 5, true>), grid, blk, 0, s, g);
+  } else if (g.Wt) {
+    if (nt2)
+      hipLaunchKernelGGL((skinny_mfma_kernel<BT, 2, 5, false, true>), grid, blk, 0, s, g);
+    else
+      hipLaunchKernelGGL((skinny_mfma_kernel<BT, 1, 5, false, true>), grid, blk, 0, s, g);
   } else if (nt2)
     hipLaunchKernelGGL((skinny_mfma_kernel<BT, 2, 5>), grid, blk, 0, s, g);
   else
@@ -251,7 +280,8 @@ static int launch_skinny(const GemvArgs& g, hipStream_t s) {
 }
 
 int skinny_mfma(const GemvArgs& g, hipStream_t s) {
-  ITTS_REQUIRE(g.X && (g.W || g.W8) && (g.Y || g.ksplit > 1) && g.N > 0, "skinny_mfma: bad args");
+  ITTS_REQUIRE(g.X && (g.W || g.W8 || g.Wt) && (g.Y || g.ksplit > 1) && g.N > 0, "skinny_mfma: bad args");
+  ITTS_REQUIRE(!g.Wt || !((uintptr_t)g.Wt & 15), "skinny_mfma: tiled weights must be 16-byte aligned");
   ITTS_REQUIRE(skinny_mfma_supported(g), "skinny_mfma: unsupported shape");
   ITTS_REQUIRE(g.ksplit <= (g.K >> 5), "skinny_mfma: ksplit larger than the number of k-steps");
   const int bt = (g.B + 15) / 16;

@@ -32,6 +32,7 @@ struct Lin {
   int N = 0, Cin = 0, taps = 1, nphase = 1, dt = 0;
   const void* w8 = nullptr;       // optional fp8 e4m3 copy of w (decode GEMV of the GPT), one scale per output row
   const float* wscale = nullptr;
+  void* wt = nullptr;             // bf16 copy in MFMA-fragment tiles (wtile_off) for the batched decode step, made on first use
 };
 struct Norm {
   const float* g = nullptr;
@@ -189,6 +190,8 @@ struct Engine {
   std::map<std::string, std::vector<float>> taps;
   int tap(const char* name, const void* p, int dt, int64_t n, hipStream_t s);
 
+  void* gpt_tiles = nullptr;  // one allocation: Lin::wt of every GPT projection + head (batched decode, bf16)
+  int ensure_decode_tiles(hipStream_t s);
   ~Engine();
 
   // op wrappers (skip launches in dry mode)

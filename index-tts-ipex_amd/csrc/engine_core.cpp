@@ -8,6 +8,7 @@ namespace itts {
 
 Engine::~Engine() {
   if (ws) (void)hipFree(ws);
+  if (gpt_tiles) (void)hipFree(gpt_tiles);
   DecodeState& d = ds;
   void* ptrs[] = {d.kc, d.vc, d.h, d.qkv, d.ctx, d.act, d.hn, d.logits, d.len, d.prefix_dev,
                   d.kv_start, d.cur_tok, d.ids, d.unfinished, d.seen, d.partial, d.attn_o, d.attn_ml, d.uniforms, d.forced, d.scores2, d.gran, d.fuse_err, d.beam_ids, d.anc, d.beam_scores, d.hyp_tok,
@@ -223,6 +224,8 @@ int Engine::finalize() {
   if (any_prefix(*this, "gpt.")) {
     const int D = c.model_dim, V = c.number_mel_codes;
     gpt = GptW();
+    if (gpt_tiles) (void)hipFree(gpt_tiles);  // fragment-tiled copies belong to the weights they were made from
+    gpt_tiles = nullptr;
     for (int i = 0; i < c.layers; ++i) {
       const std::string p = "gpt.h." + std::to_string(i) + ".";
       GptLayerW L;

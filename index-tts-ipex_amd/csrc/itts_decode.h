@@ -32,6 +32,7 @@ struct GemvArgs {
   const float* wscale = nullptr; // ... with one scale per output row: y = scale[n] * (x . w8[n]) + bias[n]
   unsigned long long* stamp = nullptr;  // -DITTS_GEMV_STAMPS builds only (tools/ubench_gemv2.hip): s_memtime per phase
   int x_tiled = 0, y_tiled = 0;  // skinny_mfma: bf16 X / Y in MFMA-fragment tiles (tile_off) instead of row-major
+  const void* Wt = nullptr;      // skinny_mfma: W as bf16 fragment tiles (wtile_off) - used instead of W when set
 };
 
 // bf16 activations of the batched decode step live in the operand order of v_mfma_f32_16x16x32_bf16: element (b, k) of a
@@ -40,6 +41,16 @@ struct GemvArgs {
 __host__ __device__ inline size_t tile_off(int b, int k, int BT) {
   return ((size_t)(k >> 5) * BT + (b >> 4)) * 512 + ((((k & 31) >> 3) << 4) + (b & 15)) * 8 + (k & 7);
 }
+
+// bf16 weights of the batched decode step in the same operand order: element (n, k) of W[N, K] at
+// ((n/16) * (K/32) + k/32) * 512 + ((k%32)/8 * 16 + n%16) * 8 + k%8 - every wave-load of a (16 features x 32 k) fragment is
+// one contiguous KiB (8 whole 128-B lines) instead of 16 half lines 2*K bytes apart, and the K/32 fragments of a feature
+// tile are contiguous: the HBM weight stream of the skinny GEMMs runs 1.3x faster (tools/ubench_skinny.hip).
+// Rows N .. 16*ceil(N/16) are zero.
+__host__ __device__ inline size_t wtile_off(int n, int k, int K) {
+  return ((size_t)(n >> 4) * (K >> 5) + (k >> 5)) * 512 + ((((k & 31) >> 3) << 4) + (n & 15)) * 8 + (k & 7);
+}
+int retile_weights_bf16(void* dst, const void* src, int N, int K, hipStream_t s);
 
 struct SamplerArgs {
   const float* logits = nullptr;  // [B, V]

@@ -128,10 +128,35 @@ static int dev_alloc(void** p, size_t bytes) {
   return OK;
 }
 
+// The batched decode step (B > 4, bf16) streams its weights from fragment-tiled copies (wtile_off): made once per loaded
+// checkpoint, on the first batched generation (+ 2 bytes per GPT weight; ITTS_NO_TILED_W=1 keeps the row-major stream).
+int Engine::ensure_decode_tiles(hipStream_t s) {
+  static const bool off = getenv("ITTS_NO_TILED_W") != nullptr;
+  if (gpt_tiles || off || !gpt.ok) return OK;
+  std::vector<Lin*> lins;
+  for (GptLayerW& L : gpt.layers)
+    for (Lin* l : {&L.attn, &L.proj, &L.fc, &L.proj2}) lins.push_back(l);
+  lins.push_back(&gpt.head);
+  size_t total = 0;
+  for (Lin* l : lins) {
+    if (l->dt != BF16 || l->Cin % 32 != 0 || l->taps != 1) return OK;  // not a bf16 checkpoint: nothing to tile
+    total += (size_t)((l->N + 15) / 16) * 16 * l->Cin * 2;
+  }
+  ITTS_TRY(dev_alloc(&gpt_tiles, total));
+  size_t o = 0;
+  for (Lin* l : lins) {
+    l->wt = (char*)gpt_tiles + o;
+    ITTS_TRY(retile_weights_bf16(l->wt, l->w, l->N, l->Cin, s));
+    o += (size_t)((l->N + 15) / 16) * 16 * l->Cin * 2;
+  }
+  return OK;
+}
+
 int Engine::ensure_decode_state(int B, int Smax, int max_gen, hipStream_t s) {
   const itts_config& c = cfg;
   const int D = c.model_dim, H = c.heads, dh = D / H, V = c.number_mel_codes;
   DecodeState& d = ds;
+  if (adt == BF16 && B > 4 && D % 32 == 0 && D <= 2048) ITTS_TRY(ensure_decode_tiles(s));
   const size_t need = (size_t)c.layers * B * H * Smax * dh * es;
   const bool regrow = B > d.cap_B || max_gen > d.cap_gen;
   if (need > d.cache_bytes || regrow || B != d.B || Smax != d.Smax) {
@@ -159,7 +184,7 @@ int Engine::ensure_decode_state(int B, int Smax, int max_gen, hipStream_t s) {
     ITTS_TRY(dev_alloc((void**)&d.ctx, (size_t)cb * D * 4));
     ITTS_TRY(dev_alloc((void**)&d.act, (size_t)cb * 4 * D * 4));
     ITTS_TRY(dev_alloc((void**)&d.hn, (size_t)cb * D * 4));
-    ITTS_TRY(dev_alloc((void**)&d.partial, (size_t)4 * cb * D * 4));
+    ITTS_TRY(dev_alloc((void**)&d.partial, (size_t)8 * cb * D * 4));
     ITTS_TRY(dev_alloc((void**)&d.attn_o, (size_t)cb * D * ATTN_NSPLIT * 4));
     ITTS_TRY(dev_alloc((void**)&d.attn_ml, (size_t)cb * H * 2 * ATTN_NSPLIT * 4));
     ITTS_TRY(dev_alloc((void**)&d.logits, (size_t)cb * V * 4));
@@ -467,6 +492,7 @@ int Engine::head_and_sample(hipStream_t s) {
     g.prologue = 0;
     g.W8 = gpt.head.w8;
     g.wscale = gpt.head.wscale;
+    g.Wt = gpt.head.wt;
     ITTS_TRY(skinny_mfma(g, s));
   } else if (adt == BF16 && gemv_bf16_supported(g)) {
     g.W8 = gpt.head.w8;
@@ -647,6 +673,7 @@ int Engine::decode_step_launch(hipStream_t s) {
     g.ln_gamma = L.ln1.g;
     g.ln_beta = L.ln1.b;
     g.w8src = L.attn.w8 ? &L.attn : nullptr;
+    g.Wt = L.attn.wt;
     const size_t lo = (size_t)l * B * H * ds.Smax * dh * es;
     // few (row, head) pairs: the keys of each pair go to ATTN_NSPLIT workgroups and the projection merges the partials
     static const bool no_split = getenv("ITTS_ATTN_NOSPLIT") != nullptr;
@@ -687,6 +714,7 @@ int Engine::decode_step_launch(hipStream_t s) {
       ITTS_REQUIRE(gemv_bf16_supported(p), "decode: split attention needs the bf16 GEMV with prologue 3");
     }
     p.w8src = L.proj.w8 ? &L.proj : nullptr;
+    p.Wt = L.proj.wt;
     ITTS_TRY(run(p, L.proj.dt));
     GemvArgs f;  // act = gelu_new(LN2(h) Wfc + b)
     f.B = B;
@@ -703,6 +731,7 @@ int Engine::decode_step_launch(hipStream_t s) {
     f.ln_gamma = L.ln2.g;
     f.ln_beta = L.ln2.b;
     f.w8src = L.fc.w8 ? &L.fc : nullptr;
+    f.Wt = L.fc.wt;
     ITTS_TRY(run(f, L.fc.dt));
     GemvArgs q;  // h += act Wproj2 + b
     q.B = B;
@@ -716,6 +745,7 @@ int Engine::decode_step_launch(hipStream_t s) {
     q.ldy = D;
     q.accumulate = 1;
     q.w8src = L.proj2.w8 ? &L.proj2 : nullptr;
+    q.Wt = L.proj2.wt;
     ITTS_TRY(run(q, L.proj2.dt));
   }
   return head_and_sample(s);

@@ -64,6 +64,7 @@ _PROTOS = {
     "itts_attention": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, f32, i32, vp, i32, vp]),
     "itts_gemv": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, i32, i32, vp]),
     "itts_skinny_gemm": (i32, [vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, i32, vp]),
+    "itts_retile_weights": (i32, [vp, vp, i32, i32, vp]),
     "itts_ln_rows_bf16": (i32, [vp, vp, vp, vp, i32, i32, f32, i32, vp, i32, vp, i32, vp]),
     "itts_transpose": (i32, [vp, vp, i32, i32, i32, i32, vp]),
     "itts_engine_create": (i32, [C.POINTER(Config), C.POINTER(vp)]),

@@ -284,6 +284,22 @@ def test_skinny_gemm(lib, case, tiled):
                                      stream()))
         torch.cuda.synchronize()
         assert torch.equal(y1.cpu()[:N], got[r])
+    # the fragment-tiled weight copy (what the engine streams at batch > 4) gives the same bits; its layout is wtile_off
+    wt = torch.empty((N + 15) // 16 * 16 * K, dtype=torch.bfloat16, device=DEV)
+    L.check(lib.itts_retile_weights(wt.data_ptr(), wd.data_ptr(), N, K, stream()))
+    wp = torch.zeros((N + 15) // 16 * 16, K, dtype=torch.bfloat16)
+    wp[:N] = w
+    assert torch.equal(wt.cpu(), wp.view(-1, 16, K // 32, 4, 8).permute(0, 2, 3, 1, 4).reshape(-1))
+    y2 = y0.to(DEV).clone() if not ybf else torch.empty(BT * 16 * N, dtype=torch.bfloat16, device=DEV)
+    L.check(lib.itts_skinny_gemm(y2.data_ptr(), ybf, xd.data_ptr(), wt.data_ptr(), bd.data_ptr(), B, N, K, act, acc, 1, None,
+                                 layout | 4, stream()))
+    torch.cuda.synchronize()
+    if ybf and not tiled:
+        assert torch.equal(y2.cpu()[:B * N], y.cpu()[:B * N])
+    elif ybf:
+        assert torch.equal(from_tiles(y2.cpu(), B, N), got)
+    else:
+        assert torch.equal(y2.cpu(), y.cpu())
 
 
 @pytest.mark.gpu

@@ -9,8 +9,8 @@ typedef float f32x4v __attribute__((ext_vector_type(4)));
 constexpr int SW = 8;
 
 // XMODE 0: no X loads (constant), 1: row-major [B][K], 2: fragment-tiled [K/32][BT][64 lanes][8]
-// WMODE 0: no W loads, 1: nontemporal row-major [N][K], 2: plain loads
-template <int BT, int NT, int SU, int XMODE, int WMODE, int WAVES>
+// WMODE 0: no W loads, 1: nontemporal row-major [N][K], 2: plain loads, 3: nontemporal fragment-tiled [N/16][K/32][64 lanes][8]
+template <int BT, int NT, int SU, int XMODE, int WMODE, int WAVES, bool XFIRST = false>
 __global__ __launch_bounds__(WAVES * 64) void k_skinny(float* __restrict__ Y, const unsigned short* __restrict__ X,
                                                        const unsigned short* __restrict__ W, int B, int N, int K) {
   __shared__ float red[WAVES][NT * BT][256];
@@ -20,7 +20,9 @@ __global__ __launch_bounds__(WAVES * 64) void k_skinny(float* __restrict__ Y, co
   const int ks0 = split * per, nks = min(per, nks_all - ks0);
   const unsigned short* wp[NT];
 #pragma unroll
-  for (int t = 0; t < NT; ++t) wp[t] = W + (size_t)min(n0 + t * 16 + fr, N - 1) * K + fg * 8 + (size_t)ks0 * 32;
+  for (int t = 0; t < NT; ++t)
+    wp[t] = WMODE == 3 ? W + (((size_t)min(n0 / 16 + t, N / 16 - 1) * nks_all + ks0) * 64 + lane) * 8
+                       : W + (size_t)min(n0 + t * 16 + fr, N - 1) * K + fg * 8 + (size_t)ks0 * 32;
   const unsigned short* xp[BT];
 #pragma unroll
   for (int bt = 0; bt < BT; ++bt)
@@ -32,12 +34,37 @@ __global__ __launch_bounds__(WAVES * 64) void k_skinny(float* __restrict__ Y, co
     for (int bt = 0; bt < BT; ++bt) acc[t][bt] = f32x4v{0.f, 0.f, 0.f, 0.f};
   for (int k0 = wave; k0 < nks; k0 += WAVES * SU) {
     bf16x8 wf[SU][NT], xf[SU][BT];
+    if (XFIRST) {
+#pragma unroll
+    for (int u = 0; u < SU; ++u) {
+      const int ks = min(k0 + u * WAVES, nks - 1);
+#pragma unroll
+      for (int bt = 0; bt < BT; ++bt) {
+        if (XMODE == 1) xf[u][bt] = *reinterpret_cast<const bf16x8*>(xp[bt] + (size_t)ks * 32);
+        else if (XMODE == 2) xf[u][bt] = *reinterpret_cast<const bf16x8*>(xp[bt] + (size_t)ks * BT * 512);
+        else xf[u][bt] = bf16x8{(short)ks, 1, 2, 3, 4, 5, 6, (short)lane};
+      }
+    }
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int u = 0; u < SU; ++u) {
       const int ks = min(k0 + u * WAVES, nks - 1);
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
-        if (WMODE == 1) wf[u][t] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(wp[t] + (size_t)ks * 32));
+        if (WMODE == 3) wf[u][t] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(wp[t] + (size_t)ks * 512));
+        else if (WMODE == 1) wf[u][t] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(wp[t] + (size_t)ks * 32));
+        else if (WMODE == 2) wf[u][t] = *reinterpret_cast<const bf16x8*>(wp[t] + (size_t)ks * 32);
+        else wf[u][t] = bf16x8{(short)ks, 1, 2, 3, 4, 5, 6, (short)lane};
+      }
+    }
+    } else {
+#pragma unroll
+    for (int u = 0; u < SU; ++u) {
+      const int ks = min(k0 + u * WAVES, nks - 1);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        if (WMODE == 3) wf[u][t] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(wp[t] + (size_t)ks * 512));
+        else if (WMODE == 1) wf[u][t] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(wp[t] + (size_t)ks * 32));
         else if (WMODE == 2) wf[u][t] = *reinterpret_cast<const bf16x8*>(wp[t] + (size_t)ks * 32);
         else wf[u][t] = bf16x8{(short)ks, 1, 2, 3, 4, 5, 6, (short)lane};
       }
@@ -52,6 +79,8 @@ __global__ __launch_bounds__(WAVES * 64) void k_skinny(float* __restrict__ Y, co
         else xf[u][bt] = bf16x8{(short)ks, 1, 2, 3, 4, 5, 6, (short)lane};
       }
     }
+    }
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int u = 0; u < SU; ++u)
       if (k0 + u * WAVES < nks)
@@ -121,6 +150,45 @@ int main() {
   RUN("qkv  4 waves SU=10 X tiled", 4, 1, 10, 2, 1, 4, 3840, 1280, 1)
   RUN("qkv  4 waves SU=5 X tiled", 4, 1, 5, 2, 1, 4, 3840, 1280, 1)
   RUN("qkv  16 waves SU=3 X tiled", 4, 1, 3, 2, 1, 16, 3840, 1280, 1)
+#define RUNX(name, BT, NT, SU, XM, WM, WV, N, K, S)                                                                       \
+  {                                                                                                                      \
+    const int tiles = (N + 16 * NT - 1) / (16 * NT);                                                                     \
+    float us = timeit([&](int i) { hipLaunchKernelGGL((k_skinny<BT, NT, SU, XM, WM, WV, true>), dim3(tiles, S), dim3(WV * 64), 0, s, Y, X, \
+                                                      W + (size_t)i * slab, B, N, K); }, REP, s);                        \
+    printf("%-52s N=%4d K=%4d S=%d blocks=%4d  %.2f us\n", name, N, K, S, tiles * S, us);                                 \
+  }
+  RUNX("qkv  X tiled, X loads issued first", 4, 1, 5, 2, 1, 8, 3840, 1280, 1)
+  RUNX("fc   NT=2 X tiled, X first", 4, 2, 5, 2, 1, 8, 5120, 1280, 1)
+  RUNX("proj2 NT=2 S=4 X tiled, X first", 4, 2, 5, 2, 1, 8, 1280, 5120, 4)
+  RUNX("proj  NT=1 S=2 X tiled, X first", 4, 1, 5, 2, 1, 8, 1280, 1280, 2)
+  // all 256 CUs, small X per workgroup: wide feature tiles x deep K split (partials)
+  RUN("fc   NT=4 S=3 (240 WGs) 8 waves", 4, 4, 2, 2, 1, 8, 5120, 1280, 3)
+  RUN("fc   NT=5 S=4 (256 WGs) 8 waves", 4, 5, 2, 2, 1, 8, 5120, 1280, 4)
+  RUN("fc   NT=5 S=4 (256 WGs) 4 waves", 4, 5, 3, 2, 1, 4, 5120, 1280, 4)
+  RUN("fc   NT=2 S=2 (320 WGs) 8 waves", 4, 2, 3, 2, 1, 8, 5120, 1280, 2)
+  RUN("fc   NT=4 S=4 (320 WGs) 4 waves", 4, 4, 3, 2, 1, 4, 5120, 1280, 4)
+  RUN("qkv  NT=3 S=3 (240 WGs) 8 waves", 4, 3, 2, 2, 1, 8, 3840, 1280, 3)
+  RUN("qkv  NT=5 S=5 (240 WGs) 8 waves", 4, 5, 1, 2, 1, 8, 3840, 1280, 5)
+  RUN("qkv  NT=5 S=5 (240 WGs) 4 waves", 4, 5, 2, 2, 1, 4, 3840, 1280, 5)
+  RUN("qkv  NT=2 S=2 (240 WGs) 8 waves", 4, 2, 3, 2, 1, 8, 3840, 1280, 2)
+  RUN("proj2 NT=5 S=16 (256 WGs) 8 waves", 4, 5, 2, 2, 1, 8, 1280, 5120, 16)
+  RUN("proj2 NT=5 S=16 (256 WGs) 4 waves", 4, 5, 3, 2, 1, 4, 1280, 5120, 16)
+  RUN("proj2 NT=4 S=12 (240 WGs) 8 waves", 4, 4, 2, 2, 1, 8, 1280, 5120, 12)
+  RUN("proj2 NT=2 S=6 (240 WGs) 8 waves", 4, 2, 4, 2, 1, 8, 1280, 5120, 6)
+  RUN("proj  NT=2 S=6 (240 WGs) 8 waves", 4, 2, 1, 2, 1, 8, 1280, 1280, 6)
+  RUN("proj  NT=5 S=8 (128 WGs) 4 waves", 4, 5, 2, 2, 1, 4, 1280, 1280, 8)
+  RUN("proj  NT=2 S=4 (160 WGs) 8 waves", 4, 2, 2, 2, 1, 8, 1280, 1280, 4)
+  // W in fragment tiles too (every wave-load 1 KiB contiguous)
+  RUN("qkv  X tiled, W tiled", 4, 1, 5, 2, 3, 8, 3840, 1280, 1)
+  RUN("qkv  no X, W tiled", 4, 1, 5, 0, 3, 8, 3840, 1280, 1)
+  RUN("fc   NT=2 X tiled, W tiled", 4, 2, 5, 2, 3, 8, 5120, 1280, 1)
+  RUN("fc   NT=2 no X, W tiled", 4, 2, 5, 0, 3, 8, 5120, 1280, 1)
+  RUN("fc   NT=1 X tiled, W tiled", 4, 1, 5, 2, 3, 8, 5120, 1280, 1)
+  RUN("fc   NT=4 S=3 W tiled", 4, 4, 2, 2, 3, 8, 5120, 1280, 3)
+  RUN("proj2 NT=2 S=4 X tiled, W tiled", 4, 2, 5, 2, 3, 8, 1280, 5120, 4)
+  RUN("proj2 NT=2 S=6 W tiled", 4, 2, 4, 2, 3, 8, 1280, 5120, 6)
+  RUN("proj  NT=1 S=2 X tiled, W tiled", 4, 1, 5, 2, 3, 8, 1280, 1280, 2)
+  RUN("proj  NT=2 S=6 W tiled", 4, 2, 1, 2, 3, 8, 1280, 1280, 6)
   RUN("fc   cur NT=2", 4, 2, 5, 1, 1, 8, 5120, 1280, 1)
   RUN("fc   NT=2 X tiled", 4, 2, 5, 2, 1, 8, 5120, 1280, 1)
   RUN("fc   NT=1 X tiled", 4, 1, 5, 2, 1, 8, 5120, 1280, 1)
