@@ -47,7 +47,8 @@ __global__ __launch_bounds__(512) void skinny_mfma_kernel(GemvArgs g) {
     const size_t off = (size_t)min(n0 + t * 16 + fr, g.N - 1) * K + fg * 8 + (size_t)ks0 * 32;
     // tiled: tile (n0/16 + t) clamped to the last one (a workgroup's surplus tile re-reads it; its outputs are masked)
     wp[t] = WT ? W + (((size_t)min(n0 / 16 + t, (g.N + 15) / 16 - 1) * nks_all + ks0) * 64 + lane) * 8 : W + off;
-    wq[t] = (const uint8_t*)g.W8 + off;
+    wq[t] = WT ? (const uint8_t*)g.W8t + (((size_t)min(n0 / 16 + t, (g.N + 15) / 16 - 1) * nks_all + ks0) * 64 + lane) * 8
+               : (const uint8_t*)g.W8 + off;
   }
   // X either row-major [B][K] or fragment-tiled [K/32][BT][64 lanes][8] (tile_off): one MFMA operand = 1 KiB contiguous
   const int btr = (g.B + 15) >> 4;  // batch tiles that exist (the template rounds up to 1 / 2 / 4 / 8)
@@ -80,11 +81,12 @@ __global__ __launch_bounds__(512) void skinny_mfma_kernel(GemvArgs g) {
     bf16x8 wf[SU][NT], xf[SU][BT];
 #pragma unroll
     for (int u = 0; u < SU; ++u) {
-      const int ks = min(k0 + u * SW, nks - 1);  // clamped loads, masked below: keeps the loads branch-free
+      const int ks = k0 + u * SW;
+      if (ks >= nks) break;  // wave-uniform: a wave with fewer k-steps than SU requests only its own (no duplicate ingest)
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
         if constexpr (W8) {
-          const u32x2v q = __builtin_nontemporal_load(reinterpret_cast<const u32x2v*>(wq[t] + (size_t)ks * 32));
+          const u32x2v q = __builtin_nontemporal_load(reinterpret_cast<const u32x2v*>(wq[t] + (size_t)ks * WSTEP));
           u32x4v w4;  // bytes 0,1 | 2,3 of each dword -> one bf16 pair each (same pairing as gemv_bf16_kernel<W8>)
           w4[0] = __builtin_bit_cast(unsigned int, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(q[0], 1.0f, false));
           w4[1] = __builtin_bit_cast(unsigned int, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(q[0], 1.0f, true));
@@ -98,7 +100,8 @@ __global__ __launch_bounds__(512) void skinny_mfma_kernel(GemvArgs g) {
     }
 #pragma unroll
     for (int u = 0; u < SU; ++u) {
-      const int ks = min(k0 + u * SW, nks - 1);
+      const int ks = k0 + u * SW;
+      if (ks >= nks) break;
 #pragma unroll
       for (int bt = 0; bt < BT; ++bt) xf[u][bt] = *reinterpret_cast<const bf16x8*>(xp[bt] + (size_t)ks * xstep);
     }
@@ -162,14 +165,14 @@ __global__ __launch_bounds__(256) void ln_rows_bf16_kernel(bf16_t* __restrict__ 
 #pragma unroll
   for (int i = 0; i < MAXE; ++i) v[i] = tid + i * 256 < D ? xr[tid + i * 256] : 0.f;
   if (nsplit > 0) {
-    // all partial loads of a thread are issued together (up to 4 splits x MAXE elements), then summed in split order
-    float pv[4][MAXE], bv[MAXE];
+    // all partial loads of a thread are issued together (up to 8 splits x MAXE elements), then summed in split order
+    float pv[8][MAXE], bv[MAXE];
 #pragma unroll
     for (int i = 0; i < MAXE; ++i) {
       const int c = min(tid + i * 256, D - 1);
       bv[i] = pbias ? pbias[c] : 0.f;
 #pragma unroll
-      for (int sp = 0; sp < 4; ++sp) pv[sp][i] = sp < nsplit ? partial[((size_t)sp * rows + row) * D + c] : 0.f;
+      for (int sp = 0; sp < 8; ++sp) pv[sp][i] = sp < nsplit ? partial[((size_t)sp * rows + row) * D + c] : 0.f;
     }
 #pragma unroll
     for (int i = 0; i < MAXE; ++i) {
@@ -177,7 +180,7 @@ __global__ __launch_bounds__(256) void ln_rows_bf16_kernel(bf16_t* __restrict__ 
       if (c < D) {
         float a = bv[i];
 #pragma unroll
-        for (int sp = 0; sp < 4; ++sp) a += pv[sp][i];
+        for (int sp = 0; sp < 8; ++sp) a += pv[sp][i];
         v[i] += a;
         xr[c] = v[i];
       }
@@ -237,7 +240,29 @@ __global__ __launch_bounds__(256) void retile_weights_kernel(u32x4v* __restrict_
   dst[i] = n < N ? *reinterpret_cast<const u32x4v*>(src + (size_t)n * K + k) : u32x4v{0u, 0u, 0u, 0u};
 }
 
+// fp8: one thread per 8-byte group
+__global__ __launch_bounds__(256) void retile_weights8_kernel(u32x2v* __restrict__ dst, const uint8_t* __restrict__ src, int N, int K,
+                                                              size_t groups) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= groups) return;
+  const int lane = (int)(i & 63), nks = K >> 5;
+  const size_t tk = i >> 6;
+  const int ks = (int)(tk % nks), tile = (int)(tk / nks);
+  const int n = tile * 16 + (lane & 15), k = ks * 32 + (lane >> 4) * 8;
+  dst[i] = n < N ? *reinterpret_cast<const u32x2v*>(src + (size_t)n * K + k) : u32x2v{0u, 0u};
+}
+
 }  // namespace
+
+int retile_weights_fp8(void* dst, const void* src, int N, int K, hipStream_t s) {
+  ITTS_REQUIRE(dst && src && N > 0 && K > 0 && K % 32 == 0, "retile_weights_fp8: K must be a multiple of 32");
+  ITTS_REQUIRE(!(((uintptr_t)dst | (uintptr_t)src) & 7), "retile_weights_fp8: pointers must be 8-byte aligned");
+  const size_t groups = (size_t)((N + 15) / 16) * (K / 32) * 64;
+  hipLaunchKernelGGL(retile_weights8_kernel, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, s, (u32x2v*)dst, (const uint8_t*)src, N, K,
+                     groups);
+  ITTS_HIP_CHECK(hipGetLastError());
+  return OK;
+}
 
 int retile_weights_bf16(void* dst, const void* src, int N, int K, hipStream_t s) {
   ITTS_REQUIRE(dst && src && N > 0 && K > 0 && K % 32 == 0, "retile_weights_bf16: K must be a multiple of 32");
@@ -261,7 +286,12 @@ static int launch_skinny(const GemvArgs& g, hipStream_t s) {
   const int tiles = (g.N + 15) / 16;
   const bool nt2 = tiles * g.ksplit >= 300 && BT <= 4;
   dim3 grid(nt2 ? (tiles + 1) / 2 : tiles, g.ksplit), blk(512);
-  if (g.W8) {
+  if (g.W8 && g.W8t) {
+    if (nt2)
+      hipLaunchKernelGGL((skinny_mfma_kernel<BT, 2, 5, true, true>), grid, blk, 0, s, g);
+    else
+      hipLaunchKernelGGL((skinny_mfma_kernel<BT, 1, 5, true, true>), grid, blk, 0, s, g);
+  } else if (g.W8) {
     if (nt2)
       hipLaunchKernelGGL((skinny_mfma_kernel<BT, 2, 5, true>), grid, blk, 0, s, g);
     else
@@ -282,6 +312,7 @@ static int launch_skinny(const GemvArgs& g, hipStream_t s) {
 int skinny_mfma(const GemvArgs& g, hipStream_t s) {
   ITTS_REQUIRE(g.X && (g.W || g.W8 || g.Wt) && (g.Y || g.ksplit > 1) && g.N > 0, "skinny_mfma: bad args");
   ITTS_REQUIRE(!g.Wt || !((uintptr_t)g.Wt & 15), "skinny_mfma: tiled weights must be 16-byte aligned");
+  ITTS_REQUIRE(!g.W8t || (g.W8 && !((uintptr_t)g.W8t & 7)), "skinny_mfma: tiled fp8 weights come with the row-major ones, 8-byte aligned");
   ITTS_REQUIRE(skinny_mfma_supported(g), "skinny_mfma: unsupported shape");
   ITTS_REQUIRE(g.ksplit <= (g.K >> 5), "skinny_mfma: ksplit larger than the number of k-steps");
   const int bt = (g.B + 15) / 16;
@@ -294,7 +325,7 @@ int skinny_mfma(const GemvArgs& g, hipStream_t s) {
 int ln_rows_bf16(void* y, float* x, const float* g1, const float* b1, int rows, int D, float eps, int passes,
                  const float* partial, int nsplit, const float* pbias, int y_tiled, hipStream_t s) {
   ITTS_REQUIRE(D <= 2048 && passes >= 1 && passes <= 2, "ln_rows_bf16: D > 2048 or bad pass count");
-  ITTS_REQUIRE(nsplit == 0 || (partial && nsplit <= 4), "ln_rows_bf16: partial sums missing or more than 4 splits");
+  ITTS_REQUIRE(nsplit == 0 || (partial && nsplit <= 8), "ln_rows_bf16: partial sums missing or more than 8 splits");
   ITTS_REQUIRE(!y_tiled || D % 32 == 0, "ln_rows_bf16: tiled output needs D % 32 == 0");
   if (D <= 1280)
     hipLaunchKernelGGL(ln_rows_bf16_kernel<5>, dim3(rows), dim3(256), 0, s, (bf16_t*)y, x, g1, b1, D, eps, passes, partial,

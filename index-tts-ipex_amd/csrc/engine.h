@@ -33,6 +33,7 @@ struct Lin {
   const void* w8 = nullptr;       // optional fp8 e4m3 copy of w (decode GEMV of the GPT), one scale per output row
   const float* wscale = nullptr;
   void* wt = nullptr;             // bf16 copy in MFMA-fragment tiles (wtile_off) for the batched decode step, made on first use
+  void* wt8 = nullptr;            // the same for the fp8 copy (8 bytes per lane: half-KiB fragments)
 };
 struct Norm {
   const float* g = nullptr;

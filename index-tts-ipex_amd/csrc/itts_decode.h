@@ -33,6 +33,7 @@ struct GemvArgs {
   unsigned long long* stamp = nullptr;  // -DITTS_GEMV_STAMPS builds only (tools/ubench_gemv2.hip): s_memtime per phase
   int x_tiled = 0, y_tiled = 0;  // skinny_mfma: bf16 X / Y in MFMA-fragment tiles (tile_off) instead of row-major
   const void* Wt = nullptr;      // skinny_mfma: W as bf16 fragment tiles (wtile_off) - used instead of W when set
+  const void* W8t = nullptr;     // skinny_mfma: the fp8 bytes in the same tile order - used instead of W8 when set
 };
 
 // bf16 activations of the batched decode step live in the operand order of v_mfma_f32_16x16x32_bf16: element (b, k) of a
@@ -51,6 +52,7 @@ __host__ __device__ inline size_t wtile_off(int n, int k, int K) {
   return ((size_t)(n >> 4) * (K >> 5) + (k >> 5)) * 512 + ((((k & 31) >> 3) << 4) + (n & 15)) * 8 + (k & 7);
 }
 int retile_weights_bf16(void* dst, const void* src, int N, int K, hipStream_t s);
+int retile_weights_fp8(void* dst, const void* src, int N, int K, hipStream_t s);  // same order, one byte per element
 
 struct SamplerArgs {
   const float* logits = nullptr;  // [B, V]

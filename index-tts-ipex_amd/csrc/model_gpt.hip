@@ -140,14 +140,20 @@ int Engine::ensure_decode_tiles(hipStream_t s) {
   size_t total = 0;
   for (Lin* l : lins) {
     if (l->dt != BF16 || l->Cin % 32 != 0 || l->taps != 1) return OK;  // not a bf16 checkpoint: nothing to tile
-    total += (size_t)((l->N + 15) / 16) * 16 * l->Cin * 2;
+    total += (size_t)((l->N + 15) / 16) * 16 * l->Cin * (l->w8 ? 3 : 2);
   }
   ITTS_TRY(dev_alloc(&gpt_tiles, total));
   size_t o = 0;
   for (Lin* l : lins) {
+    const size_t elems = (size_t)((l->N + 15) / 16) * 16 * l->Cin;
     l->wt = (char*)gpt_tiles + o;
     ITTS_TRY(retile_weights_bf16(l->wt, l->w, l->N, l->Cin, s));
-    o += (size_t)((l->N + 15) / 16) * 16 * l->Cin * 2;
+    o += elems * 2;
+    if (l->w8) {  // BASELINE config 5: the fp8 bytes in the same order
+      l->wt8 = (char*)gpt_tiles + o;
+      ITTS_TRY(retile_weights_fp8(l->wt8, l->w8, l->N, l->Cin, s));
+      o += elems;
+    }
   }
   return OK;
 }
@@ -493,6 +499,7 @@ int Engine::head_and_sample(hipStream_t s) {
     g.W8 = gpt.head.w8;
     g.wscale = gpt.head.wscale;
     g.Wt = gpt.head.wt;
+    g.W8t = gpt.head.wt8;
     ITTS_TRY(skinny_mfma(g, s));
   } else if (adt == BF16 && gemv_bf16_supported(g)) {
     g.W8 = gpt.head.w8;
@@ -626,8 +633,10 @@ int Engine::decode_step_launch(hipStream_t s) {
         g.prologue = 0;
       } else if (g.accumulate && g.Y == ds.h && g.N == D) {
         // residual projections have few 16-feature tiles (D/16 = 80 on 256 CUs): split K over workgroups, reduced by
-        // the LayerNorm that follows
-        g.ksplit = g.K >= 4 * D ? 4 : 2;
+        // the LayerNorm that follows.  3 / 5 splits (240 / 200 workgroups): best of tools/split_sweep.sh
+        static const int e_s1 = getenv("ITTS_SKINNY_SPLIT_PROJ") ? atoi(getenv("ITTS_SKINNY_SPLIT_PROJ")) : 3;
+        static const int e_s2 = getenv("ITTS_SKINNY_SPLIT_PROJ2") ? atoi(getenv("ITTS_SKINNY_SPLIT_PROJ2")) : 5;
+        g.ksplit = g.K >= 4 * D ? e_s2 : e_s1;
         g.partial = ds.partial;
         ds.pend_split = g.ksplit;
         ds.pend_bias = g.bias;
@@ -637,6 +646,7 @@ int Engine::decode_step_launch(hipStream_t s) {
       if (g.w8src) {  // fp8 copy of this projection (BASELINE config 5): the same weight bytes the GEMV path streams
         g.W8 = g.w8src->w8;
         g.wscale = g.w8src->wscale;
+        g.W8t = g.w8src->wt8;
       }
       return skinny_mfma(g, s);
     }
