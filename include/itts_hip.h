@@ -73,7 +73,9 @@ int itts_gemv(float* Y, const float* X, const void* W, const float* bias, int B,
  * itts_ln_rows_bf16 (deterministic two-stage reduction, no atomics).
  * layout bit 0: X is MFMA-fragment tiled, bit 1: bf16 Y is written tiled - element (b, k) at
  * ((k/32) * ceil(B/16) + b/16) * 512 + ((k%32)/8 * 16 + b%16) * 8 + k%8 (csrc/itts_decode.h tile_off).
- * layout bit 2: W is the fragment-tiled copy made by itts_retile_weights (same bits out, 1.3x faster weight stream). */
+ * layout bit 2: W is the fragment-tiled copy made by itts_retile_weights (same bits out, 1.3x faster weight stream).
+ * B <= 16 only - bit 3: X is the fp32 residual stream and LayerNorm (eps 1e-5, affine folded into W) runs in the
+ * prologue (K <= 1280, ksplit 1); bit 4: 8 features per workgroup (narrow residual projections, ksplit 1). */
 int itts_skinny_gemm(void* Y, int y_bf16, const void* X, const void* W, const float* bias, int B, int N, int K, int act,
                      int accumulate, int ksplit, float* partial, int layout, itts_stream stream);
 

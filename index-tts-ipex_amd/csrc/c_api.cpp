@@ -93,6 +93,11 @@ int itts_skinny_gemm(void* Y, int y_bf16, const void* X, const void* W, const fl
     g.Wt = W;
     g.W = nullptr;
   }
+  if (layout & 8) {  // X is fp32 [B, K]: LayerNorm (eps 1e-5, no affine) in the prologue, B <= 16
+    g.x_bf16 = 0;
+    g.prologue = 1;
+  }
+  g.half_tiles = (layout >> 4) & 1;
   return skinny_mfma(g, (hipStream_t)stream);
 }
 

@@ -27,12 +27,24 @@ constexpr int SW = 8;  // waves per workgroup (K split inside the workgroup)
 typedef unsigned int u32x2v __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
 
-template <int BT, int NT, int SU, bool W8 = false, bool WT = false>
+// LNP (B <= 16 only, BT = 1): X is the fp32 residual stream [B][K]; LayerNorm without affine (folded into W) runs in the
+// prologue - wave w owns rows 2w and 2w + 1, moments by DPP wave sums, the normalised bf16 rows go to LDS and every wave
+// reads its k-steps' fragments from there.  At 5-16 rows the step is launch-bound (7 launches a layer at ~5 us), so
+// folding the two LayerNorm launches of a layer into the projections they feed is worth more than their redundant
+// compute (80 KB of h per workgroup, L2 hits).
+// HALF (BT = 1, NT = 1): a workgroup owns 8 of a tile's 16 features (lanes of the other 8 load nothing and store nothing):
+// twice the workgroups for the narrow residual projections (N = D: 160 instead of 80), so they need no K split across
+// workgroups and accumulate straight into the residual stream - no partial sums for a LayerNorm launch to absorb.
+template <int BT, int NT, int SU, bool W8 = false, bool WT = false, bool LNP = false, bool HALF = false>
 __global__ __launch_bounds__(512) void skinny_mfma_kernel(GemvArgs g) {
+  static_assert(!(LNP || HALF) || BT == 1, "LayerNorm prologue / half tiles are the <= 16-row forms");
+  static_assert(!HALF || NT == 1, "half tiles: one tile per workgroup");
   __shared__ float red[SW][NT * BT][256];
+  extern __shared__ __attribute__((aligned(16))) unsigned short xs[];  // LNP: [16][K + 8] bf16
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int fr = lane & 15, fg = lane >> 4;
-  const int n0 = blockIdx.x * (16 * NT);
+  const int n0 = HALF ? (blockIdx.x >> 1) * 16 : blockIdx.x * (16 * NT);
+  const bool wlive = !HALF || (fr >> 3) == (int)(blockIdx.x & 1);  // HALF: this lane's feature belongs to this workgroup
   const bf16_t* __restrict__ W = (const bf16_t*)(WT ? g.Wt : g.W);
   const bf16_t* __restrict__ X = (const bf16_t*)g.X;
   const int K = g.K, nks_all = K >> 5;
@@ -58,6 +70,22 @@ __global__ __launch_bounds__(512) void skinny_mfma_kernel(GemvArgs g) {
   for (int bt = 0; bt < BT; ++bt)
     xp[bt] = g.x_tiled ? X + ((size_t)ks0 * btr + min(bt, btr - 1)) * 512 + lane * 8
                        : X + (size_t)min(bt * 16 + fr, g.B - 1) * K + fg * 8 + (size_t)ks0 * 32;
+  // LNP: this wave's two rows of the residual stream, requested before the weights (L2 hits: they return while the HBM
+  // weight requests behind them are in flight - loads return in issue order)
+  constexpr int LNE = 8;  // float4 per lane and row: K <= 2048
+  f32x4v hx[LNP ? 2 : 1][LNP ? LNE : 1];
+  float hpiv[2] = {0.f, 0.f};
+  if constexpr (LNP) {
+    const float* Hs = g.X;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const float* hr = Hs + (size_t)min(wave * 2 + r, g.B - 1) * K;
+      hpiv[r] = hr[0];
+#pragma unroll
+      for (int i = 0; i < LNE; ++i)
+        if (i * 256 < K) hx[r][i] = *reinterpret_cast<const f32x4v*>(hr + min(i * 256 + lane * 4, K - 4));
+    }
+  }
   f32x4v acc[NT][BT];
 #pragma unroll
   for (int t = 0; t < NT; ++t)
@@ -77,7 +105,9 @@ __global__ __launch_bounds__(512) void skinny_mfma_kernel(GemvArgs g) {
       spre[it] = W8 ? g.wscale[nn] : 1.f;
     }
   }
-  for (int k0 = wave; k0 < nks; k0 += SW * SU) {
+  // LNP: every wave passes through the body exactly once (nks <= SW * SU, host-checked), also one without a k-step of its
+  // own - it still normalises its two rows and joins the barrier
+  for (int k0 = wave; k0 < nks || (LNP && k0 == wave); k0 += SW * SU) {
     bf16x8 wf[SU][NT], xf[SU][BT];
 #pragma unroll
     for (int u = 0; u < SU; ++u) {
@@ -85,7 +115,9 @@ __global__ __launch_bounds__(512) void skinny_mfma_kernel(GemvArgs g) {
       if (ks >= nks) break;  // wave-uniform: a wave with fewer k-steps than SU requests only its own (no duplicate ingest)
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
-        if constexpr (W8) {
+        if (HALF && !wlive) {
+          wf[u][t] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+        } else if constexpr (W8) {
           const u32x2v q = __builtin_nontemporal_load(reinterpret_cast<const u32x2v*>(wq[t] + (size_t)ks * WSTEP));
           u32x4v w4;  // bytes 0,1 | 2,3 of each dword -> one bf16 pair each (same pairing as gemv_bf16_kernel<W8>)
           w4[0] = __builtin_bit_cast(unsigned int, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(q[0], 1.0f, false));
@@ -98,12 +130,56 @@ __global__ __launch_bounds__(512) void skinny_mfma_kernel(GemvArgs g) {
         }
       }
     }
+    if constexpr (LNP) {
+      const int xld = K + 8;  // bf16 elements per LDS row
 #pragma unroll
-    for (int u = 0; u < SU; ++u) {
-      const int ks = k0 + u * SW;
-      if (ks >= nks) break;
+      for (int r = 0; r < 2; ++r) {
+        const int row = wave * 2 + r;
+        float sm = 0.f, sq = 0.f;
 #pragma unroll
-      for (int bt = 0; bt < BT; ++bt) xf[u][bt] = *reinterpret_cast<const bf16x8*>(xp[bt] + (size_t)ks * xstep);
+        for (int i = 0; i < LNE; ++i)
+          if (i * 256 < K) {
+            const bool ok = i * 256 + lane * 4 < K;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float d = ok ? hx[r][i][e] - hpiv[r] : 0.f;  // moments about the row's first element, as ln_rows_bf16
+              sm += d;
+              sq = fmaf(d, d, sq);
+            }
+          }
+        sm = wave_sum(sm);
+        sq = wave_sum(sq);
+        const float invK = 1.f / (float)K, md = sm * invK, mean = hpiv[r] + md;
+        const float rstd = rsqrtf(fmaxf(sq * invK - md * md, 0.f) + g.ln_eps);
+#pragma unroll
+        for (int i = 0; i < LNE; ++i)
+          if (i * 256 < K && i * 256 + lane * 4 < K) {
+            bf16_t o4[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o4[e] = row < g.B ? (bf16_t)((hx[r][i][e] - mean) * rstd) : (bf16_t)0.f;
+            *reinterpret_cast<uint2*>(xs + (size_t)row * xld + i * 256 + lane * 4) = *reinterpret_cast<const uint2*>(o4);
+          }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int u = 0; u < SU; ++u) {
+        const int ks = k0 + u * SW;
+        if (ks >= nks) break;
+        xf[u][0] = *reinterpret_cast<const bf16x8*>(xs + (size_t)fr * xld + ((size_t)ks0 + ks) * 32 + fg * 8);
+      }
+    } else {
+#pragma unroll
+      for (int u = 0; u < SU; ++u) {
+        const int ks = k0 + u * SW;
+        if (ks >= nks) break;
+#pragma unroll
+        for (int bt = 0; bt < BT; ++bt) {
+          if (HALF && fr >= g.B)  // rows past the batch: nothing to fetch (their outputs are never stored)
+            xf[u][bt] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+          else
+            xf[u][bt] = *reinterpret_cast<const bf16x8*>(xp[bt] + (size_t)ks * xstep);
+        }
+      }
     }
 #pragma unroll
     for (int u = 0; u < SU; ++u) {
@@ -130,6 +206,7 @@ __global__ __launch_bounds__(512) void skinny_mfma_kernel(GemvArgs g) {
     const int tb = idx >> 8, t = tb / BT, bt = tb - t * BT, e = idx & 255, r = e >> 6, l = e & 63;
     const int b = bt * 16 + (l >> 4) * 4 + r, n = n0 + t * 16 + (l & 15);
     if (b >= g.B || n >= g.N) continue;
+    if (HALF && ((l & 15) >> 3) != (int)(blockIdx.x & 1)) continue;  // the other workgroup of the pair owns this feature
     float v = 0.f;
 #pragma unroll
     for (int w = 0; w < SW; ++w) v += red[w][tb][e];
@@ -275,9 +352,46 @@ int retile_weights_bf16(void* dst, const void* src, int N, int K, hipStream_t s)
 }
 
 bool skinny_mfma_supported(const GemvArgs& g) {
-  return g.B >= 1 && g.B <= 128 && g.K % 32 == 0 && g.x_bf16 && g.prologue == 0 && !(g.accumulate && g.y_bf16) &&
+  if (g.prologue == 1) {
+    if (!(g.B <= 16 && !g.x_bf16 && !g.half_tiles && g.K <= 1280 && g.ksplit == 1)) return false;
+  } else if (!(g.x_bf16 && g.prologue == 0)) {
+    return false;
+  }
+  if (g.half_tiles && !(g.B <= 16 && g.ksplit == 1)) return false;
+  return g.B >= 1 && g.B <= 128 && g.K % 32 == 0 && !(g.accumulate && g.y_bf16) &&
          !(((uintptr_t)g.W | (uintptr_t)g.X) & 15) && !((uintptr_t)g.W8 & 7) && (!g.W8 || g.wscale) && g.ksplit >= 1 &&
          (g.ksplit == 1 || (g.partial && g.act == ACT_NONE));
+}
+
+// <= 16 rows: LayerNorm prologue (prologue == 1, X = fp32 residual stream) or half-tile residual projection (half_tiles)
+template <bool LNP, bool HALF>
+static int launch_skinny16(const GemvArgs& g, hipStream_t s) {
+  const int tiles = (g.N + 15) / 16;
+  const bool nt2 = !HALF && tiles >= 300;
+  dim3 grid(HALF ? tiles * 2 : nt2 ? (tiles + 1) / 2 : tiles), blk(512);
+  const size_t lds = LNP ? (size_t)16 * (g.K + 8) * 2 : 0;
+  // HALF has no K split: a deep projection (K = 4 D: 160 k-steps, 20 per wave) keeps all of them in flight at once
+  // (SU = 20: 160 VGPRs of operands at one tile per wave) instead of four dependent rounds of 5
+  const bool deep = HALF && (g.K >> 5) > SW * 5;
+#define GO(W8_, WT_)                                                                                           \
+  {                                                                                                            \
+    if constexpr (HALF) {                                                                                      \
+      if (deep)                                                                                                \
+        hipLaunchKernelGGL((skinny_mfma_kernel<1, 1, 20, W8_, WT_, LNP, true>), grid, blk, lds, s, g);         \
+      else                                                                                                     \
+        hipLaunchKernelGGL((skinny_mfma_kernel<1, 1, 5, W8_, WT_, LNP, true>), grid, blk, lds, s, g);          \
+    } else if (nt2)                                                                                              \
+      hipLaunchKernelGGL((skinny_mfma_kernel<1, 2, 5, W8_, WT_, LNP, false>), grid, blk, lds, s, g);           \
+    else                                                                                                       \
+      hipLaunchKernelGGL((skinny_mfma_kernel<1, 1, 5, W8_, WT_, LNP, false>), grid, blk, lds, s, g);           \
+  }
+  if (g.W8 && g.W8t) GO(true, true)
+  else if (g.W8) GO(true, false)
+  else if (g.Wt) GO(false, true)
+  else GO(false, false)
+#undef GO
+  ITTS_HIP_CHECK(hipGetLastError());
+  return OK;
 }
 
 template <int BT>
@@ -316,6 +430,15 @@ int skinny_mfma(const GemvArgs& g, hipStream_t s) {
   ITTS_REQUIRE(skinny_mfma_supported(g), "skinny_mfma: unsupported shape");
   ITTS_REQUIRE(g.ksplit <= (g.K >> 5), "skinny_mfma: ksplit larger than the number of k-steps");
   const int bt = (g.B + 15) / 16;
+  if (g.prologue == 1 || g.half_tiles) {
+    ITTS_REQUIRE(bt == 1 && g.ksplit == 1, "skinny_mfma: LayerNorm prologue / half tiles are for <= 16 rows, no K split");
+    if (g.prologue == 1) {
+      ITTS_REQUIRE(!g.x_bf16 && !g.half_tiles && g.K <= 1280 && !((uintptr_t)g.X & 15),
+                   "skinny_mfma: LayerNorm prologue needs fp32 X [B, K], K <= 1280");
+      return launch_skinny16<true, false>(g, s);
+    }
+    return launch_skinny16<false, true>(g, s);
+  }
   if (bt <= 1) return launch_skinny<1>(g, s);
   if (bt <= 2) return launch_skinny<2>(g, s);
   if (bt <= 4) return launch_skinny<4>(g, s);

@@ -34,6 +34,7 @@ struct GemvArgs {
   int x_tiled = 0, y_tiled = 0;  // skinny_mfma: bf16 X / Y in MFMA-fragment tiles (tile_off) instead of row-major
   const void* Wt = nullptr;      // skinny_mfma: W as bf16 fragment tiles (wtile_off) - used instead of W when set
   const void* W8t = nullptr;     // skinny_mfma: the fp8 bytes in the same tile order - used instead of W8 when set
+  int half_tiles = 0;            // skinny_mfma, <= 16 rows: 8 features per workgroup (narrow projections, no K split)
 };
 
 // bf16 activations of the batched decode step live in the operand order of v_mfma_f32_16x16x32_bf16: element (b, k) of a

@@ -622,7 +622,25 @@ int Engine::decode_step_launch(hipStream_t s) {
   const bool fast = adt == BF16 && B <= 4;  // bf16 activations between the decode kernels (ctx, act)
   const bool skinny = adt == BF16 && B > 4 && D % 32 == 0 && D <= 2048;  // weights once, batch on MFMA
   ds.pend_split = 0;
+  // 5-16 rows: the step is launch-bound, so the two LayerNorm launches of a layer fold into the projections they feed
+  // (skinny_mfma_kernel<LNP>) and the residual projections run as half tiles without a K split (<HALF>): 5 launches a
+  // layer instead of 7 (ITTS_NO_SKINNY16=1 keeps the 7-launch form)
+  static const bool no_s16 = getenv("ITTS_NO_SKINNY16") != nullptr;
+  const bool small16 = skinny && B <= 16 && D <= 1280 && !no_s16;
   auto run = [&](GemvArgs& g, int dt) -> int {
+    if (small16 && ((g.prologue == 1 && !g.ln_gamma) || (g.prologue == 0 && g.accumulate && g.Y == ds.h && g.N == D))) {
+      if (g.prologue != 1) {
+        g.half_tiles = 1;
+        g.x_tiled = 1;
+      }
+      g.y_tiled = g.y_bf16;
+      if (g.w8src) {
+        g.W8 = g.w8src->w8;
+        g.wscale = g.w8src->wscale;
+        g.W8t = g.w8src->wt8;
+      }
+      return skinny_mfma(g, s);
+    }
     if (skinny) {
       if (g.prologue == 1) {  // LayerNorm as a row kernel (its affine lives in the projection); it also absorbs the
                               // split-K partial sums of the projection that fed the residual stream

@@ -303,6 +303,70 @@ def test_skinny_gemm(lib, case, tiled):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("tiledw", [0, 1])
+@pytest.mark.parametrize("case", [(6, 3840, 1280, 0, 0), (16, 5120, 1280, 1, 1), (9, 66, 128, 0, 0), (5, 200, 512, 1, 1)])
+def test_skinny_gemm_layernorm_prologue(lib, case, tiledw):
+    """5-16 decode rows: LayerNorm (affine folded into W) inside the projection that consumes it; vs fp64 LayerNorm of the
+    fp32 rows, rounded to bf16 as the row kernel does, times the same bf16 weights."""
+    B, N, K, gelu, ybf = case
+    x = rnd("skl.x", (B, K)) * 2.5 + 0.3
+    w = (rnd("skl.w", (N, K)) * 0.05).to(torch.bfloat16)
+    bias = rnd("skl.b", (N,))
+    xn = torch.nn.functional.layer_norm(x.double(), (K,), None, None, 1e-5).to(torch.bfloat16)
+    ref = xn.double() @ w.double().T + bias.double()
+    if gelu:
+        ref = 0.5 * ref * (1 + torch.tanh(0.7978845608028654 * (ref + 0.044715 * ref ** 3)))
+    xd, wd, bd = x.to(DEV), w.to(DEV), bias.to(DEV)
+    if tiledw:
+        wt = torch.empty((N + 15) // 16 * 16 * K, dtype=torch.bfloat16, device=DEV)
+        L.check(lib.itts_retile_weights(wt.data_ptr(), wd.data_ptr(), N, K, stream()))
+        wd = wt
+    y = torch.empty(16 * N, dtype=torch.bfloat16, device=DEV) if ybf else torch.empty(B, N, device=DEV)
+    act = L.ACT_GELU_NEW if gelu else L.ACT_NONE
+    L.check(lib.itts_skinny_gemm(y.data_ptr(), ybf, xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), B, N, K, act, 0, 1, None,
+                                 8 | (4 if tiledw else 0), stream()))
+    torch.cuda.synchronize()
+    got = y.cpu()[:B * N].view(B, N).float() if ybf else y.cpu()
+    # a bf16 rounding of LN(x) may land on the neighbouring value where the moments differ in the last ulp
+    assert relerr(got, ref.float()) < (1e-2 if ybf else 2e-3)
+    # a row does not depend on the rest of the batch
+    y1 = torch.empty_like(y)
+    r = B // 2
+    L.check(lib.itts_skinny_gemm(y1.data_ptr(), ybf, xd[r:r + 1].contiguous().data_ptr(), wd.data_ptr(), bd.data_ptr(), 1, N, K, act, 0,
+                                 1, None, 8 | (4 if tiledw else 0), stream()))
+    torch.cuda.synchronize()
+    assert torch.equal(y1.cpu().view(-1)[:N], y.cpu().view(-1)[r * N:(r + 1) * N])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tiledw", [0, 1])
+@pytest.mark.parametrize("case", [(6, 1280, 5120), (16, 1280, 1280), (11, 72, 96)])
+def test_skinny_gemm_half_tiles_accumulate(lib, case, tiledw):
+    """5-16 decode rows: the residual projections as 8-feature workgroups, no K split, accumulating into the fp32 stream:
+    the same bits as the whole-tile form."""
+    B, N, K = case
+    x = (rnd("skh.x", (B, K)) * 1.5).to(torch.bfloat16)
+    w = (rnd("skh.w", (N, K)) * 0.05).to(torch.bfloat16)
+    bias = rnd("skh.b", (N,))
+    y0 = rnd("skh.y", (B, N))
+    ref = x.double() @ w.double().T + bias.double() + y0.double()
+    xd, wd, bd = to_tiles(x, 1).to(DEV), w.to(DEV), bias.to(DEV)
+    if tiledw:
+        wt = torch.empty((N + 15) // 16 * 16 * K, dtype=torch.bfloat16, device=DEV)
+        L.check(lib.itts_retile_weights(wt.data_ptr(), wd.data_ptr(), N, K, stream()))
+        wd = wt
+    lay = 1 | (4 if tiledw else 0)
+    ya, yb = y0.to(DEV).clone(), y0.to(DEV).clone()
+    L.check(lib.itts_skinny_gemm(ya.data_ptr(), 0, xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), B, N, K, L.ACT_NONE, 1, 1, None,
+                                 lay | 16, stream()))
+    L.check(lib.itts_skinny_gemm(yb.data_ptr(), 0, xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), B, N, K, L.ACT_NONE, 1, 1, None,
+                                 lay, stream()))
+    torch.cuda.synchronize()
+    assert relerr(ya.cpu(), ref.float()) < 2e-5
+    assert torch.equal(ya.cpu(), yb.cpu())
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("passes", [1, 2])
 def test_ln_rows_bf16(lib, passes):
     rows, D = 37, 1280
