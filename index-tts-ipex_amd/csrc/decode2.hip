@@ -1914,6 +1914,7 @@ int gemv_bf16(const GemvArgs& g, hipStream_t s) {
   ITTS_REQUIRE(!(g.accumulate && g.y_bf16), "gemv_bf16: accumulate needs an fp32 output");
   if (g.B == 1) return dispatch_gemv_bf16<1>(g, s);
   if (g.B == 2) return dispatch_gemv_bf16<2>(g, s);
+  if (g.B == 3) return dispatch_gemv_bf16<3>(g, s);  // one sentence x 3 beams, the reference's default generate() mode
   return dispatch_gemv_bf16<4>(g, s);
 }
 
