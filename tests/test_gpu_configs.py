@@ -140,3 +140,41 @@ def test_config5_longform_fp8_weights_batched_and_sequential(mel, accuracy):
     accuracy["config5_fp8_batched20_vs_sequential_first_logits_rel_rms"] = worst
     accuracy["config5_fp8_batched20_vs_sequential_ids_agree_steps"] = agree
     assert worst < 3e-2, worst
+
+
+def test_rows_5_to_16_layernorm_in_projection_and_half_tiles(mel, accuracy):
+    """The reference's default mode decodes 3 beams per sentence, 2-4 sentences per bucket: 6-12 rows.  At 5-16 rows the
+    engine folds the LayerNorms into c_attn / c_fc and runs the residual projections as half tiles (decode_mfma.hip
+    LNP / HALF), on the fragment-tiled weight copies.
+    (a) a row's codes and logits do not depend on how many other rows share the batch (5, 9 or 16 rows: bit-identical);
+    (b) fp8 weights (config 5's format) give the bits of their bf16 dequantisation on this path too;
+    (c) against the 2-row GEMV path the first-step logits agree within the bf16 tolerance of the two kernel families."""
+    texts = np.stack([synth.text_ids(105, 700 + i, CFG.gpt.number_text_tokens) for i in range(16)]).astype(np.int32)
+    n = 20
+    eng = ieng.build_engine(CFG, "bf16", parts=("gpt",), max_batch=16)
+    cond = eng.conditioning(mel)
+    out = {}
+    for rows in (16, 9, 5, 2):
+        eng.prefill(cond, texts[:rows], n, 10.0, True)
+        first = eng.fetch(logits=True)[1].copy()
+        eng.decode(n - 1)
+        codes, lg = eng.fetch(logits=True)
+        out[rows] = (codes.copy(), lg.copy(), first)
+        eng._exit()
+    for rows in (9, 5):
+        assert np.array_equal(out[rows][0], out[16][0][:rows]) and np.array_equal(out[rows][1], out[16][1][:rows]), rows
+    worst = max(rms_rel(out[16][2][i], out[2][2][i]) for i in range(2))
+    accuracy["bf16_rows16_vs_rows2_first_logits_rel_rms"] = worst
+    assert worst < 3e-2, worst
+    del eng
+    torch.cuda.empty_cache()
+    res = {}
+    for mode in ("fp8", "dequant"):
+        e8 = ieng.build_engine(CFG, "bf16", parts=("gpt",), gpt_fp8=mode, max_batch=16)
+        e8.prefill(cond, texts[:8], n, 10.0, True)
+        e8.decode(n - 1)
+        res[mode] = e8.fetch(logits=True)
+        e8._exit()
+        del e8
+        torch.cuda.empty_cache()
+    assert np.array_equal(res["fp8"][0], res["dequant"][0]) and np.array_equal(res["fp8"][1], res["dequant"][1])
