@@ -48,6 +48,9 @@ def parse():
     ap.add_argument("--micro", action="store_true", help="tiny config (plumbing check)")
     ap.add_argument("--gpt-fp8", action="store_true",
                     help="BASELINE config 5 storage: GPT projections as fp8 e4m3 + row scales for the decode GEMV (bf16 activations / KV)")
+    ap.add_argument("--beams", type=int, default=1,
+                    help="HF beam-sample with this many beams per sentence (the reference's default generate() mode is 3: top_k 30, "
+                         "top_p 0.8, temperature 1.0) instead of greedy; decode rows = sentences x beams")
     ap.add_argument("--no-graph", action="store_true", help="eager decode launches (for rocprofv3 --pmc passes)")
     ap.add_argument("--no-also", action="store_true", help="skip the secondary BASELINE config 3 measurement of the default run")
     return ap.parse_args()
@@ -179,6 +182,7 @@ def measure(eng, cfg, a, BU, steps, warmup, rank, world):
     B = BU * NS
     mel = torch.from_numpy(synth.prompt_mel(a.prompt_frames, seed=7)).to(device)  # resident in HBM
     texts = np.stack([synth.text_ids(L, 11 + u * NS + k, g["number_text_tokens"]) for u in mine for k in range(NS)]).astype(np.int32)
+    beam_uniforms = np.random.default_rng(5).random((T, B, 2 * a.beams), dtype=np.float32) if a.beams > 1 else None
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
     dec_ms, dec_steps = [0.0], [0]
     # per-phase device time (conditioning+ECAPA / prefill+AR decode / latent pass / vocoder), as infer.py:218-220 prints
@@ -193,6 +197,8 @@ def measure(eng, cfg, a, BU, steps, warmup, rank, world):
         spk = eng.ecapa(mel.transpose(1, 2))
         if timed:
             pev[1].record(eng.stream)
+        if a.beams > 1:
+            eng.set_beam_sample(a.beams, 30, 0.8, 1.0, beam_uniforms)
         eng.prefill(cond, texts, T, 10.0, True)
         if timed:
             ev[0].record(eng.stream)  # HIP events on the stream the decode graphs are launched on
@@ -201,6 +207,8 @@ def measure(eng, cfg, a, BU, steps, warmup, rank, world):
             ev[1].record(eng.stream)
         codes = eng.fetch()
         eng._exit()
+        if a.beams > 1:
+            eng.set_beam_sample(1)
         if timed:
             dec_ms[0] += ev[0].elapsed_time(ev[1])
             dec_steps[0] += T - 1
@@ -266,7 +274,7 @@ def measure(eng, cfg, a, BU, steps, warmup, rank, world):
     w_bytes = w_params * esz
     if a.gpt_fp8:  # the decode projections stream the fp8 copy (+ one fp32 scale per output row); biases stay fp32-sized
         w_bytes = NL * 12 * D * D + D * V + 4 * (NL * 9 * D + V) + esz * (NL * 13 * D + 4 * D + V)
-    step_bytes = w_bytes + B * kv_per_pos * s_bar
+    step_bytes = w_bytes + B * a.beams * kv_per_pos * s_bar
     ms_step = dec_ms[0] / max(dec_steps[0], 1)
     achieved = step_bytes / (ms_step * 1e-3) / 1e9
     # HBM traffic of the decode step: the committed rocprofv3 --pmc passes of this command (tools/round_profile.sh runs
@@ -278,7 +286,7 @@ def measure(eng, cfg, a, BU, steps, warmup, rank, world):
         pm = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_decode.json"))
         for f in reversed(pm):
             pj = json.load(open(os.path.join(ROOT, "profiles", f)))
-            if (int(pj.get("decode_rows", -1)) == B and abs(float(pj.get("mean_S", -1)) - s_bar) <= 2.0 and a.dtype == "bf16"
+            if (int(pj.get("decode_rows", -1)) == B * a.beams and abs(float(pj.get("mean_S", -1)) - s_bar) <= 2.0 and a.dtype == "bf16"
                     and not a.micro and not a.gpt_fp8):
                 traffic = int(pj["hbm_bytes_per_step"])
                 traffic_src = (f"profiles/{f}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py --no-graph at this run's "
@@ -290,8 +298,9 @@ def measure(eng, cfg, a, BU, steps, warmup, rank, world):
         "value": round(audio_s / dt, 3), "ms_per_step": round(dt / steps * 1e3, 2), "rtf": round(dt / audio_s, 5),
         "phases_ms_per_step": {k: round(v / steps, 2) for k, v in phase_ms.items()},
         "config": {"workload": ("IndexTTS-1.5, %d utterance(s)/GPU x %d sentences x (L=%d text tokens, T=%d mel codes), "
-                                "prompt %d frames, greedy fixed-length decode, rep_penalty 10" % (BU, NS, L, T, a.prompt_frames)),
-                   "utterances_per_gpu": BU, "decode_batch": B, "audio_sec_per_step_per_gpu": round(audio_s / steps / world, 3)},
+                                "prompt %d frames, %s fixed-length decode, rep_penalty 10" %
+                                (BU, NS, L, T, a.prompt_frames, "greedy" if a.beams == 1 else "beam-sample x%d" % a.beams)),
+                   "utterances_per_gpu": BU, "decode_batch": B * a.beams, "audio_sec_per_step_per_gpu": round(audio_s / steps / world, 3)},
         "roofline": {"bound": "hbm", "kernel": ("gpt decode step (hipGraph: 97 gemv + 24 cache-attention + sampler)" if B <= 4 else
                                                 "gpt decode step (hipGraph: 97 skinny MFMA gemm + 49 layernorm + 24 cache-attention + sampler)"),
                      "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",

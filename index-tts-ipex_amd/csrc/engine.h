@@ -142,6 +142,8 @@ struct DecodeState {
   int* beam_ids = nullptr;           // [2][B][max_gen]
   uint8_t* anc = nullptr;            // [2][B][Smax]
   float* beam_scores = nullptr;      // [B]
+  float* cand_sc = nullptr;          // beam sampler scratch [rows][BEAM_MAX_CAND]
+  int *cand_tok = nullptr, *cand_n = nullptr;
   int *hyp_tok = nullptr, *hyp_len = nullptr, *hyp_order = nullptr, *hyp_n = nullptr, *hyp_counter = nullptr, *beam_done = nullptr;
   float *hyp_score = nullptr, *hyp_worst = nullptr;
   size_t beam_cap = 0;               // bytes-independent capacity key: rows * max_gen * Smax the beam buffers were sized for

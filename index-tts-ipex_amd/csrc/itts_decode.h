@@ -108,7 +108,12 @@ struct BeamArgs {
   int preprocessed = 0;  // logits already went through typical_filter (log_softmax, penalty, stop suppression done)
   int do_sample = 1;     // 1: beam_sample (warpers + draws from uniforms); 0: beam_search (top 2 * nb, no warpers)
   float length_penalty = 0.f;  // BeamHypotheses score = sum_logprobs / generated_len ** length_penalty
+  // scratch between the two launches of a step: every beam's kept candidates (token-ascending, beam score included)
+  float* cand_sc = nullptr;  // [B * nb][BEAM_MAX_CAND]
+  int* cand_tok = nullptr;   // [B * nb][BEAM_MAX_CAND]
+  int* cand_n = nullptr;     // [B * nb]
 };
+constexpr int BEAM_MAX_CAND = 128;
 int beam_sample_step(const BeamArgs& a, hipStream_t s);
 
 // TypicalLogitsWarper pre-pass (beam.hip): processed scores of every row -> out [rows, V] with the filtered ones at -inf

@@ -232,6 +232,9 @@ int Engine::ensure_beam_state(int rows, int max_gen, int Smax, hipStream_t s) {
   ITTS_TRY(dev_alloc((void**)&d.beam_ids, (size_t)2 * r * g * 4));
   ITTS_TRY(dev_alloc((void**)&d.anc, (size_t)2 * r * sm));
   ITTS_TRY(dev_alloc((void**)&d.beam_scores, (size_t)r * 4));
+  ITTS_TRY(dev_alloc((void**)&d.cand_sc, (size_t)r * BEAM_MAX_CAND * 4));
+  ITTS_TRY(dev_alloc((void**)&d.cand_tok, (size_t)r * BEAM_MAX_CAND * 4));
+  ITTS_TRY(dev_alloc((void**)&d.cand_n, (size_t)r * 4));
   ITTS_TRY(dev_alloc((void**)&d.hyp_tok, (size_t)r * 2 * g * 4));  // [B][nb + 1][g] <= rows * 2 * g
   ITTS_TRY(dev_alloc((void**)&d.hyp_score, (size_t)r * 2 * 4));
   ITTS_TRY(dev_alloc((void**)&d.hyp_len, (size_t)r * 2 * 4));
@@ -546,6 +549,9 @@ int Engine::head_and_sample(hipStream_t s) {
     ba.preprocessed = typical;
     ba.do_sample = ds.beam_sample;
     ba.length_penalty = ds.length_penalty;
+    ba.cand_sc = ds.cand_sc;
+    ba.cand_tok = ds.cand_tok;
+    ba.cand_n = ds.cand_n;
     ba.V = V;
     ba.max_gen = ds.max_gen;
     ba.stop = c.stop_mel_token;
