@@ -51,6 +51,7 @@ def parse():
     ap.add_argument("--beams", type=int, default=1,
                     help="HF beam-sample with this many beams per sentence (the reference's default generate() mode is 3: top_k 30, "
                          "top_p 0.8, temperature 1.0) instead of greedy; decode rows = sentences x beams")
+    ap.add_argument("--sample", action="store_true", help="HF sample() (top_k 30, top_p 0.8, temperature 1.0, one beam) instead of greedy")
     ap.add_argument("--no-graph", action="store_true", help="eager decode launches (for rocprofv3 --pmc passes)")
     ap.add_argument("--no-also", action="store_true", help="skip the secondary BASELINE config 3 measurement of the default run")
     return ap.parse_args()
@@ -183,6 +184,7 @@ def measure(eng, cfg, a, BU, steps, warmup, rank, world):
     mel = torch.from_numpy(synth.prompt_mel(a.prompt_frames, seed=7)).to(device)  # resident in HBM
     texts = np.stack([synth.text_ids(L, 11 + u * NS + k, g["number_text_tokens"]) for u in mine for k in range(NS)]).astype(np.int32)
     beam_uniforms = np.random.default_rng(5).random((T, B, 2 * a.beams), dtype=np.float32) if a.beams > 1 else None
+    sample_uniforms = np.random.default_rng(6).random((T, B), dtype=np.float32) if a.sample else None
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
     dec_ms, dec_steps = [0.0], [0]
     # per-phase device time (conditioning+ECAPA / prefill+AR decode / latent pass / vocoder), as infer.py:218-220 prints
@@ -199,6 +201,8 @@ def measure(eng, cfg, a, BU, steps, warmup, rank, world):
             pev[1].record(eng.stream)
         if a.beams > 1:
             eng.set_beam_sample(a.beams, 30, 0.8, 1.0, beam_uniforms)
+        elif a.sample:
+            eng.set_sampling(True, 30, 0.8, 1.0, sample_uniforms)
         eng.prefill(cond, texts, T, 10.0, True)
         if timed:
             ev[0].record(eng.stream)  # HIP events on the stream the decode graphs are launched on
@@ -209,6 +213,8 @@ def measure(eng, cfg, a, BU, steps, warmup, rank, world):
         eng._exit()
         if a.beams > 1:
             eng.set_beam_sample(1)
+        elif a.sample:
+            eng.set_sampling(False)
         if timed:
             dec_ms[0] += ev[0].elapsed_time(ev[1])
             dec_steps[0] += T - 1
@@ -299,7 +305,7 @@ def measure(eng, cfg, a, BU, steps, warmup, rank, world):
         "phases_ms_per_step": {k: round(v / steps, 2) for k, v in phase_ms.items()},
         "config": {"workload": ("IndexTTS-1.5, %d utterance(s)/GPU x %d sentences x (L=%d text tokens, T=%d mel codes), "
                                 "prompt %d frames, %s fixed-length decode, rep_penalty 10" %
-                                (BU, NS, L, T, a.prompt_frames, "greedy" if a.beams == 1 else "beam-sample x%d" % a.beams)),
+                                (BU, NS, L, T, a.prompt_frames, ("sample" if a.sample else "greedy") if a.beams == 1 else "beam-sample x%d" % a.beams)),
                    "utterances_per_gpu": BU, "decode_batch": B * a.beams, "audio_sec_per_step_per_gpu": round(audio_s / steps / world, 3)},
         "roofline": {"bound": "hbm", "kernel": ("gpt decode step (hipGraph: 97 gemv + 24 cache-attention + sampler)" if B <= 4 else
                                                 "gpt decode step (hipGraph: 97 skinny MFMA gemm + 49 layernorm + 24 cache-attention + sampler)"),

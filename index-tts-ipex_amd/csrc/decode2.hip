@@ -1637,6 +1637,22 @@ __device__ __forceinline__ unsigned order_key(float v) {
 
 constexpr int SMAXC = 128;  // kept candidates (top_k <= 128: the reference web UI offers 0..100)
 
+// value of lane l (wave-uniform l) in every lane: v_readlane_b32, no LDS crossbar round trip
+__device__ __forceinline__ float lane_val(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
+
+// histogram increment aggregated over the wave (as beam.hip): the digits of scores crowd into a few bins and 64 lanes
+// adding to one LDS word serialise; each distinct digit of the wave costs one atomic.  Every lane of the wave calls it.
+__device__ __forceinline__ void hist_add_wave(unsigned* hist, unsigned digit, bool act, int lane) {
+  unsigned long long m = __ballot(act);
+  while (m) {  // wave-uniform
+    const int leader = __ffsll((long long)m) - 1;
+    const unsigned dl = (unsigned)__shfl((int)digit, leader, 64);
+    const unsigned long long same = __ballot(act && digit == dl);
+    if (lane == leader) atomicAdd(&hist[dl], (unsigned)__popcll(same));
+    m &= ~same;
+  }
+}
+
 __global__ __launch_bounds__(1024) void sampler_sample_kernel(SamplerArgs a) {
   extern __shared__ float ssc[];  // [V] processed scores
   __shared__ unsigned hist[256];
@@ -1644,7 +1660,6 @@ __global__ __launch_bounds__(1024) void sampler_sample_kernel(SamplerArgs a) {
   __shared__ float cval[SMAXC];
   __shared__ int cidx[SMAXC];
   __shared__ int si[2];
-  __shared__ float ce[SMAXC];
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
   const float* __restrict__ lg = a.logits + (size_t)b * a.V;
   const uint8_t* seen = a.seen + (size_t)b * a.V;
@@ -1665,9 +1680,11 @@ __global__ __launch_bounds__(1024) void sampler_sample_kernel(SamplerArgs a) {
     const int shift = pass * 8;
     if (tid < 256) hist[tid] = 0;
     __syncthreads();
-    for (int i = tid; i < a.V; i += 1024) {
-      const unsigned key = order_key(ssc[i]);
-      if (pass == 3 || (key >> (shift + 8)) == (prefix >> (shift + 8))) atomicAdd(&hist[(key >> shift) & 255u], 1u);
+    for (int i0 = 0; i0 < a.V; i0 += 1024) {  // every lane takes part in every round (wave-aggregated atomics)
+      const int i = i0 + tid;
+      const unsigned key = i < a.V ? order_key(ssc[i]) : 0u;
+      const bool act = i < a.V && (pass == 3 || (key >> (shift + 8)) == (prefix >> (shift + 8)));
+      hist_add_wave(hist, (key >> shift) & 255u, act, lane);
     }
     __syncthreads();
     if (tid < 64) {
@@ -1719,11 +1736,13 @@ __global__ __launch_bounds__(1024) void sampler_sample_kernel(SamplerArgs a) {
     }
   }
   __syncthreads();
-  // bitonic sort in LDS by the whole block: descending score, ascending index on ties
-  for (int kq = 2; kq <= SMAXC; kq <<= 1)
-    for (int j = kq >> 1; j > 0; j >>= 1) {
-      if (tid < SMAXC / 2) {
-        const int lo = ((tid & ~(j - 1)) << 1) | (tid & (j - 1)), hi = lo | j;
+  // bitonic sort in LDS by ONE wave (64 lanes = the SMAXC / 2 comparators of a stage; a wave's LDS operations execute in
+  // program order, so the 28 stages need no workgroup barrier): descending score, ascending index on ties
+  static_assert(SMAXC == 128, "one comparator per lane");
+  if (tid < 64) {
+    for (int kq = 2; kq <= SMAXC; kq <<= 1)
+      for (int j = kq >> 1; j > 0; j >>= 1) {
+        const int lo = ((lane & ~(j - 1)) << 1) | (lane & (j - 1)), hi = lo | j;
         const bool up = (lo & kq) == 0;
         const float v0 = cval[lo], v1 = cval[hi];
         const int i0 = cidx[lo], i1 = cidx[hi];
@@ -1734,25 +1753,27 @@ __global__ __launch_bounds__(1024) void sampler_sample_kernel(SamplerArgs a) {
           cidx[lo] = i1;
           cidx[hi] = i0;
         }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
       }
-      __syncthreads();
-    }
-  if (tid == 0) {
+  }
+  __syncthreads();
+  if (tid < 64) {
+    // wave 0: the exponentials and quotients in parallel (lane r and r + 64 of the sorted candidates), the running sums
+    // sequentially in the restatement's order, every lane carrying them (values broadcast lane by lane)
     const int n = min(s_cnt, SMAXC);
     const float m = cval[0];
-    float* e = ce;
+    const float e0 = lane < n ? expf(cval[lane] - m) : 0.f, e1 = lane + 64 < n ? expf(cval[lane + 64] - m) : 0.f;
+    auto ev = [&](int r) { return r < 64 ? lane_val(e0, r) : lane_val(e1, r - 64); };
     float Z = 0.f;
-    for (int r = 0; r < n; ++r) {
-      e[r] = expf(cval[r] - m);
-      Z += e[r];
-    }
+    for (int r = 0; r < n; ++r) Z += ev(r);
     int R = n;
     if (a.top_p < 1.f) {
       // TopPLogitsWarper: ascending cumulative probability <= 1 - top_p is removed; the best token always stays
+      const float t0 = e0 / Z, t1 = e1 / Z;
       float tail = 0.f;
       R = 1;
       for (int r = n - 1; r >= 1; --r) {
-        tail += e[r] / Z;
+        tail += r < 64 ? lane_val(t0, r) : lane_val(t1, r - 64);
         if (!(tail <= 1.f - a.top_p)) {
           R = r + 1;
           break;
@@ -1760,20 +1781,20 @@ __global__ __launch_bounds__(1024) void sampler_sample_kernel(SamplerArgs a) {
       }
     }
     float total = 0.f;
-    for (int r = 0; r < R; ++r) total += e[r];
+    for (int r = 0; r < R; ++r) total += ev(r);
     const int k = k_pre;
     const float u = a.uniforms[(size_t)min(k, a.max_gen - 1) * a.B + b];
     const float target = u * total;
     int pick = R - 1;
     float c = 0.f;
     for (int r = 0; r < R; ++r) {
-      c += e[r];
+      c += ev(r);
       if (c >= target) {
         pick = r;
         break;
       }
     }
-    sampler_commit(a, b, cidx[pick], si, k_pre, unf_pre);
+    if (lane == 0) sampler_commit(a, b, cidx[pick], si, k_pre, unf_pre);
   }
   __syncthreads();
   sampler_next_embedding(a, b, si, tid);
