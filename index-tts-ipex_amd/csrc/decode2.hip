@@ -1490,7 +1490,7 @@ struct FusedQkvAttn {
   int* err;
   bf16_t *kc, *vc;
   const int *len, *kv_start, *prefix;  // prefix[0] = prefix length, prefix[1] = generation epoch
-  int H, B, Smax, n_gemv, nb, sleep0, sleep1, attn_first;
+  int H, B, Smax, n_gemv, nb, sleep0, sleep1;
   float scale;
   float *part_o, *part_ml;
   const uint8_t* anc;
@@ -1498,13 +1498,13 @@ struct FusedQkvAttn {
 
 template <int NB, int RPW, int NCH, bool ANC>
 __global__ __launch_bounds__(256) void qkv_attn_fused_kernel(FusedQkvAttn f) {
-  const int n_attn = f.H * f.B * ATTN_NSPLIT;
-  const int gblk = f.attn_first ? (int)blockIdx.x - n_attn : (int)blockIdx.x;  // projection block id (negative: attention)
-  if (gblk >= 0 && gblk < f.n_gemv) {
-    fused_gemv_part<NB, RPW, NCH>(f.g, gblk, f.gran, f.len, f.prefix);
+  // projection workgroups first (dispatching the attention workgroups first was measured worse: they occupy the CUs the
+  // projection needs)
+  if ((int)blockIdx.x < f.n_gemv) {
+    fused_gemv_part<NB, RPW, NCH>(f.g, blockIdx.x, f.gran, f.len, f.prefix);
   } else {
     const unsigned tag = ((unsigned)f.prefix[1] << 12) | (unsigned)(f.len[0] + 1);
-    const int idx = f.attn_first ? (int)blockIdx.x : (int)blockIdx.x - f.n_gemv;
+    const int idx = (int)blockIdx.x - f.n_gemv;
     const int h = idx % f.H, b = (idx / f.H) % f.B, sp = idx / (f.H * f.B);
     fused_attn_part<ANC>(f.gran, tag, f.err, f.kc, f.vc, f.len, f.kv_start, f.prefix, f.H, f.B, f.Smax, f.scale, f.part_o,
                          f.part_ml, f.anc, f.nb, h, b, sp, f.sleep0, f.sleep1);
@@ -2025,10 +2025,8 @@ int qkv_attn_fused(const GemvArgs& g, unsigned long long* gran, int* err, void* 
   f.anc = anc;
   static const int e_s0 = getenv("ITTS_FUSE_SLEEP0") ? atoi(getenv("ITTS_FUSE_SLEEP0")) : 24;  // x 256 clocks before the first poll (best of tools/fuse_sweep.sh)
   static const int e_s1 = getenv("ITTS_FUSE_SLEEP1") ? atoi(getenv("ITTS_FUSE_SLEEP1")) : 4;   // x 64 clocks between sweeps
-  static const int e_af = getenv("ITTS_FUSE_ATTN_FIRST") ? atoi(getenv("ITTS_FUSE_ATTN_FIRST")) : 0;
   f.sleep0 = e_s0;
   f.sleep1 = e_s1;
-  f.attn_first = e_af;
   const dim3 grid(f.n_gemv + H * g.B * ATTN_NSPLIT), blk(256);
   const size_t lds = (size_t)(g.B <= 2 ? g.B : 4) * g.K * 2;
 #define FUSED_GO(NB, RPW, NCH)                                                                            \
