@@ -709,7 +709,16 @@ template <typename TC> struct CacheVec;
 template <> struct CacheVec<bf16_t> {
   static constexpr int VEC = 8, LPK = 8;
   uint4 raw;
+#ifdef ITTS_KV_PLAIN_LOADS
   __device__ __forceinline__ void load(const bf16_t* p) { raw = *reinterpret_cast<const uint4*>(p); }
+#else
+  // the cache is read once per step and never again before it has left every cache: nontemporal (streaming) loads
+  __device__ __forceinline__ void load(const bf16_t* p) {
+    typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+    const v4u t = __builtin_nontemporal_load(reinterpret_cast<const v4u*>(p));
+    raw = make_uint4(t[0], t[1], t[2], t[3]);
+  }
+#endif
   __device__ __forceinline__ float get(int i) const {
     const uint32_t w = (&raw.x)[i >> 1];
     return __uint_as_float((i & 1) ? (w & 0xFFFF0000u) : (w << 16));
