@@ -94,18 +94,22 @@ __global__ __launch_bounds__(512) void skinny_mfma_kernel(GemvArgs g) {
   // epilogue operands (bias of the outputs this thread will finish) requested up front: the tail then has no
   // dependent memory latency
   constexpr int EPT = (NT * BT * 256 + 511) / 512;
-  float bpre[EPT], spre[EPT], ypre[EPT];
+  float bpre[EPT], spre[EPT], ypre[HALF ? EPT : 1];
   {
     const float* bp = g.bias ? g.bias : (W8 ? g.wscale : reinterpret_cast<const float*>(W));  // any readable address without a bias
-    const bool rmw = g.accumulate && S == 1 && !g.y_bf16;  // the residual-stream value this thread will add into
+    const bool rmw = HALF && g.accumulate && !g.y_bf16;  // the residual-stream value this thread will add into (HALF: the
+                                                         // launch-bound <= 16-row form, where the late read-modify-write
+                                                         // of the epilogue is 1.5 us of dependent latency)
 #pragma unroll
     for (int it = 0; it < EPT; ++it) {
       const int idx = tid + it * 512, tb = idx >> 8, t = tb / BT, bt = tb - t * BT, e = idx & 255;
       const int nn = min(n0 + t * 16 + (idx & 15), g.N - 1);
       bpre[it] = bp[nn];
       spre[it] = W8 ? g.wscale[nn] : 1.f;
-      const int bb = min(bt * 16 + ((e & 63) >> 4) * 4 + (e >> 6), g.B - 1);
-      ypre[it] = rmw ? g.Y[(size_t)bb * g.ldy + nn] : 0.f;
+      if constexpr (HALF) {
+        const int bb = min(bt * 16 + ((e & 63) >> 4) * 4 + (e >> 6), g.B - 1);
+        ypre[it] = rmw ? g.Y[(size_t)bb * g.ldy + nn] : 0.f;
+      }
     }
   }
   // LNP: every wave passes through the body exactly once (nks <= SW * SU, host-checked), also one without a k-step of its
@@ -224,7 +228,7 @@ __global__ __launch_bounds__(512) void skinny_mfma_kernel(GemvArgs g) {
     if (g.y_bf16)
       reinterpret_cast<bf16_t*>(g.Y)[g.y_tiled ? tile_off(b, n, btr) : o] = (bf16_t)v;
     else if (g.accumulate)
-      g.Y[o] = ypre[it] + v;
+      g.Y[o] = (HALF ? ypre[HALF ? it : 0] : g.Y[o]) + v;
     else
       g.Y[o] = v;
   }
