@@ -279,3 +279,21 @@ def test_full_beam_search_bf16_six_rows_track_three_rows(eng16, mel, accuracy):
                 worst = max(worst, rms_rel(both[k][i * nb + r], one[k][r]))
     accuracy["bf16_beam_search_6rows_vs_3rows_logits_rel_rms"] = worst
     assert worst < 3e-2, worst
+
+
+def test_full_beam_sample_bf16_graph_replay_equals_eager_12_rows(eng16, mel):
+    """4 sentences x 3 beams (12 rows: two-launch beam sampler with its candidate scratch, ancestry attention, the
+    LayerNorm-in-projection kernels): the captured graph replays give the ids of eager launches, twice in a row on one
+    engine (the scratch and ping-pong buffers carry nothing over)."""
+    cond = eng16.conditioning(mel)
+    text = np.stack([synth.text_ids(105, 80 + i, CFG.gpt.number_text_tokens) for i in range(4)]).astype(np.int32)
+    n, nb = 24, 3
+    u = np.random.default_rng(3).random((n, 4, 2 * nb), dtype=np.float32)
+    kw = dict(do_sample=True, num_beams=nb, top_k=30, top_p=0.8, temperature=1.0, uniforms=u, suppress_stop=True)
+    res = []
+    for no_graph in (False, True, False):
+        eng16.debug(no_graph=no_graph)
+        res.append(eng16.generate(cond, text, n, **kw))
+    eng16.debug()
+    assert res[0].shape == (4, n)
+    assert np.array_equal(res[0], res[1]) and np.array_equal(res[0], res[2])
