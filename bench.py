@@ -53,7 +53,10 @@ def parse():
                          "top_p 0.8, temperature 1.0) instead of greedy; decode rows = sentences x beams")
     ap.add_argument("--sample", action="store_true", help="HF sample() (top_k 30, top_p 0.8, temperature 1.0, one beam) instead of greedy")
     ap.add_argument("--no-graph", action="store_true", help="eager decode launches (for rocprofv3 --pmc passes)")
-    ap.add_argument("--no-also", action="store_true", help="skip the secondary BASELINE config 3 measurement of the default run")
+    ap.add_argument("--no-also", action="store_true", help="skip the secondary measurements of the default run (BASELINE config 3 / 4, product loop)")
+    ap.add_argument("--eos", action="store_true",
+                    help="decode with the product loop of Engine.generate: a status() read-back (stream sync + D2H of the unfinished "
+                         "flags) every 16 steps, as with eos enabled; the stop token stays suppressed so the work is the same")
     return ap.parse_args()
 
 
@@ -87,7 +90,11 @@ def build_engine_dp(cfg, dtype, device, gpt_fp8=False, max_batch=128):
         p = pack.pack_gpt(synth.gpt_state_dict(cfg, 1234), cfg)
         return pack.quantize_gpt_fp8(p) if gpt_fp8 else p
 
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
     dp.replicate_packed(eng, [gpt_packed, lambda: pack.pack_bigvgan(synth.bigvgan_state_dict(cfg, 1234), cfg)])
+    torch.cuda.synchronize()
+    eng.replicate_s = time.perf_counter() - t0  # rank 0: synthesis + packing + broadcast; other ranks: wait + broadcast
     eng.finalize()
     return eng
 
@@ -167,7 +174,7 @@ def cpu_baseline(cfg, a):
     }
 
 
-def measure(eng, cfg, a, BU, steps, warmup, rank, world):
+def measure(eng, cfg, a, BU, steps, warmup, rank, world, product_loop=False):
     """Time `steps` passes of the hot path over this rank's shard (BU utterances per GPU, weak scaling) and return the
     aggregated numbers.  The global utterance list (world * BU equal-length utterances) is dealt by dp.partition; the
     data path has no collective."""
@@ -206,7 +213,15 @@ def measure(eng, cfg, a, BU, steps, warmup, rank, world):
         eng.prefill(cond, texts, T, 10.0, True)
         if timed:
             ev[0].record(eng.stream)  # HIP events on the stream the decode graphs are launched on
-        eng.decode(T - 1)
+        if product_loop:  # Engine.generate's loop with eos enabled: status() (sync + D2H) in front of every 16 steps
+            done = 1
+            while done < T:
+                eng.status()
+                n = min(16, T - done)
+                eng.decode(n)
+                done += n
+        else:
+            eng.decode(T - 1)
         if timed:
             ev[1].record(eng.stream)
         codes = eng.fetch()
@@ -305,7 +320,8 @@ def measure(eng, cfg, a, BU, steps, warmup, rank, world):
         "phases_ms_per_step": {k: round(v / steps, 2) for k, v in phase_ms.items()},
         "config": {"workload": ("IndexTTS-1.5, %d utterance(s)/GPU x %d sentences x (L=%d text tokens, T=%d mel codes), "
                                 "prompt %d frames, %s fixed-length decode, rep_penalty 10" %
-                                (BU, NS, L, T, a.prompt_frames, ("sample" if a.sample else "greedy") if a.beams == 1 else "beam-sample x%d" % a.beams)),
+                                (BU, NS, L, T, a.prompt_frames, ("sample" if a.sample else "greedy") if a.beams == 1 else "beam-sample x%d" % a.beams)
+                                + (", product loop (status() every 16 steps)" if product_loop else "")),
                    "utterances_per_gpu": BU, "decode_batch": B * a.beams, "audio_sec_per_step_per_gpu": round(audio_s / steps / world, 3)},
         "roofline": {"bound": "hbm", "kernel": ("gpt decode step (hipGraph: 97 gemv + 24 cache-attention + sampler)" if B <= 4 else
                                                 "gpt decode step (hipGraph: 97 skinny MFMA gemm + 49 layernorm + 24 cache-attention + sampler)"),
@@ -333,6 +349,9 @@ def main():
         backend = os.environ.get("ITTS_DIST_BACKEND", "nccl")  # "gloo": rehearse N ranks on a one-GPU box
         if backend != "nccl":
             local = local % max(torch.cuda.device_count(), 1)
+            # ranks SHARE a GPU in this rehearsal mode: the persistent decode engine needs all 256 CUs of a device for its
+            # one process (two co-running persistent grids could starve each other until their bounded waits give up)
+            os.environ["ITTS_ENGINE"] = "0"
         torch.cuda.set_device(local)
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
@@ -349,7 +368,7 @@ def main():
     eng = build_engine_dp(cfg, a.dtype, device, a.gpt_fp8)
     if a.no_graph:
         eng.debug(no_graph=True)
-    m = measure(eng, cfg, a, a.batch, a.steps, a.warmup, rank, world)
+    m = measure(eng, cfg, a, a.batch, a.steps, a.warmup, rank, world, product_loop=a.eos)
     out = {
         "metric": "audio_sec_per_sec", "value": m["value"], "unit": "audio-s/s", "n_gpus": world,
         "steps": a.steps, "warmup": a.warmup, "ms_per_step": m["ms_per_step"], "higher_is_better": True,
@@ -357,18 +376,37 @@ def main():
         "dtype": ("fp8-e4m3 gpt weights (decode), bf16 activations/KV" if a.gpt_fp8 else a.dtype), "data": "synthetic",
         "rtf": m["rtf"], "phases_ms_per_step": m["phases_ms_per_step"], "config": m["config"], "roofline": m["roofline"],
     }
-    # the default single-GPU run also measures BASELINE config 3 (32 utterances per GPU = 64 decode rows) next to the
-    # headline line, so the driver's BENCH file carries both; never allowed to break the headline
-    if world == 1 and a.batch == 1 and not (a.micro or a.no_also or a.no_graph or a.gpt_fp8) and a.dtype == "bf16":
+    if world > 1:
+        import torch.distributed as dist
+
+        out["dist"] = {"backend": dist.get_backend(), "world_size": dist.get_world_size(),
+                       "weights_replicate_s": round(getattr(eng, "replicate_s", 0.0), 3),
+                       "collectives_in_timed_region": 0}
+    # the default run also measures, next to the headline line (the same per-GPU workload at every N, so the driver's
+    # scaling curve compares like with like): 32 utterances per GPU = 64 decode rows - BASELINE config 3 at one GPU, BASELINE
+    # config 4 (N x 32 utterances sharded data-parallel) at N GPUs - and, at one GPU, the product loop of Engine.generate
+    # (status() read-back every 16 steps).  Never allowed to break the headline.
+    if a.batch == 1 and not (a.no_also or a.no_graph or a.gpt_fp8 or a.eos) and a.dtype == "bf16" and a.beams == 1 and not a.sample:
+        also = {}
+        key = "config3_batch32" if world == 1 else "config4_batch32_per_gpu"
         try:
             m3 = measure(eng, cfg, a, 32, 2, 1, rank, world)
-            out["also"] = {"config3_batch32": {"value": m3["value"], "unit": "audio-s/s", "steps": 2, "warmup": 1,
-                                               "ms_per_step": m3["ms_per_step"], "phases_ms_per_step": m3["phases_ms_per_step"],
-                                               "config": m3["config"], "roofline": m3["roofline"]}}
+            also[key] = {"value": m3["value"], "unit": "audio-s/s", "n_gpus": world, "steps": 2, "warmup": 1,
+                         "ms_per_step": m3["ms_per_step"], "phases_ms_per_step": m3["phases_ms_per_step"],
+                         "config": m3["config"], "roofline": m3["roofline"]}
         except Exception as e:  # noqa: BLE001
-            out["also"] = {"config3_batch32": {"error": repr(e)[:200]}}
+            also[key] = {"error": repr(e)[:200]}
+        if world == 1:
+            try:
+                mp = measure(eng, cfg, a, a.batch, max(2, min(a.steps, 5)), 1, rank, world, product_loop=True)
+                also["product_loop"] = {"value": mp["value"], "unit": "audio-s/s", "ms_per_step": mp["ms_per_step"],
+                                        "vs_headline": round(mp["value"] / max(m["value"], 1e-9), 4), "config": mp["config"],
+                                        "decode_ms_per_token_step": mp["roofline"]["avg_launch_ms"]}
+            except Exception as e:  # noqa: BLE001
+                also["product_loop"] = {"error": repr(e)[:200]}
+        out["also"] = also
     if rank == 0:
-        if not a.no_cpu_baseline and world == 1:
+        if not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, a)
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -259,6 +259,8 @@ int itts_debug_enable(itts_engine* e, int on) {
   e->e.force_simple = (on & 2) != 0;
   e->e.use_graph = (on & 4) == 0;
   e->e.ds.fuse = (on & 8) != 0;  // bit 3: the fused projection + attention launch instead of two launches (A/B, parity tests)
+  e->e.ds.eng_off = (on & 16) != 0;  // bit 4: the launch path instead of the persistent decode engine (A/B, parity tests)
+  e->e.ds.eng_force = (on & 32) != 0;  // bit 5: the persistent decode engine whatever ITTS_ENGINE says
   return OK;
 }
 

@@ -7,6 +7,7 @@
 #include <cstdlib>
 
 #include "itts_decode.h"
+#include "decode_pinned.h"
 
 namespace itts {
 namespace {
@@ -413,9 +414,10 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_bf16_kernel(GemvArgs g) {
           S += red[pass][ww][2 * b];
           Q += red[pass][ww][2 * b + 1];
         }
-        const float md = S * invK;
-        const float mean = (pass == 0 ? pivot[b] : 0.f) + md;
-        const float rstd = __builtin_amdgcn_rsqf(fmaxf(Q * invK - md * md, 0.f) + g.ln_eps);
+        // contraction pinned (decode_pinned.h): the persistent engine repeats these operations bit for bit
+        const float md = __fmul_rn(S, invK);
+        const float mean = __fadd_rn(pass == 0 ? pivot[b] : 0.f, md);
+        const float rstd = __builtin_amdgcn_rsqf(__fadd_rn(fmaxf(ln_var_rn(Q, invK, md), 0.f), g.ln_eps));
 #pragma unroll
         for (int j = 0; j < KCH; ++j)
 #pragma unroll
@@ -515,7 +517,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_bf16_kernel(GemvArgs g) {
   GEMV_STAMP(4)
   if (lane < RPW * NB && n0 + er < g.N && eb < g.B) {
     float v = mine * spre + (g.bias ? bpre : 0.f);
-    v = act_apply(g.act, v);
+    v = g.act == ACT_GELU_NEW ? gelu_new_rn(v) : act_apply(g.act, v);
     const size_t o = (size_t)eb * g.ldy + en;
     if (YBF)
       ((bf16_t*)g.Y)[o] = (bf16_t)v;
@@ -688,7 +690,7 @@ __global__ __launch_bounds__(256) void gemv_wave_kernel(GemvArgs g) {
   GEMV_STAMP(4)
   if (lane < RPW * NB && n0 + er < g.N && eb < g.B) {
     float v = mine * spre + (g.bias ? bpre : 0.f);
-    v = act_apply(g.act, v);
+    v = g.act == ACT_GELU_NEW ? gelu_new_rn(v) : act_apply(g.act, v);
     const size_t o = (size_t)eb * g.ldy + en;
     if (YBF)
       ((bf16_t*)g.Y)[o] = (bf16_t)v;
@@ -913,7 +915,7 @@ __global__ __launch_bounds__(NT) void decode_attn2_kernel(TO* __restrict__ ctx, 
     const float mn = fmaxf(m, sc);
     const float corr = mn > -INFINITY ? __expf(m - mn) : 1.f;
     const float p = ok ? __expf(sc - mn) : 0.f;
-    l = l * corr + p;
+    l = fmaf(l, corr, p);  // contraction pinned: same operation in every build of this loop (decode_pinned.h)
 #pragma unroll
     for (int i = 0; i < VEC; ++i) acc[i] = fmaf(p, ok ? vv.get(i) : 0.f, acc[i] * corr);
     m = mn;
@@ -1134,9 +1136,10 @@ __device__ __forceinline__ void fused_gemv_part(const GemvArgs& g, int blk, unsi
           S += red[pass][ww][2 * b];
           Q += red[pass][ww][2 * b + 1];
         }
-        const float md = S * invK;
-        const float mean = (pass == 0 ? pivot[b] : 0.f) + md;
-        const float rstd = __builtin_amdgcn_rsqf(fmaxf(Q * invK - md * md, 0.f) + g.ln_eps);
+        // contraction pinned (decode_pinned.h): the persistent engine repeats these operations bit for bit
+        const float md = __fmul_rn(S, invK);
+        const float mean = __fadd_rn(pass == 0 ? pivot[b] : 0.f, md);
+        const float rstd = __builtin_amdgcn_rsqf(__fadd_rn(fmaxf(ln_var_rn(Q, invK, md), 0.f), g.ln_eps));
 #pragma unroll
         for (int j = 0; j < KCH; ++j)
 #pragma unroll
@@ -1234,7 +1237,7 @@ __device__ __forceinline__ void fused_gemv_part(const GemvArgs& g, int blk, unsi
     }
   if (lane < RPW * NB && n0 + er < g.N && eb < g.B) {
     float v = mine * spre + (g.bias ? bpre : 0.f);
-    v = act_apply(g.act, v);
+    v = g.act == ACT_GELU_NEW ? gelu_new_rn(v) : act_apply(g.act, v);
     // publish as one 8-byte {value, tag} granule (sc1: write-through, L2-served for the polling consumer on any XCD); the
     // tag's two scalars are read here, at the end: nothing in front of the weight requests waits for them
     const unsigned tag = ((unsigned)prefix[1] << 12) | (unsigned)(len[0] + 1);
@@ -1418,7 +1421,7 @@ __device__ __forceinline__ void fused_attn_part(const unsigned long long* __rest
     const float mn = fmaxf(m, sc);
     const float corr = mn > -INFINITY ? __expf(m - mn) : 1.f;
     const float p = ok ? __expf(sc - mn) : 0.f;
-    l = l * corr + p;
+    l = fmaf(l, corr, p);  // contraction pinned: same operation in every build of this loop (decode_pinned.h)
 #pragma unroll
     for (int i = 0; i < VEC; ++i) acc[i] = fmaf(p, ok ? vv.get(i) : 0.f, acc[i] * corr);
     m = mn;

@@ -1,0 +1,735 @@
+// Persistent decode engine (decode batches <= 4, bf16 weights): the 24 GPT-2 blocks of ONE token step as ONE launch.
+//
+// Reference hot loop: GPT2InferenceModel.forward, indextts/gpt/model.py:115-192 (HF 4.36.2 GPT2Block: LN -> c_attn ->
+// attention over the cache -> c_proj + residual -> LN -> c_fc -> gelu_new -> c_proj + residual).  The launch path
+// (decode2.hip, five graph-captured kernels per layer) is bound by its 120 dependent kernel boundaries per token, not by
+// HBM.  Here every one of the chip's 256 CUs holds ONE 1024-thread workgroup for the whole step:
+//
+//   * each workgroup owns a fixed slice of every projection's output features (16 of c_attn - a head's q / k / v rows are
+//     spread over the 12 workgroups of that head's group -, 5 of c_proj, 20 of c_fc, 5 of mlp.c_proj: 153.6 KB of bf16
+//     weights per layer) and streams it with nontemporal 16-byte loads straight into REGISTERS, one phase ahead of its
+//     use (the 512 KB register file of a CU holds a layer's share three times over; no LDS ring, no loader wave);
+//   * the five all-to-all phase edges of a layer (residual stream -> LN1, q/k/v -> attention, context -> c_proj,
+//     residual stream -> LN2, gelu(fc) -> mlp.c_proj) are 8-byte {value, tag} granules: written with ONE agent-scope
+//     (sc1, write-through) store by the lane that finished the value, polled with agent-scope loads by the four GATHER
+//     waves of every consuming workgroup - waves that never issue a weight load, so a poll never queues behind the
+//     workgroup's own weight stream (vmcnt is in-order per wave); the twelve COMPUTE waves never poll;
+//   * tag = a step counter kept in device memory and advanced by the kernel itself: every (layer, edge) has its own
+//     granule block, so a tag can only match a value of THIS step; nothing is reset between launches (graph replay safe);
+//   * one attention workgroup per (row, head) - workgroup `row` of the head's group - runs the four key splits of
+//     decode_attn2_kernel<.., 256, 4> on its 16 waves and merges them in LDS: no cross-CU hop for the partials.  Its K/V
+//     rows are requested right after the layer's first gather, one projection ahead of the scores.
+//
+// Arithmetic is the launch path's, operation for operation (same lane <-> k mapping and accumulation order of the GEMV
+// dot products, same LayerNorm reduction tree, same attention window / split / merge): logits and ids are bit-identical
+// to gemv_bf16_kernel + decode_attn2_kernel (tests/test_gpu_engine_persistent.py).
+//
+// Every spin is bounded (wall clock, s_memrealtime) and also ends on a chip-wide abort word; a workgroup that gave up
+// runs on without waiting, so the grid always drains.  The host reads the abort word at status / fetch.
+#include <cstdlib>
+
+#include "itts_decode.h"
+#include "itts_engine_kernel.h"
+#include "decode_pinned.h"
+
+namespace itts {
+namespace {
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef unsigned long long u64;
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float v) {
+  return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+// full-wave sum, uniform in every lane (decode2.hip wave_sum_rl: same tree, same bits)
+__device__ __forceinline__ float wave_sum_rl(float v) {
+  v = dpp_add<0xB1>(v);
+  v = dpp_add<0x4E>(v);
+  v = dpp_add<0x141>(v);
+  v = dpp_add<0x140>(v);
+  const int iv = __float_as_int(v);
+  const float a = __int_as_float(__builtin_amdgcn_readlane(iv, 0)), b = __int_as_float(__builtin_amdgcn_readlane(iv, 16));
+  const float c = __int_as_float(__builtin_amdgcn_readlane(iv, 32)), d = __int_as_float(__builtin_amdgcn_readlane(iv, 48));
+  return (a + b) + (c + d);
+}
+__device__ __forceinline__ uint32_t pack_bf16(float a, float b) {
+  bf16x2_t v = {(bf16_t)a, (bf16_t)b};
+  return __builtin_bit_cast(uint32_t, v);
+}
+__device__ __forceinline__ float dot2(uint32_t a, uint32_t b, float c) {
+  return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, a), __builtin_bit_cast(bf16x2_t, b), c, false);
+}
+__device__ __forceinline__ float bf16_lo(uint32_t w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float bf16_hi(uint32_t w) { return __uint_as_float(w & 0xFFFF0000u); }
+
+struct KVec {  // 8 bf16 of one cache row (decode2.hip CacheVec<bf16_t>)
+  u32x4 raw;
+  __device__ __forceinline__ void load(const bf16_t* p) { raw = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p)); }
+  __device__ __forceinline__ float get(int i) const {
+    const uint32_t w = raw[i >> 1];
+    return (i & 1) ? bf16_hi(w) : bf16_lo(w);
+  }
+};
+
+// ---- run-time state of one workgroup's hand-offs ----
+struct Rt {
+  unsigned tag;
+  bool dead;  // a wait of this thread gave up: later waits return at once, the kernel drains
+  u64 t0;
+  unsigned limit;
+  unsigned* ctr;  // [0] step counter (tag), [1] abort word
+};
+
+// debugging aid (EngArgs::stamp): wall-clock (100 MHz) stamp i of block l of this workgroup
+#define ENG_STAMP(i)                                                                                              \
+  if (a.stamp && (tl & 63) == 0 && (i < 8 ? tl == 0 : tl == 256))                                                \
+    a.stamp[((size_t)cu * a.NL + l) * 12 + (i)] = (unsigned)__builtin_amdgcn_s_memrealtime();
+
+__device__ __forceinline__ u64 ld_gran(const u64* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_gran(u64* p, unsigned tag, uint32_t v) {
+  __hip_atomic_store(p, ((u64)tag << 32) | (u64)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ __forceinline__ bool spin_fail(Rt& rt, unsigned& spins) {
+  if ((++spins & 15u) != 0) return false;
+  const bool ab = __hip_atomic_load(rt.ctr + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+  const bool to = (u64)(__builtin_amdgcn_s_memrealtime() - rt.t0) > (u64)rt.limit;
+  if (ab || to) {
+    if (!ab) __hip_atomic_store(rt.ctr + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    rt.dead = true;
+    return true;
+  }
+  return false;
+}
+
+// One gather thread (gt = 0..255) collects granules gt, gt + 256, ... < n of an edge: CH loads in flight, only the
+// granules whose tag has not matched yet are requested again.  sink(index, value) runs once per granule.
+template <int PER, int CH, typename Sink>
+__device__ __forceinline__ void sweep(const u64* __restrict__ g, int n, int gt, Rt& rt, Sink&& sink) {
+  // stage 1: while the edge's producers are still computing, ONE lane of each gather wave polls ONE granule (a different
+  // producer per wave) - 256 workgroups x 2560 requests per pass would otherwise compete with the producers' own weight
+  // stream and stores for the fabric (MI355X_MICROARCH "polling-cost")
+  {
+    const int w = gt >> 6;
+    const u64* __restrict__ p = g + min(n - 1, (n / 4) * w + n / 8);
+    unsigned spins = 0;
+    bool ok = rt.dead || (gt & 63) != 0;
+    while (!ok) {
+      ok = (unsigned)(ld_gran(p) >> 32) == rt.tag;
+      if (ok || spin_fail(rt, spins)) break;
+      __builtin_amdgcn_s_sleep(2);
+    }
+  }
+#pragma unroll
+  for (int j0 = 0; j0 < PER; j0 += CH) {
+    unsigned need = 0;
+#pragma unroll
+    for (int jj = 0; jj < CH; ++jj)
+      if (j0 + jj < PER && gt + 256 * (j0 + jj) < n) need |= 1u << jj;
+    if (rt.dead) need = 0;
+    unsigned spins = 0;
+    while (need) {
+      u64 x[CH];
+#pragma unroll
+      for (int jj = 0; jj < CH; ++jj)
+        if (j0 + jj < PER && ((need >> jj) & 1u)) x[jj] = ld_gran(g + gt + 256 * (j0 + jj));
+#pragma unroll
+      for (int jj = 0; jj < CH; ++jj)
+        if (j0 + jj < PER && ((need >> jj) & 1u) && (unsigned)(x[jj] >> 32) == rt.tag) {
+          sink(gt + 256 * (j0 + jj), (uint32_t)x[jj]);
+          need &= ~(1u << jj);
+        }
+      if (!need) break;
+      if (spin_fail(rt, spins)) break;
+      __builtin_amdgcn_s_sleep(1);
+    }
+  }
+}
+
+// ---- weights: global -> LDS by LDS-DMA, one phase ahead of their use ----
+// One wave instruction moves a 1 KiB fragment (512 bf16 of one weight row; lane l: elements 8l .. 8l + 7 - the lane <-> k
+// mapping of gemv_bf16_kernel) without touching a VGPR.  Written as asm so that hipcc neither counts it nor drains it in
+// front of every barrier (cdna_hip_programming.md 5.7): the issuing wave waits with its own s_waitcnt vmcnt(0) before
+// the phase barrier behind which the fragment is read.  nt: every weight byte is read once per step (nt-weights).
+__device__ __forceinline__ void dma16(const void* gsrc, unsigned lds_addr) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(gsrc), "s"(lds_addr)
+               : "memory");
+}
+__device__ __forceinline__ void dma4(const void* gsrc, unsigned lds_addr) {  // 4 bytes per lane (bias rows)
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(gsrc), "s"(lds_addr)
+               : "memory");
+}
+__device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// rows [n0, n0 + ROWS) of W [N][K] -> LDS slot (compact rows of K * 2 bytes), fragments dealt round-robin to the NCW
+// compute waves; bias[n0 ..] -> the 64 floats in front of the slot (one instruction of the last compute wave)
+template <int ROWS, int K, int NCW>
+__device__ __forceinline__ void dma_rows(const bf16_t* __restrict__ W, const float* __restrict__ bias, int n0, unsigned slot,
+                                         int cw, int lane) {
+  constexpr int NF = (K + 511) / 512, TOT = ROWS * NF, TAIL = K - (NF - 1) * 512;  // elements in the last fragment
+  static_assert(TAIL == 512 || TAIL == 256, "whole or half last fragment");
+#pragma unroll
+  for (int i = 0; i < (TOT + NCW - 1) / NCW; ++i) {
+    const int f = cw + i * NCW;
+    if (f < TOT) {
+      const int r = f / NF, c = f % NF;
+      const bf16_t* src = W + (size_t)(n0 + r) * K + c * 512 + lane * 8;
+      const unsigned dst = slot + 256 + (unsigned)(r * K * 2 + c * 1024);
+      if (TAIL == 512 || c != NF - 1) {
+        dma16(src, dst);
+      } else if (lane < 32) {
+        dma16(src, dst);
+      }
+    }
+  }
+  if (cw == NCW - 1 && lane < ROWS) dma4(bias + n0 + lane, slot);
+}
+
+// acc[b] += W[row] . x[b] in gemv_bf16_kernel's order (fragments ascending, four v_dot2c per fragment); W from its LDS slot
+template <int NB, int K>
+__device__ __forceinline__ void dots(const unsigned char* __restrict__ wrow, const uint32_t* __restrict__ sxb, int lane,
+                                     float (&acc)[NB]) {
+  constexpr int NCH = (K + 511) / 512;
+  const int klast = (NCH - 1) * 512 + lane * 8;
+  const bool kok = klast < K;
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int k = c == NCH - 1 ? (kok ? klast : K - 8) : c * 512 + lane * 8;
+    // lanes past the end of a half last fragment multiply by x = 0 like the launch path; they read a valid (finite) weight
+    const u32x4 w = *reinterpret_cast<const u32x4*>(wrow + c * 1024 + ((c == NCH - 1 && !kok) ? (lane & 31) : lane) * 16);
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      u32x4 xq = *reinterpret_cast<const u32x4*>(sxb + (b * K + k) / 2);
+      if (c == NCH - 1)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) xq[e] = kok ? xq[e] : 0u;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[b] = dot2(w[e], xq[e], acc[b]);
+    }
+  }
+}
+
+// LayerNorm without affine of xf [NB][K] fp32 -> bf16 pairs sxb [NB][K/2]: the prologue of gemv_bf16_kernel<.., PRO = 1>
+// on its 256 threads (threads 0..255 here), same shifted moments, same wave / workgroup reduction order.
+template <int NB, int K>
+__device__ __forceinline__ void ln_to_sxb(const float* __restrict__ xf, uint32_t* __restrict__ sxb, float* __restrict__ red,
+                                          int t, float eps) {
+  constexpr int KCH = 2, NTHR = 256;
+  static_assert(K > NTHR * 4 && K <= NTHR * 8, "two 4-element chunks per thread");
+  const int lane = t & 63, wave = t >> 6;
+  const float invK = 1.f / (float)K;
+  float xv[NB][KCH][4], pivot[NB];
+  bool xok[KCH];
+  if (t < NTHR) {
+#pragma unroll
+    for (int j = 0; j < KCH; ++j) {
+      const int i = (t + j * NTHR) * 4;
+      xok[j] = i < K;
+      const int ic = xok[j] ? i : K - 4;
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(xf + b * K + ic);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) xv[b][j][e] = v[e];
+      }
+    }
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      pivot[b] = xf[b * K];
+      float s = 0.f, q = 0.f;
+#pragma unroll
+      for (int j = 0; j < KCH; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float d = xok[j] ? xv[b][j][e] - pivot[b] : 0.f;
+          s += d;
+          q = fmaf(d, d, q);
+        }
+      s = wave_sum_rl(s);
+      q = wave_sum_rl(q);
+      if (lane == 0) {
+        red[wave * 2 * NB + 2 * b] = s;
+        red[wave * 2 * NB + 2 * b + 1] = q;
+      }
+    }
+  }
+  __syncthreads();
+  if (t < NTHR) {
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      float S = 0.f, Q = 0.f;
+#pragma unroll
+      for (int ww = 0; ww < 4; ++ww) {
+        S += red[ww * 2 * NB + 2 * b];
+        Q += red[ww * 2 * NB + 2 * b + 1];
+      }
+      const float md = __fmul_rn(S, invK);
+      const float mean = __fadd_rn(pivot[b], md);
+      const float rstd = __builtin_amdgcn_rsqf(__fadd_rn(fmaxf(ln_var_rn(Q, invK, md), 0.f), eps));
+#pragma unroll
+      for (int j = 0; j < KCH; ++j) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) xv[b][j][e] = (xv[b][j][e] - mean) * rstd;
+        if (xok[j]) {
+          const int i = (t + j * NTHR) * 4;
+          uint2 p;
+          p.x = pack_bf16(xv[b][j][0], xv[b][j][1]);
+          p.y = pack_bf16(xv[b][j][2], xv[b][j][3]);
+          *reinterpret_cast<uint2*>(sxb + (b * K + i) / 2) = p;
+        }
+      }
+    }
+  }
+  __syncthreads();
+}
+
+// ---------------------------------------------------------------------------------------------
+template <int NB>
+__global__ __launch_bounds__(1024) void decode_engine_kernel(EngArgs a) {
+  constexpr int D = ENG_D, H = ENG_H, DH = 64, NCU = ENG_NCU;
+  constexpr int GPH = NCU / H;       // workgroups per head group (12)
+  constexpr int QO = 3 * DH / GPH;   // c_attn rows per workgroup (16)
+  constexpr int HO = D / NCU;        // residual-projection rows per workgroup (5)
+  constexpr int FO = 4 * D / NCU;    // c_fc rows per workgroup (20)
+  constexpr int NCW = 12;            // compute waves (4..15); gather waves 0..3
+  static_assert(GPH * QO == 3 * DH && HO * NCU == D && FO * NCU == 4 * D && (FO % 2) == 0, "partition");
+  static_assert(QO <= 2 * NCW && HO <= NCW && FO / 2 <= NCW, "wave assignment");
+  constexpr int NIT = 3, NSPLIT = 4, SLOTS = 32, LPK = 8, VEC = 8, UNC = 2;  // decode_attn2_kernel<.., 3, 256, 4>
+  constexpr int SD = 2;  // rows in flight beyond the register window (the launch path takes 4: same rows, same order)
+  static_assert(ATTN_NSPLIT == NSPLIT, "split count of the launch path");
+  static_assert(NB <= ENG_MAX_ROWS, "LDS budget");
+
+  // LDS map.  Two weight slots (bias row + rows): slot 0 holds c_attn, then c_fc; slot 1 c_proj, then mlp.c_proj - the
+  // projection a slot is refilled with is requested only behind the barrier that ends the previous occupant's last use.
+  // Every edge lands in a buffer of its own: a gather may run while the compute waves still read the previous input.
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+  constexpr unsigned SLOT = 256 + FO * D * 2;  // = 256 + HO * 4D * 2
+  static_assert(SLOT >= 256 + QO * D * 2 && SLOT >= 256 + HO * 4 * D * 2, "slot size");
+  unsigned char* W0 = smem;
+  unsigned char* W1 = smem + SLOT;
+  float* xf = reinterpret_cast<float*>(smem + 2 * SLOT);            // [NB][D] gathered residual stream (fp32)
+  uint32_t* xn = reinterpret_cast<uint32_t*>(xf + NB * D);          // [NB][D / 2] LayerNorm output, bf16 pairs
+  uint32_t* xc = xn + NB * D / 2;                                   // [NB][D / 2] attention context, bf16 pairs
+  uint32_t* xa = xc + NB * D / 2;                                   // [NB][4D / 2] gelu(fc), bf16 pairs
+  float* red = reinterpret_cast<float*>(xa + NB * 2 * D);           // [4][2 NB]
+  float* hown = red + 4 * 2 * 4;                                    // [NB][8] this workgroup's slice of the residual stream
+  float* qkvs = hown + 4 * 8;                                       // [3][64] q / k / v of this (row, head)
+  float* so = qkvs + 3 * DH;                                        // [16][64]
+  float* smx = so + 16 * DH;                                        // [16]
+  float* slx = smx + 16;                                            // [16]
+  float* po = slx + 16;                                             // [4][64] partial of each key split
+  float* pml = po + NSPLIT * DH;                                    // [2][4]
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+  const unsigned S0 = lds0, S1 = lds0 + SLOT;
+
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int cu = blockIdx.x;
+  const bool gw = wave < 4;
+  const int cw = wave - 4;
+  const int gh = cu / GPH, gm = cu % GPH;
+  const bool qcu = cu < H * GPH;        // takes part in c_attn
+  const bool acu = qcu && gm < NB;      // runs the attention of (row gm, head gh)
+  // c_attn rows of this workgroup: q, k or v (gm / 4) of head gh, 16 consecutive features
+  const int an0 = (gm / 4) * D + gh * DH + (gm % 4) * QO;
+
+  Rt rt;
+  rt.t0 = __builtin_amdgcn_s_memrealtime();
+  rt.limit = a.timeout_ticks;
+  rt.ctr = a.ctr;
+  rt.dead = false;
+  rt.tag = a.ctr[0];
+  const EngLayerW* __restrict__ LW = a.layers;
+  const int prefix = a.prefix[0];
+
+  if (!gw && qcu) dma_rows<QO, D, NCW>(LW[0].wa, LW[0].ba, an0, S0, cw, lane);
+  if (t < NB * HO) hown[(t / HO) * 8 + t % HO] = a.h[(size_t)(t / HO) * D + cu * HO + t % HO];
+
+  constexpr size_t LSTRIDE = (size_t)NB * D * 15 / 2;
+  constexpr size_t OQKV = 0, OCTX = (size_t)NB * 3 * D, OH1 = OCTX + NB * D / 2, OACT = OH1 + NB * D, OH2 = OACT + NB * 2 * D;
+  for (int l = 0; l < a.NL; ++l) {
+    const EngLayerW w = LW[l];
+    // per-thread indices re-derived from an opaque copy each layer: hipcc otherwise hoists every per-thread address of
+    // the five phases out of the layer loop and spills them (53 VGPRs of scratch traffic inside the hand-off waits)
+    int tl = t;
+    asm volatile("" : "+v"(tl));
+    const int ll = tl & 63;
+    u64* __restrict__ G = a.gran + (size_t)l * LSTRIDE;
+
+    // ================= P1: residual stream -> LN1 -> c_attn =================
+    if (gw) {
+      if (l == 0) {
+        for (int i = tl; i < NB * D; i += 256) xf[i] = a.h[i];
+      } else {
+        sweep<(NB * D + 255) / 256, 10>(G - LSTRIDE + OH2, NB * D, tl, rt, [&](int i, uint32_t v) { xf[i] = __uint_as_float(v); });
+      }
+    } else {
+      dma_wait();  // c_attn rows of this layer (requested one phase ago)
+    }
+    ENG_STAMP(0)
+    __syncthreads();
+    ENG_STAMP(1)
+    if (!gw) dma_rows<HO, D, NCW>(w.wp, w.bp, cu * HO, S1, cw, ll);  // c_proj, one phase ahead
+    ln_to_sxb<NB, D>(xf, xn, red, tl, a.eps);
+    if (qcu && !gw) {
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const int r = cw + NCW * s;
+        if (r < QO) {
+          float acc[NB];
+#pragma unroll
+          for (int b = 0; b < NB; ++b) acc[b] = 0.f;
+          dots<NB, D>(W0 + 256 + r * D * 2, xn, ll, acc);
+          float mine = 0.f;
+#pragma unroll
+          for (int b = 0; b < NB; ++b) {
+            const float x = wave_sum_rl(acc[b]);
+            mine = ll == b ? x : mine;
+          }
+          if (ll < NB) {
+            st_gran(G + OQKV + (size_t)ll * 3 * D + an0 + r, rt.tag, __float_as_uint(mine + reinterpret_cast<const float*>(W0)[r]));
+            if (a.dbg && l == a.dbg_layer) a.dbg[(size_t)ll * 3 * D + an0 + r] = mine + reinterpret_cast<const float*>(W0)[r];
+          }
+        }
+      }
+    }
+
+    ENG_STAMP(8)
+    // ================= P2: cache attention of (row gm, head gh) =================
+    if (acu) {
+      // K/V rows: requested before the q / k / v hand-off is polled, so the cache stream hides behind that hop (all 16
+      // waves; the thread <-> (split, slot, sub) mapping of decode_attn2_kernel<.., 256, 4>)
+      const int sp = tl >> 8, atid = tl & 255, slot = atid / LPK, sub = atid % LPK;
+      KVec kr[2 * NIT], vr[2 * NIT];
+      const size_t lo = ((size_t)l * a.B * H + (size_t)gm * H + gh) * a.Smax * DH;
+      bf16_t* kb = a.kc + lo;
+      bf16_t* vb = a.vc + lo;
+#pragma unroll
+      for (int u = 0; u < UNC; ++u) {
+        const int j = min((u * NSPLIT + sp) * SLOTS + slot, a.Smax - 1);
+        kr[u].load(kb + (size_t)j * DH + sub * VEC);
+        vr[u].load(vb + (size_t)j * DH + sub * VEC);
+      }
+      const int pos = prefix + a.len[gm];
+      const int S = pos + 1;
+      const int ks = a.kv_start[gm];
+#pragma unroll
+      for (int u = UNC; u < 2 * NIT; ++u)
+        if ((u * NSPLIT + sp) * SLOTS < S) {
+          const int j = min((u * NSPLIT + sp) * SLOTS + slot, a.Smax - 1);
+          kr[u].load(kb + (size_t)j * DH + sub * VEC);
+          vr[u].load(vb + (size_t)j * DH + sub * VEC);
+        }
+      __builtin_amdgcn_sched_barrier(0);
+      if (gw && tl < 3 * DH) {  // q / k / v of this (row, head): 192 granules, one per thread
+        const u64* __restrict__ p = G + OQKV + (size_t)gm * 3 * D + (tl / DH) * D + gh * DH + tl % DH;
+        unsigned spins = 0;
+        while (!rt.dead) {
+          const u64 x = ld_gran(p);
+          if ((unsigned)(x >> 32) == rt.tag) {
+            qkvs[tl] = __uint_as_float((uint32_t)x);
+            break;
+          }
+          if (spin_fail(rt, spins)) break;
+          __builtin_amdgcn_s_sleep(1);
+        }
+      }
+      ENG_STAMP(2)
+      __syncthreads();
+      float qr[VEC];
+      const bool own = atid < LPK && sp == 0;  // slot 0 of split 0 appends this step's row
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) qr[i] = qkvs[sub * VEC + i] * a.scale;
+      if (own) {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+          kb[(size_t)pos * DH + sub * VEC + i] = (bf16_t)qkvs[DH + sub * VEC + i];
+          vb[(size_t)pos * DH + sub * VEC + i] = (bf16_t)qkvs[2 * DH + sub * VEC + i];
+        }
+      }
+      float m = -INFINITY, lsum = 0.f, acc[VEC];
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
+      auto score = [&](const KVec& kk) {
+        float sc = 0.f;
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) sc = fmaf(qr[i], kk.get(i), sc);
+        sc = dpp_add<0xB1>(sc);
+        sc = dpp_add<0x4E>(sc);
+        sc = dpp_add<0x141>(sc);
+        return sc;
+      };
+      {
+        float sc[2 * NIT + 1];
+#pragma unroll
+        for (int u = 0; u < 2 * NIT; ++u) {
+          const int j = (u * NSPLIT + sp) * SLOTS + slot;
+          const bool live = u < UNC || (u * NSPLIT + sp) * SLOTS < S;
+          const float tt = live ? score(kr[u]) : 0.f;
+          sc[u] = (live && j < S && j >= ks && j != pos) ? tt : -INFINITY;
+        }
+        {  // the row appended by this step, with the cache's rounding, from LDS
+          float tt = 0.f;
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) tt = fmaf(qr[i], own ? (float)(bf16_t)qkvs[DH + sub * VEC + i] : 0.f, tt);
+          tt = dpp_add<0xB1>(tt);
+          tt = dpp_add<0x4E>(tt);
+          tt = dpp_add<0x141>(tt);
+          sc[2 * NIT] = (slot == 0 && sp == 0) ? tt : -INFINITY;
+        }
+        float mw = sc[0];
+#pragma unroll
+        for (int u = 1; u <= 2 * NIT; ++u) mw = fmaxf(mw, sc[u]);
+        if (mw > -INFINITY) {
+#pragma unroll
+          for (int u = 0; u < 2 * NIT; ++u)
+            if (u < UNC || (u * NSPLIT + sp) * SLOTS < S) {
+              const float p = __expf(sc[u] - mw);
+              lsum += p;
+#pragma unroll
+              for (int i = 0; i < VEC; ++i) acc[i] = fmaf(p, vr[u].get(i), acc[i]);
+            }
+          const float p = __expf(sc[2 * NIT] - mw);
+          lsum += p;
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) acc[i] = fmaf(p, own ? (float)(bf16_t)qkvs[2 * DH + sub * VEC + i] : 0.f, acc[i]);
+          m = mw;
+        }
+      }
+      auto consume = [&](const KVec& kk, const KVec& vv, int j) {
+        const bool ok = j < S && j >= ks && j != pos;
+        float sc = score(kk);
+        sc = ok ? sc : -INFINITY;
+        const float mn = fmaxf(m, sc);
+        const float corr = mn > -INFINITY ? __expf(m - mn) : 1.f;
+        const float p = ok ? __expf(sc - mn) : 0.f;
+        lsum = fmaf(lsum, corr, p);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) acc[i] = fmaf(p, ok ? vv.get(i) : 0.f, acc[i] * corr);
+        m = mn;
+      };
+      for (int cb = 2 * NIT; (cb * NSPLIT + sp) * SLOTS < S; cb += SD) {
+        KVec k2[SD], v2[SD];
+#pragma unroll
+        for (int u = 0; u < SD; ++u) {
+          const int j = min(((cb + u) * NSPLIT + sp) * SLOTS + slot, a.Smax - 1);
+          k2[u].load(kb + (size_t)j * DH + sub * VEC);
+          v2[u].load(vb + (size_t)j * DH + sub * VEC);
+        }
+#pragma unroll
+        for (int u = 0; u < SD; ++u) consume(k2[u], v2[u], ((cb + u) * NSPLIT + sp) * SLOTS + slot);
+      }
+      auto bfly_max = [&](float x, int o) {
+        if (o == 8) return fmaxf(x, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x128, 0xf, 0xf, true)));
+        const u32x2 r = o == 16 ? __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false)
+                                : __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+        return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+      };
+      auto bfly_sum = [&](float x, int o) {
+        if (o == 8) return x + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x128, 0xf, 0xf, true));
+        const u32x2 r = o == 16 ? __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false)
+                                : __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+        return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+      };
+      float M = m;
+#pragma unroll
+      for (int o = LPK; o < 64; o <<= 1) M = bfly_max(M, o);
+      const float sc0 = M > -INFINITY ? __expf(m - M) : 0.f;
+      lsum *= sc0;
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) acc[i] *= sc0;
+#pragma unroll
+      for (int o = LPK; o < 64; o <<= 1) {
+        lsum = bfly_sum(lsum, o);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) acc[i] = bfly_sum(acc[i], o);
+      }
+      if (ll < LPK)
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) so[wave * DH + ll * VEC + i] = acc[i];
+      if (ll == 0) {
+        smx[wave] = M;
+        slx[wave] = lsum;
+      }
+      __syncthreads();
+      if (atid < DH) {  // the four waves of split sp -> its partial (the tail of decode_attn2_kernel)
+        float MM = smx[4 * sp];
+#pragma unroll
+        for (int i = 1; i < 4; ++i) MM = fmaxf(MM, smx[4 * sp + i]);
+        float o = 0.f, L = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float e = smx[4 * sp + i] > -INFINITY ? __expf(smx[4 * sp + i] - MM) : 0.f;
+          o = fmaf(e, so[(4 * sp + i) * DH + atid], o);
+          L = fmaf(e, slx[4 * sp + i], L);
+        }
+        po[sp * DH + atid] = o;
+        if (atid == 0) {
+          pml[sp] = MM;
+          pml[NSPLIT + sp] = L;
+        }
+      }
+      __syncthreads();
+      if (tl < DH / 2) {  // merge of the four partials (gemv_bf16_kernel prologue 3), two dims = one bf16 pair per thread
+        const float Mx = fmaxf(fmaxf(pml[0], pml[1]), fmaxf(pml[2], pml[3]));
+        float wgt[NSPLIT], L = 0.f;
+#pragma unroll
+        for (int s2 = 0; s2 < NSPLIT; ++s2) {
+          wgt[s2] = pml[s2] > -INFINITY ? __expf(pml[s2] - Mx) : 0.f;
+          L = fmaf(wgt[s2], pml[NSPLIT + s2], L);
+        }
+        const float inv = 1.f / L;
+        float xm[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          float v = 0.f;
+#pragma unroll
+          for (int s2 = 0; s2 < NSPLIT; ++s2) v = fmaf(wgt[s2], po[s2 * DH + 2 * tl + e], v);
+          xm[e] = v * inv;
+        }
+        st_gran(G + OCTX + (size_t)gm * (D / 2) + gh * (DH / 2) + tl, rt.tag, pack_bf16(xm[0], xm[1]));
+      }
+      ENG_STAMP(3)
+    }
+
+    // ================= P3: context -> c_proj + residual =================
+    if (gw) {
+      sweep<(NB * D / 2 + 255) / 256, 10>(G + OCTX, NB * D / 2, tl, rt, [&](int i, uint32_t v) { xc[i] = v; });
+    } else {
+      dma_wait();  // c_proj rows
+    }
+    ENG_STAMP(4)
+    __syncthreads();
+    if (!gw) dma_rows<FO, D, NCW>(w.wf, w.bf, cu * FO, S0, cw, ll);  // c_fc, one phase ahead (c_attn's slot)
+    if (!gw && cw < HO) {
+      float acc[NB];
+#pragma unroll
+      for (int b = 0; b < NB; ++b) acc[b] = 0.f;
+      dots<NB, D>(W1 + 256 + cw * D * 2, xc, ll, acc);
+      float mine = 0.f;
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        const float x = wave_sum_rl(acc[b]);
+        mine = ll == b ? x : mine;
+      }
+      if (ll < NB) {
+        const float hn = hown[ll * 8 + cw] + (mine + reinterpret_cast<const float*>(W1)[cw]);
+        hown[ll * 8 + cw] = hn;
+        st_gran(G + OH1 + (size_t)ll * D + cu * HO + cw, rt.tag, __float_as_uint(hn));
+        if (a.dbg && l == a.dbg_layer) a.dbg[(size_t)NB * 3 * D + (size_t)ll * D + cu * HO + cw] = hn;
+      }
+    }
+
+    ENG_STAMP(9)
+    // ================= P4: residual stream -> LN2 -> c_fc -> gelu_new =================
+    if (gw) {
+      sweep<(NB * D + 255) / 256, 10>(G + OH1, NB * D, tl, rt, [&](int i, uint32_t v) { xf[i] = __uint_as_float(v); });
+    } else {
+      dma_wait();  // c_fc rows
+    }
+    ENG_STAMP(5)
+    __syncthreads();
+    if (!gw) dma_rows<HO, 4 * D, NCW>(w.w2, w.b2, cu * HO, S1, cw, ll);  // mlp.c_proj, one phase ahead (c_proj's slot)
+    ln_to_sxb<NB, D>(xf, xn, red, tl, a.eps);
+    if (!gw && cw < FO / 2) {  // an adjacent pair of features per wave: one bf16-pair granule per batch row
+      float acc[2][NB];
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+#pragma unroll
+        for (int b = 0; b < NB; ++b) acc[r][b] = 0.f;
+        dots<NB, D>(W0 + 256 + (2 * cw + r) * D * 2, xn, ll, acc[r]);
+      }
+      float mine = 0.f;
+#pragma unroll
+      for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+          const float x = wave_sum_rl(acc[r][b]);
+          mine = ll == r * NB + b ? x : mine;
+        }
+      const float v = gelu_new_rn(mine + reinterpret_cast<const float*>(W0)[2 * cw + (ll < NB ? 0 : 1)]);
+      const float v1 = __shfl_down(v, NB, 64);  // (feature 1, batch row ll) for lanes < NB
+      if (ll < NB) {
+        st_gran(G + OACT + (size_t)ll * 2 * D + cu * (FO / 2) + cw, rt.tag, pack_bf16(v, v1));
+        if (a.dbg && l == a.dbg_layer) {
+          float* d = a.dbg + (size_t)NB * 4 * D + (size_t)ll * 4 * D + cu * FO + 2 * cw;
+          d[0] = (float)(bf16_t)v;
+          d[1] = (float)(bf16_t)v1;
+        }
+      }
+    }
+
+    ENG_STAMP(10)
+    // ================= P5: gelu(fc) -> mlp.c_proj + residual =================
+    if (gw) {
+      sweep<(NB * 2 * D + 255) / 256, 10>(G + OACT, NB * 2 * D, tl, rt, [&](int i, uint32_t v) { xa[i] = v; });
+    } else {
+      dma_wait();  // mlp.c_proj rows
+    }
+    ENG_STAMP(6)
+    __syncthreads();
+    ENG_STAMP(7)
+    if (!gw && qcu && l + 1 < a.NL) dma_rows<QO, D, NCW>(LW[l + 1].wa, LW[l + 1].ba, an0, S0, cw, ll);  // next layer's c_attn
+    if (!gw && cw < HO) {
+      float acc[NB];
+#pragma unroll
+      for (int b = 0; b < NB; ++b) acc[b] = 0.f;
+      dots<NB, 4 * D>(W1 + 256 + cw * 4 * D * 2, xa, ll, acc);
+      float mine = 0.f;
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        const float x = wave_sum_rl(acc[b]);
+        mine = ll == b ? x : mine;
+      }
+      if (ll < NB) {
+        const float hn = hown[ll * 8 + cw] + (mine + reinterpret_cast<const float*>(W1)[cw]);
+        hown[ll * 8 + cw] = hn;
+        if (a.dbg && l == a.dbg_layer) a.dbg[(size_t)NB * 8 * D + (size_t)ll * D + cu * HO + cw] = hn;
+        if (l + 1 < a.NL)
+          st_gran(G + OH2 + (size_t)ll * D + cu * HO + cw, rt.tag, __float_as_uint(hn));
+        else
+          a.h[(size_t)ll * D + cu * HO + cw] = hn;
+      }
+    }
+    ENG_STAMP(11)
+  }
+  // advance the step counter (never 0): every workgroup read it before its first publish, and this workgroup got here
+  // only after gathering from all of them
+  if (cu == 0 && t == 0) a.ctr[0] = rt.tag + 1 == 0 ? 1u : rt.tag + 1;
+}
+
+}  // namespace
+
+size_t eng_gran_count(int layers) { return (size_t)layers * 4 * ENG_D * 15 / 2; }
+
+int decode_engine_layers(const EngArgs& a, hipStream_t s) {
+  ITTS_REQUIRE(a.B >= 1 && a.B <= ENG_MAX_ROWS && a.layers && a.gran && a.h && a.kc && a.vc && a.ctr, "decode_engine: bad arguments");
+  const size_t lds = 152 * 1024;  // weight slots + edge buffers: one workgroup per CU
+#define ITTS_ENG_GO(NB)                                                                                                         \
+  {                                                                                                                             \
+    static bool attr = false;                                                                                                   \
+    if (!attr) {                                                                                                                \
+      ITTS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&decode_engine_kernel<NB>),                              \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                                \
+      attr = true;                                                                                                              \
+    }                                                                                                                           \
+    hipLaunchKernelGGL((decode_engine_kernel<NB>), dim3(ENG_NCU), dim3(1024), lds, s, a);                                       \
+  }
+  if (a.B == 1) ITTS_ENG_GO(1)
+  else ITTS_ENG_GO(2)
+#undef ITTS_ENG_GO
+  ITTS_HIP_CHECK(hipGetLastError());
+  return OK;
+}
+
+}  // namespace itts

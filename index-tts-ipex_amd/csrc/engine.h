@@ -8,6 +8,7 @@
 
 #include "../../include/itts_hip.h"
 #include "itts_decode.h"
+#include "itts_engine_kernel.h"
 #include "itts_kernels.h"
 
 namespace itts {
@@ -153,6 +154,14 @@ struct DecodeState {
   int* fuse_err = nullptr;
   int fuse_failed = 0;                 // a hand-off timed out: two launches from then on
   int fuse = 0, graph_fuse = 0;        // opt-in (ITTS_FUSE_QKV_ATTN=1 / debug bit 3): measured 1.5 % slower than two launches; 0 again after a hand-off timeout
+  // persistent decode engine (decode_engine.hip): the blocks of a step as one launch, <= 4 rows, bf16, no beams / fp8
+  EngLayerW* eng_layers = nullptr;       // device table [layers]
+  unsigned long long* eng_gran = nullptr;
+  unsigned* eng_ctr = nullptr;           // [0] step counter, [1] abort word
+  int eng_off = 0;                       // debug bit 4 / ITTS_ENGINE=0: keep the five-launches-per-layer path (A/B)
+  int eng_force = 0;                     // debug bit 5: use the engine whatever ITTS_ENGINE / the default says
+  int eng_failed = 0;                    // a hand-off timed out: launch path from then on
+  int graph_eng = 0;
   float typical_mass = 0.f, graph_typical = 0.f;  // TypicalLogitsWarper pre-pass (0 = off)
   float* scores2 = nullptr;                        // [cap_B][V] its output
   int* forced = nullptr;  // [cap_B][cap_gen] forced token per (row, step) or -1; allocated with ids
@@ -239,6 +248,9 @@ struct Engine {
   // internals
   int gpt_layers_full(float* h, int B, int S, const int* kv_start_dev, bool write_cache, hipStream_t s);
   int decode_step_launch(hipStream_t s);
+  bool engine_usable() const;
+  int ensure_engine_state(hipStream_t s);
+  int engine_check(hipStream_t s);
   int head_and_sample(hipStream_t s);
   int ensure_decode_state(int B, int Smax, int max_gen, hipStream_t s);
   template <typename F>

@@ -1,0 +1,36 @@
+// Persistent decode engine (decode_engine.hip): one launch for the 24 GPT-2 blocks of a token step, decode batches <= 4.
+#pragma once
+#include "itts_common.h"
+
+namespace itts {
+
+constexpr int ENG_D = 1280, ENG_H = 20, ENG_NCU = 256, ENG_MAX_ROWS = 2;
+constexpr bool ENG_DEFAULT_ON = false;  // ITTS_ENGINE=1 / 0 overrides  // IndexTTS-1.5 GPT on the 256 CUs of an MI355X
+
+struct EngLayerW {  // one GPT-2 block: bf16 [N][K] projections (LayerNorm affine folded in by the packer), fp32 biases
+  const bf16_t *wa, *wp, *wf, *w2;
+  const float *ba, *bp, *bf, *b2;
+};
+
+struct EngArgs {
+  const EngLayerW* layers = nullptr;  // device table [NL]
+  unsigned long long* gran = nullptr; // hand-off granules: eng_gran_count(NL) words, zeroed once at allocation
+  float* h = nullptr;                 // residual stream [B][D]: this step's input embedding in, last block's output out
+  bf16_t* kc = nullptr;               // KV cache [NL][B][H][Smax][64]
+  bf16_t* vc = nullptr;
+  const int* len = nullptr;           // [B] tokens generated so far
+  const int* kv_start = nullptr;      // [B] first valid (not left-padded) cache row
+  const int* prefix = nullptr;        // [0] prefix length
+  unsigned* ctr = nullptr;            // [0] step counter = hand-off tag (starts at 1, never 0), [1] abort word
+  int NL = 0, B = 0, Smax = 0;
+  float scale = 0.125f, eps = 1e-5f;
+  unsigned timeout_ticks = 2000000;   // wall-clock bound of every wait, 100 MHz ticks (20 ms)
+  float* dbg = nullptr;               // debugging aid (ITTS_TAP_LAYER): qkv [B][3D], h1 [B][D], act [B][4D], h2 [B][D] of block dbg_layer
+  int dbg_layer = -1;
+  unsigned* stamp = nullptr;          // debugging aid (ITTS_ENGINE_STAMPS): [256][NL][12] wall-clock stamps (100 MHz) of one step
+};
+
+size_t eng_gran_count(int layers);  // 8-byte words of the granule buffer (sized for 4 rows)
+int decode_engine_layers(const EngArgs& a, hipStream_t s);
+
+}  // namespace itts

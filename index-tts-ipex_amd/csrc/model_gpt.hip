@@ -158,6 +158,52 @@ int Engine::ensure_decode_tiles(hipStream_t s) {
   return OK;
 }
 
+// The persistent decode engine (decode_engine.hip) replaces the 120 per-layer launches of a step when the step is the
+// launch-bound small-batch bf16 one it was built for: IndexTTS-1.5 GPT dims, <= 4 rows, no beams (cache ancestry), no fp8
+// copies, a whole MI355X (256 CUs) to itself.  ITTS_ENGINE=0 (or debug bit 4) keeps the launch path.
+bool Engine::engine_usable() const {
+  const char* ev = getenv("ITTS_ENGINE");  // read per call: tests flip it inside one process
+  const bool env_off = ev ? atoi(ev) == 0 : !ENG_DEFAULT_ON;
+  static const int ncu = [] {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0;
+    return n;
+  }();
+  const itts_config& c = cfg;
+  if ((env_off && !ds.eng_force) || ds.eng_off || ds.eng_failed || ncu != ENG_NCU) return false;
+  if (adt != BF16 || ds.B < 1 || ds.B > ENG_MAX_ROWS || ds.nb != 1) return false;
+  if (c.model_dim != ENG_D || c.heads != ENG_H || c.layers < 1 || ds.Smax > 2048 || ds.Smax % 256 != 0) return false;
+  for (const GptLayerW& L : gpt.layers)
+    for (const Lin* l : {&L.attn, &L.proj, &L.fc, &L.proj2})
+      if (l->dt != BF16 || l->w8 || !l->b || l->taps != 1) return false;
+  return true;
+}
+
+int Engine::ensure_engine_state(hipStream_t s) {
+  DecodeState& d = ds;
+  if (d.eng_layers) return OK;
+  const itts_config& c = cfg;
+  std::vector<EngLayerW> tab(c.layers);
+  for (int l = 0; l < c.layers; ++l) {
+    const GptLayerW& L = gpt.layers[l];
+    ITTS_REQUIRE(L.attn.N == 3 * ENG_D && L.attn.Cin == ENG_D && L.proj.N == ENG_D && L.proj.Cin == ENG_D &&
+                     L.fc.N == 4 * ENG_D && L.fc.Cin == ENG_D && L.proj2.N == ENG_D && L.proj2.Cin == 4 * ENG_D,
+                 "decode engine: projection shapes");
+    tab[l] = {(const bf16_t*)L.attn.w, (const bf16_t*)L.proj.w, (const bf16_t*)L.fc.w, (const bf16_t*)L.proj2.w,
+              L.attn.b, L.proj.b, L.fc.b, L.proj2.b};
+  }
+  ITTS_TRY(dev_alloc((void**)&d.eng_layers, tab.size() * sizeof(EngLayerW)));
+  const size_t gb = eng_gran_count(c.layers) * 8;
+  ITTS_TRY(dev_alloc((void**)&d.eng_gran, gb));
+  ITTS_TRY(dev_alloc((void**)&d.eng_ctr, 64));
+  const unsigned ctr0[16] = {1u, 0u};
+  ITTS_HIP_CHECK(hipMemcpyAsync(d.eng_layers, tab.data(), tab.size() * sizeof(EngLayerW), hipMemcpyHostToDevice, s));
+  ITTS_HIP_CHECK(hipMemsetAsync(d.eng_gran, 0, gb, s));  // tag 0 is never issued
+  ITTS_HIP_CHECK(hipMemcpyAsync(d.eng_ctr, ctr0, 64, hipMemcpyHostToDevice, s));
+  ITTS_HIP_CHECK(hipStreamSynchronize(s));  // tab / ctr0 are host stack buffers
+  return OK;
+}
+
 int Engine::ensure_decode_state(int B, int Smax, int max_gen, hipStream_t s) {
   const itts_config& c = cfg;
   const int D = c.model_dim, H = c.heads, dh = D / H, V = c.number_mel_codes;
@@ -379,6 +425,7 @@ int Engine::gpt_prefill(const float* cond_dev, const int32_t* text_ids_in, int B
   ds.suppress_stop = suppress;
   gen_epoch = (gen_epoch % 0xFFFFF) + 1;  // 1 .. 2^20 - 1
   ds.nb = nbeam;
+  if (engine_usable()) ITTS_TRY(ensure_engine_state(s));  // allocations must not happen inside the graph capture of the step
   ds.beam_sample = beam_do_sample;
   ds.length_penalty = beam_length_penalty;
   if (nbeam > 1) {
@@ -628,6 +675,43 @@ int Engine::decode_step_launch(hipStream_t s) {
   const bool fast = adt == BF16 && B <= 4;  // bf16 activations between the decode kernels (ctx, act)
   const bool skinny = adt == BF16 && B > 4 && D % 32 == 0 && D <= 2048;  // weights once, batch on MFMA
   ds.pend_split = 0;
+  int eng_first = 0;
+  if (engine_usable()) {  // <= 4 rows: the 24 blocks as ONE persistent launch, then the head + sampler launches
+    ITTS_REQUIRE(ds.eng_layers && ds.eng_gran && ds.eng_ctr, "decode engine: state not allocated (prefill first)");
+    EngArgs ea;
+    ea.layers = ds.eng_layers;
+    ea.gran = ds.eng_gran;
+    ea.h = ds.h;
+    ea.kc = (bf16_t*)ds.kc;
+    ea.vc = (bf16_t*)ds.vc;
+    ea.len = ds.len;
+    ea.kv_start = ds.kv_start;
+    ea.prefix = ds.prefix_dev;
+    ea.ctr = ds.eng_ctr;
+    // ITTS_ENGINE_LAYERS=n (debugging aid): blocks [0, n) on the engine, the rest as launches
+    static const int e_nl = getenv("ITTS_ENGINE_LAYERS") ? atoi(getenv("ITTS_ENGINE_LAYERS")) : -1;
+    eng_first = e_nl >= 0 && e_nl < c.layers ? e_nl : c.layers;
+    ea.NL = eng_first;
+    ea.B = B;
+    ea.Smax = ds.Smax;
+    ea.scale = 1.f / std::sqrt((float)dh);
+    static const int e_tap = getenv("ITTS_TAP_LAYER") ? atoi(getenv("ITTS_TAP_LAYER")) : -1;
+    if (debug && e_tap >= 0 && e_tap < eng_first && !dry) {  // debugging aid: the engine's view of one block's edges
+      ea.dbg = ds.act;  // [16][4D] fp32 scratch of the launch path, unused by the engine: room for the 9 B D floats of the dump
+      ea.dbg_layer = e_tap;
+    }
+    static const bool e_stamps = getenv("ITTS_ENGINE_STAMPS") != nullptr;
+    if (debug && e_stamps && !dry) ea.stamp = (unsigned*)ds.logits + 0;  // [16][V] fp32 scratch >= 256 * 24 * 12 words; the head overwrites it later
+    if (eng_first > 0) ITTS_TRY(decode_engine_layers(ea, s));
+    if (ea.stamp) ITTS_TRY(tap("eng_stamps", ea.stamp, F32, (int64_t)ENG_NCU * eng_first * 12, s));
+    if (ea.dbg) {
+      ITTS_TRY(tap("eng_qkv", ea.dbg, F32, (int64_t)B * 3 * D, s));
+      ITTS_TRY(tap("eng_h1", ea.dbg + (size_t)B * 3 * D, F32, (int64_t)B * D, s));
+      ITTS_TRY(tap("eng_act", ea.dbg + (size_t)B * 4 * D, F32, (int64_t)B * 4 * D, s));
+      ITTS_TRY(tap("eng_h2", ea.dbg + (size_t)B * 8 * D, F32, (int64_t)B * D, s));
+    }
+    if (eng_first == c.layers) return head_and_sample(s);
+  }
   // 5-16 rows: the step is launch-bound, so the two LayerNorm launches of a layer fold into the projections they feed
   // (skinny_mfma_kernel<LNP>) and the residual projections run as half tiles without a K split (<HALF>): 5 launches a
   // layer instead of 7 (ITTS_NO_SKINNY16=1 keeps the 7-launch form)
@@ -692,7 +776,7 @@ int Engine::decode_step_launch(hipStream_t s) {
   const bool bf_act = skinny || (fast && gemv_bf16_supported(probe));
   probe.K = D;
   const bool bf_ctx = skinny || (fast && gemv_bf16_supported(probe));
-  for (int l = 0; l < c.layers; ++l) {
+  for (int l = eng_first; l < c.layers; ++l) {
     const GptLayerW& L = gpt.layers[l];
     GemvArgs g;  // qkv = LN1(h) Wqkv + b
     g.B = B;
@@ -722,6 +806,8 @@ int Engine::decode_step_launch(hipStream_t s) {
     } else {
       ITTS_TRY(run(g, L.attn.dt));
     }
+    static const int l_tap = getenv("ITTS_TAP_LAYER") ? atoi(getenv("ITTS_TAP_LAYER")) : -1;
+    if (l == l_tap) ITTS_TRY(tap("lp_qkv", ds.qkv, F32, (int64_t)B * 3 * D, s));
     if (fused) {
     } else if (split)
       ITTS_TRY(decode_attn2(nullptr, BF16, ds.qkv, (char*)ds.kc + lo, (char*)ds.vc + lo, ds.len, ds.kv_start, ds.prefix_dev, B, H,
@@ -750,6 +836,7 @@ int Engine::decode_step_launch(hipStream_t s) {
     p.w8src = L.proj.w8 ? &L.proj : nullptr;
     p.Wt = L.proj.wt;
     ITTS_TRY(run(p, L.proj.dt));
+    if (l == l_tap) ITTS_TRY(tap("lp_h1", ds.h, F32, (int64_t)B * D, s));
     GemvArgs f;  // act = gelu_new(LN2(h) Wfc + b)
     f.B = B;
     f.X = ds.h;
@@ -767,6 +854,7 @@ int Engine::decode_step_launch(hipStream_t s) {
     f.w8src = L.fc.w8 ? &L.fc : nullptr;
     f.Wt = L.fc.wt;
     ITTS_TRY(run(f, L.fc.dt));
+    if (l == l_tap) ITTS_TRY(tap("lp_act", ds.act, bf_act ? BF16 : F32, (int64_t)B * 4 * D, s));
     GemvArgs q;  // h += act Wproj2 + b
     q.B = B;
     q.X = ds.act;
@@ -781,6 +869,7 @@ int Engine::decode_step_launch(hipStream_t s) {
     q.w8src = L.proj2.w8 ? &L.proj2 : nullptr;
     q.Wt = L.proj2.wt;
     ITTS_TRY(run(q, L.proj2.dt));
+    if (l == l_tap) ITTS_TRY(tap("lp_h2", ds.h, F32, (int64_t)B * D, s));
   }
   return head_and_sample(s);
 }
@@ -839,7 +928,7 @@ int Engine::gpt_decode(int nsteps, hipStream_t s) {
     // everything SamplerArgs carries by value is baked into the captured nodes: max_gen is the ids row stride and the
     // `k < max_gen` bound, so a per-request max_mel_tokens must re-capture (same B / Smax notwithstanding)
     const bool stale = !d.graph || d.graph_B != d.B || d.graph_Smax != d.Smax || d.graph_max_gen != d.max_gen ||
-                       d.graph_forced != d.use_forced || d.graph_fuse != (d.fuse && !d.fuse_failed) || d.graph_nb != d.nb || d.graph_beam_sample != d.beam_sample ||
+                       d.graph_forced != d.use_forced || d.graph_fuse != (d.fuse && !d.fuse_failed) || d.graph_eng != (int)engine_usable() || d.graph_nb != d.nb || d.graph_beam_sample != d.beam_sample ||
                        d.graph_length_penalty != d.length_penalty || d.graph_typical != d.typical_mass || d.graph_penalty != d.penalty || d.graph_suppress != d.suppress_stop || d.graph_sample != d.do_sample ||
                        d.graph_top_k != d.top_k || d.graph_top_p != d.top_p || d.graph_temperature != d.temperature;
     // two executables: one step, and GK steps back to back (one launch per GK tokens: the gap between consecutive graph
@@ -874,6 +963,7 @@ int Engine::gpt_decode(int nsteps, hipStream_t s) {
       d.graph_max_gen = d.max_gen;
       d.graph_forced = d.use_forced;
       d.graph_fuse = d.fuse && !d.fuse_failed;
+      d.graph_eng = (int)engine_usable();
       d.graph_nb = d.nb;
       d.graph_beam_sample = d.beam_sample;
       d.graph_length_penalty = d.length_penalty;
@@ -895,6 +985,22 @@ int Engine::gpt_decode(int nsteps, hipStream_t s) {
   return OK;
 }
 
+// abort word of the persistent decode engine: a hand-off wait gave up, so the codes of this generation are not valid.
+// The engine is switched off for this Engine (launch path from the next generation on) and its state re-initialised.
+int Engine::engine_check(hipStream_t s) {
+  if (!ds.eng_ctr) return OK;
+  unsigned host[2] = {0, 0};
+  ITTS_HIP_CHECK(hipMemcpyAsync(host, ds.eng_ctr, 8, hipMemcpyDeviceToHost, s));
+  ITTS_HIP_CHECK(hipStreamSynchronize(s));
+  if (!host[1]) return OK;
+  ds.eng_failed = 1;
+  const unsigned ctr0[2] = {host[0] ? host[0] : 1u, 0u};
+  ITTS_HIP_CHECK(hipMemcpyAsync(ds.eng_ctr, ctr0, 8, hipMemcpyHostToDevice, s));
+  ITTS_HIP_CHECK(hipStreamSynchronize(s));
+  set_error("decode engine: an in-launch hand-off timed out (persistent engine disabled for this engine; the codes of this generation are not valid)");
+  return E_HIP;
+}
+
 int Engine::gpt_status(int* steps, int* n_unf, hipStream_t s) {
   if (!ds.active) {
     set_error("gpt_status: no active generation");
@@ -906,6 +1012,7 @@ int Engine::gpt_status(int* steps, int* n_unf, hipStream_t s) {
   ITTS_HIP_CHECK(hipMemcpyAsync(host.data(), ds.len, 4, hipMemcpyDeviceToHost, s));
   ITTS_HIP_CHECK(hipMemcpyAsync(host.data() + 1, ds.unfinished, (size_t)ds.B * 4, hipMemcpyDeviceToHost, s));
   ITTS_HIP_CHECK(hipStreamSynchronize(s));
+  ITTS_TRY(engine_check(s));
   if (ferr) {  // an attention workgroup gave up waiting for its q / k / v: the codes of this generation are not valid
     ds.fuse_failed = 1;  // later generations take the two-launch path
     ITTS_HIP_CHECK(hipMemsetAsync(ds.fuse_err, 0, 4, s));
@@ -926,6 +1033,7 @@ int Engine::gpt_fetch(int32_t* codes, float* logits, hipStream_t s) {
     set_error("gpt_fetch: no active generation");
     return E_STATE;
   }
+  ITTS_TRY(engine_check(s));
   if (codes && ds.nb > 1)
     ITTS_TRY(beam_finalize(codes, s));  // [B / nb][max_gen]
   else if (codes)

@@ -10,12 +10,15 @@ Same constructor and methods (`extract_features`, `infer`, `infer_fast`, `set_gr
     batch are independent), `infer_fast` in the reference's length-sorted buckets; both vocode as the reference does
     (`infer` per sentence, `infer_fast` over time-concatenated chunks of 2 latents); `infer_batch` takes several utterances;
   * every public call takes the engine lock: several host threads may share one IndexTTS (webui.py:441-452);
-  * generation runs on the device for the three modes the kwargs of infer.py:116-124 select: beam-sample (the default:
-    do_sample=True, num_beams=3; up to 4 beams, per-beam cache ancestry instead of HF's per-step cache copy), multinomial
-    sampling (num_beams=1) and greedy (do_sample=False) - with top_k <= 64 / top_p / temperature / repetition_penalty in HF
-    4.36.2 semantics.  Draws come from a numpy Generator seeded from torch's global RNG, so `torch.manual_seed` makes a run
-    reproducible (torch.multinomial's own stream cannot be reproduced on a device).  Beam search without sampling and
-    typical sampling are not implemented (RuntimeWarning, plain fallback);
+  * generation runs on the device for every mode the kwargs of infer.py:116-124 select: beam-sample (the default:
+    do_sample=True, num_beams=3; up to 10 beams, per-beam cache ancestry instead of HF's per-step cache copy), beam search
+    (do_sample=False, num_beams > 1), multinomial sampling (num_beams=1) and greedy - with top_k <= 128 / top_p /
+    temperature / repetition_penalty / length_penalty and `typical_sampling` (TypicalLogitsWarper) in HF 4.36.2 semantics.
+    Draws come from a numpy Generator seeded from torch's global RNG, so `torch.manual_seed` makes a run reproducible
+    (torch.multinomial's own stream cannot be reproduced on a device);
+  * the text normaliser is built and loaded as in infer.py:69-71; its third-party written-form normalisers (`tn` /
+    `wetext`) are used when installed and skipped with a RuntimeWarning otherwise (punctuation folding, pinyin and name
+    protection always apply);
   * `is_fp16=True` selects the bf16 throughput engine, `False` the fp32 parity engine; `use_cuda_kernel` is accepted
     and ignored (the fused HIP activation is always used).
 There is no CPU fallback: without a GPU / libitts_hip.so construction raises."""
@@ -36,7 +39,7 @@ from indextts.BigVGAN.models import BigVGAN as Generator
 from indextts.gpt.model import UnifiedVoice
 from indextts.utils.checkpoint import read_state_dict
 from indextts.utils.feature_extractors import MelSpectrogramFeatures, load_wav_mono, resample
-from indextts.utils.front import TextTokenizer
+from indextts.utils.front import TextNormalizer, TextTokenizer
 
 
 class IndexTTS:
@@ -71,8 +74,10 @@ class IndexTTS:
         self.gpt = UnifiedVoice(self.engine, self.cfg.gpt)
         self.bigvgan = Generator(self.engine)
         self.bpe_path = os.path.join(model_dir, self.cfg.dataset["bpe_model"])
-        self.normalizer = None
+        self.normalizer = TextNormalizer()  # infer.py:69-71
+        self.normalizer.load()
         self.tokenizer = TextTokenizer(self.bpe_path, self.normalizer)
+        print(">> bpe model loaded from:", self.bpe_path)
         self.wav2mel = MelSpectrogramFeatures()
         self.gr_progress = None
 

@@ -130,8 +130,12 @@ class Engine:
     def finalize(self):
         L.check(self.lib.itts_engine_finalize(self.h), "finalize")
 
-    def debug(self, taps: bool = False, force_simple: bool = False, no_graph: bool = False, fuse: bool = False):
-        L.check(self.lib.itts_debug_enable(self.h, int(taps) | (int(force_simple) << 1) | (int(no_graph) << 2) | (int(fuse) << 3)))
+    def debug(self, taps: bool = False, force_simple: bool = False, no_graph: bool = False, fuse: bool = False,
+              no_engine: bool = False, engine: bool = False):
+        """no_engine: keep the five-launches-per-layer decode step instead of the persistent decode engine; engine: use
+        the persistent engine (where it applies) whatever ITTS_ENGINE / the built-in default says (A/B, parity tests)."""
+        L.check(self.lib.itts_debug_enable(self.h, int(taps) | (int(force_simple) << 1) | (int(no_graph) << 2) | (int(fuse) << 3)
+                                           | (int(no_engine) << 4) | (int(engine) << 5)))
 
     def fetch_tap(self, name: str) -> np.ndarray:
         n = self.lib.itts_debug_fetch(self.h, name.encode(), None, 0)

@@ -280,7 +280,8 @@ def sample_pick(scores, top_k: int, top_p: float, temperature: float, u: float) 
 
 
 def greedy_generate(cond, text_inputs, w: W, cfg_gpt, max_generate_length: int, repetition_penalty: float = 10.0,
-                    suppress_eos: bool = False, trace: Optional[dict] = None, sampling: Optional[dict] = None):
+                    suppress_eos: bool = False, trace: Optional[dict] = None, sampling: Optional[dict] = None,
+                    input_tokens: Optional[torch.Tensor] = None):
     """UnifiedVoice.inference_speech (model.py:655-708) with HF 4.36.2 `generate` greedy_search semantics
     (do_sample False, num_beams 1; eos=pad=stop_mel_token; MaxLengthCriteria): hand-rolled because the
     installed transformers 5.x `generate` skips the prefill (SURVEY 8c 'Critical caveat').
@@ -290,13 +291,25 @@ def greedy_generate(cond, text_inputs, w: W, cfg_gpt, max_generate_length: int, 
     Returns codes [b, <=max_generate_length] (prefix stripped, model.py:704-705).
 
     sampling = {"top_k", "top_p", "temperature", "uniforms" [max_gen, b]} switches the pick to GenerationMixin.sample
-    (do_sample=True, num_beams=1) with the draws supplied as uniforms (sample_pick)."""
+    (do_sample=True, num_beams=1) with the draws supplied as uniforms (sample_pick).
+
+    input_tokens [b or 1, n] (model.py:672-686): given mel tokens are appended to the fake ids, so the FIRST forward embeds
+    [start_mel, t1..tn] with positions 0..n (model.py:141-144) and the first generated token is fed at position n + 2
+    (model.py:151-155); the returned codes start after the given tokens (trunc_index, model.py:687,704)."""
     stop = cfg_gpt["stop_mel_token"]
     fake, prefix, mask = prepare_gpt_inputs(cond, text_inputs, w, cfg_gpt)
     b, s, _ = prefix.shape
     ids = fake.clone()
+    n_in = 0
+    if input_tokens is not None:
+        it = torch.as_tensor(input_tokens).long()
+        it = it[None] if it.ndim == 1 else it
+        it = it.repeat(b // it.shape[0], 1)
+        n_in = it.shape[1]
+        ids = torch.cat([ids, it], dim=1)
+        mask = torch.cat([mask, torch.ones(b, n_in, dtype=mask.dtype)], dim=1)
     mel_emb, mel_pos = w["mel_embedding.weight"], w["mel_pos_embedding.emb.weight"]
-    start_emb = mel_emb[ids[:, s:]] + mel_pos[:1]
+    start_emb = mel_emb[ids[:, s:]] + mel_pos[: 1 + n_in]
     emb = torch.cat([prefix, start_emb], dim=1)
     h, past = gpt2_stack(emb, w, cfg_gpt, key_mask=mask)
     unfinished = torch.ones(b, dtype=torch.long)
@@ -309,7 +322,7 @@ def greedy_generate(cond, text_inputs, w: W, cfg_gpt, max_generate_length: int, 
         if suppress_eos:
             scores[:, stop] = -float("inf")
         if sampling is not None:
-            k_step = ids.shape[1] - (s + 1)
+            k_step = ids.shape[1] - (s + 1 + n_in)
             if sampling.get("typical_mass"):
                 from . import hf_beam
 
@@ -322,13 +335,13 @@ def greedy_generate(cond, text_inputs, w: W, cfg_gpt, max_generate_length: int, 
         ids = torch.cat([ids, nxt[:, None]], dim=1)
         mask = torch.cat([mask, torch.ones(b, 1, dtype=torch.long)], dim=1)
         unfinished = unfinished * (nxt != stop).long()
-        if unfinished.max() == 0 or ids.shape[1] >= s + 1 + max_generate_length:
+        if unfinished.max() == 0 or ids.shape[1] >= s + 1 + n_in + max_generate_length:
             break
         e = mel_emb[nxt][:, None] + mel_pos[mask.shape[1] - s][None, None]
         h, past = gpt2_stack(e, w, cfg_gpt, key_mask=mask, past=past)
     if trace is not None:
         trace["logits"] = torch.stack(out_logits, dim=1)
-    return ids[:, s + 1:]
+    return ids[:, s + 1 + n_in:]
 
 
 def latent_forward(cond, text_tokens, codes, w: W, cfg_gpt):

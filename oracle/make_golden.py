@@ -87,7 +87,7 @@ def build_ref_dvae(cfg, seed):
     return m
 
 
-def ref_greedy(gpt, cond_mel, text, max_gen, rep=10.0, n_trace=None, suppress_eos=False, trace_steps=None):
+def ref_greedy(gpt, cond_mel, text, max_gen, rep=10.0, n_trace=None, suppress_eos=False, trace_steps=None, input_tokens=None):
     """Hand-rolled HF-4.36.2-style greedy_search over the reference's own GPT2InferenceModel.forward
     (the installed transformers-5.x `generate` skips the prefill, so it is not used)."""
     from transformers import RepetitionPenaltyLogitsProcessor
@@ -98,6 +98,13 @@ def ref_greedy(gpt, cond_mel, text, max_gen, rep=10.0, n_trace=None, suppress_eo
     ids, emb, mask = gpt.prepare_gpt_inputs(conds, text)
     gpt.inference_model.store_mel_emb(emb)
     s = emb.shape[1]
+    n_in = 0
+    if input_tokens is not None:  # inference_speech, model.py:672-686
+        it = input_tokens[None] if input_tokens.ndim == 1 else input_tokens
+        it = it.repeat(ids.shape[0] // it.shape[0], 1)
+        n_in = it.shape[1]
+        ids = torch.cat([ids, it], dim=1)
+        mask = torch.nn.functional.pad(mask, (0, n_in), value=1)
     proc = RepetitionPenaltyLogitsProcessor(rep)
     past = None
     b = ids.shape[0]
@@ -127,10 +134,10 @@ def ref_greedy(gpt, cond_mel, text, max_gen, rep=10.0, n_trace=None, suppress_eo
         ids = torch.cat([ids, nxt[:, None]], dim=-1)
         mask = torch.cat([mask, torch.ones(b, 1, dtype=mask.dtype)], dim=-1)
         unfinished = unfinished * (nxt != stop).long()
-        if unfinished.max() == 0 or ids.shape[-1] >= s + 1 + max_gen:
+        if unfinished.max() == 0 or ids.shape[-1] >= s + 1 + n_in + max_gen:
             break
     ref_greedy.last_margins = torch.stack(margins, 1)
-    return ids[:, s + 1:], torch.stack(logits_trace, 1), conds, emb, mask[:, : s + 1]
+    return ids[:, s + 1 + n_in:], torch.stack(logits_trace, 1), conds, emb, mask[:, : s + 1]
 
 
 def ref_beam_sample(gpt, cond_mel, text, max_gen, uniforms, nb=3, top_k=30, top_p=0.8, temperature=1.0, rep=10.0,

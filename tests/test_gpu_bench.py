@@ -35,3 +35,8 @@ def test_bench_gpus2_self_launch_over_gloo():
     assert j2["n_gpus"] == 2
     a1, a2 = j1["config"]["audio_sec_per_step_per_gpu"], j2["config"]["audio_sec_per_step_per_gpu"]
     assert abs(a1 - a2) < 1e-6  # weak scaling: the per-GPU work is unchanged, `value` aggregates both ranks
+    # BASELINE config 4 (N x 32 utterances, data-parallel) rides in the same line at N > 1, config 3 at N = 1
+    c4 = j2["also"]["config4_batch32_per_gpu"]
+    assert c4["config"]["utterances_per_gpu"] == 32 and c4["n_gpus"] == 2 and c4["value"] > 0
+    assert j1["also"]["config3_batch32"]["config"]["utterances_per_gpu"] == 32 and "product_loop" in j1["also"]
+    assert j2["dist"]["world_size"] == 2 and j2["dist"]["backend"] == "gloo" and j2["dist"]["collectives_in_timed_region"] == 0

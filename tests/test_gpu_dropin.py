@@ -246,3 +246,58 @@ def test_infer_batch_equals_per_utterance_infer(tts):
         for i, u in enumerate(utts):
             sr, w = tts.infer(prompt_mel=mel, text=u, output_path=None, max_mel_tokens=6, do_sample=False, num_beams=1)
             assert batch[i][0] == sr and np.array_equal(batch[i][1], w), i
+
+
+def test_indextts_from_files(tts, tmp_path):
+    """The reference's construction path end to end (infer.py:42-76, utils/checkpoint.py:25-34): `config.yaml`,
+    `gpt.pth` = {"model": state_dict}, `bigvgan_generator.pth` = {"generator": state_dict with weight_g / weight_v pairs,
+    folded after load}, `bpe.model` - and `infer(text=<str>)` through the normaliser + SentencePiece front end."""
+    spm = pytest.importorskip("sentencepiece")
+    from indextts.infer import IndexTTS
+
+    gpt_sd = synth.gpt_state_dict(CFG, 1234)
+    bv_sd = synth.bigvgan_state_dict(CFG, 1234)
+    # un-fold weight norm the way torch.nn.utils.weight_norm stores it (dim 0): weight = g * v / ||v||
+    raw = {}
+    folded = 0
+    for k, v in bv_sd.items():
+        is_wn = k.endswith(".weight") and v.ndim == 3 and not k.startswith(("cond_layer", "conds.", "speaker_encoder"))
+        if is_wn:
+            scale = 0.5 + (np.arange(v.shape[0], dtype=np.float32) % 7)[:, None, None] / 4.0
+            vv = (v * scale).astype(np.float32)
+            raw[k[:-len("weight")] + "weight_v"] = torch.from_numpy(vv)
+            raw[k[:-len("weight")] + "weight_g"] = torch.from_numpy(
+                np.sqrt((v.astype(np.float64) ** 2).sum(axis=(1, 2), keepdims=True)).astype(np.float32))
+            folded += 1
+        else:
+            raw[k] = torch.from_numpy(np.asarray(v))
+    assert folded > 100
+    torch.save({"model": {k: torch.from_numpy(np.asarray(v)) for k, v in gpt_sd.items()}}, tmp_path / "gpt.pth")
+    torch.save({"generator": raw}, tmp_path / "bigvgan_generator.pth")
+    corpus = tmp_path / "corpus.txt"
+    corpus.write_text("\n".join(["HELLO WORLD THIS IS A TEST .", "你 好 世 界 , 今 天 天 气 很 好 .", "GOOD MORNING , HOW ARE YOU ?"] * 20))
+    spm.SentencePieceTrainer.train(input=str(corpus), model_prefix=str(tmp_path / "bpe"), vocab_size=60, model_type="bpe",
+                                   character_coverage=1.0, bos_id=0, eos_id=1, unk_id=2, pad_id=-1, hard_vocab_limit=False)
+    cfg = icfg.micro()
+    cfg["gpt_checkpoint"], cfg["bigvgan_checkpoint"] = "gpt.pth", "bigvgan_generator.pth"
+    cfg["dataset"] = {"bpe_model": "bpe.model"}
+    icfg.dump_yaml(cfg, str(tmp_path / "config.yaml"))
+    with pytest.warns(RuntimeWarning):  # WeTextProcessing is not installed here: the documented degraded mode
+        ftts = IndexTTS(str(tmp_path / "config.yaml"), str(tmp_path), is_fp16=False)
+    assert ftts.normalizer is not None and ftts.tokenizer.normalizer is ftts.normalizer
+    mel = torch.from_numpy(synth.prompt_mel(61, seed=7))
+    sents = [synth.text_ids(11, 11, CFG.gpt.number_text_tokens).astype(np.int32)]
+    kw = dict(do_sample=False, num_beams=1, max_mel_tokens=24)
+    sr, a = ftts.infer(mel, sents, None, **kw)
+    _, b = tts.infer(mel, sents, None, **kw)
+    assert sr == 24000 and a.shape == b.shape
+    d = (a.astype(np.float64) - b.astype(np.float64))
+    assert np.sqrt((d ** 2).mean()) <= 2e-3 * np.sqrt((b.astype(np.float64) ** 2).mean()) + 1.0  # weight-norm fold: fp32 rounding only
+    # a string goes through TextNormalizer (punctuation folding, "'s" expansion) and the BPE model of the checkpoint dir
+    text = "Hello world； this is a test。"
+    pieces = ftts.tokenizer.tokenize(text)
+    assert pieces and "；" not in "".join(pieces) and "。" not in "".join(pieces)
+    ids = [np.asarray(ftts.tokenizer.convert_tokens_to_ids(s), dtype=np.int32) for s in ftts.tokenizer.split_sentences(pieces, 120)]
+    _, w_str = ftts.infer(mel, text, None, **kw)
+    _, w_ids = ftts.infer(mel, ids, None, **kw)
+    assert np.array_equal(w_str, w_ids)

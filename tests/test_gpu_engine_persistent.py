@@ -1,0 +1,79 @@
+"""GPU: the persistent decode engine (csrc/decode_engine.hip: the 24 blocks of a token step as ONE launch, <= 2 rows,
+bf16) against the launch path it replaces (gemv_bf16_kernel + decode_attn2_kernel, five launches a layer): the engine
+repeats the launch path's arithmetic operation for operation, so ids AND logits have to be bit-identical - at 1 and 2
+rows, under graph replay and eager launches, through the register window of the cache attention and past it.
+Reference hot loop: indextts/gpt/model.py:115-192."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from itts_hip import config as icfg  # noqa: E402
+from itts_hip import engine as ieng  # noqa: E402
+from itts_hip import synth  # noqa: E402
+
+CFG = icfg.indextts_1_5()
+
+
+@pytest.fixture(scope="module")
+def eng16():
+    return ieng.build_engine(CFG, "bf16", parts=("gpt",))
+
+
+@pytest.fixture(scope="module")
+def cond(eng16):
+    return eng16.conditioning(torch.from_numpy(synth.prompt_mel(511, seed=7)))
+
+
+def run(eng, cond, text, steps, no_engine, no_graph=False, chunk=8):
+    eng.debug(no_engine=no_engine, engine=not no_engine, no_graph=no_graph)
+    try:
+        eng.prefill(cond, text, steps, 10.0, True)
+        done = 1
+        while done < steps:
+            n = min(chunk, steps - done)
+            eng.decode(n)
+            done += n
+        codes, lg = eng.fetch(logits=True)
+        eng._exit()
+    finally:
+        eng.debug()
+    return codes, lg
+
+
+@pytest.mark.parametrize("rows", [1, 2])
+def test_engine_equals_launch_path_bitwise(eng16, cond, rows):
+    text = np.stack([synth.text_ids(105, 11 + r, CFG.gpt.number_text_tokens) for r in range(rows)]).astype(np.int32)
+    ref_codes, ref_lg = run(eng16, cond, text, 64, no_engine=True)
+    codes, lg = run(eng16, cond, text, 64, no_engine=False)
+    assert np.array_equal(codes, ref_codes)
+    assert np.array_equal(lg.view(np.uint32), ref_lg.view(np.uint32)), float(np.abs(lg - ref_lg).max())
+    # eager launches of the same kernel (no graph): same bits again
+    codes2, lg2 = run(eng16, cond, text, 24, no_engine=False, no_graph=True)
+    assert np.array_equal(codes2, ref_codes[:, :24])
+
+
+def test_engine_ragged_rows_and_long_sequence(eng16, cond):
+    """Two rows of different text lengths (left padding -> kv_start) decoded far past the 768-key register window of the
+    cache attention (prefix 139 + 700 steps): the streaming part of every key split runs."""
+    t0 = synth.text_ids(105, 21, CFG.gpt.number_text_tokens)
+    t1 = synth.text_ids(60, 22, CFG.gpt.number_text_tokens)
+    stop = CFG.gpt.stop_text_token
+    text = np.full((2, 105), stop, np.int32)  # start/stop text ids are stripped and left-padded by the prefix builder
+    text[0] = t0
+    text[1, :60] = t1
+    ref_codes, ref_lg = run(eng16, cond, text, 700, no_engine=True, chunk=64)
+    codes, lg = run(eng16, cond, text, 700, no_engine=False, chunk=64)
+    assert np.array_equal(codes, ref_codes)
+    assert np.array_equal(lg.view(np.uint32), ref_lg.view(np.uint32))
+
+
+def test_engine_status_reports_no_timeout(eng16, cond):
+    text = synth.text_ids(105, 31, CFG.gpt.number_text_tokens).reshape(1, -1).astype(np.int32)
+    eng16.debug(engine=True)
+    try:
+        codes = eng16.generate(cond, text, 40)  # eos enabled: status() every 16 steps reads the engine's abort word
+    finally:
+        eng16.debug()
+    assert codes.shape[0] == 1 and codes.shape[1] >= 1
