@@ -87,7 +87,7 @@ struct Rt {
 // debugging aid (EngArgs::stamp): wall-clock (100 MHz) stamp i of block l of this workgroup
 #define ENG_STAMP(i)                                                                                              \
   if (a.stamp && (tl & 63) == 0 && (i < 8 ? tl == 0 : tl == 256))                                                \
-    a.stamp[((size_t)cu * a.NL + l) * 12 + (i)] = (unsigned)__builtin_amdgcn_s_memrealtime();
+    a.stamp[((size_t)cu * a.NL + l) * 16 + (i)] = (unsigned)__builtin_amdgcn_s_memrealtime();
 
 __device__ __forceinline__ u64 ld_gran(const u64* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st_gran(u64* p, unsigned tag, uint32_t v) {
@@ -96,7 +96,9 @@ __device__ __forceinline__ void st_gran(u64* p, unsigned tag, uint32_t v) {
 
 __device__ __forceinline__ bool spin_fail(Rt& rt, unsigned& spins) {
   if ((++spins & 15u) != 0) return false;
-  const bool ab = __hip_atomic_load(rt.ctr + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+  unsigned abw;  // asm load + wait: no load the compiler counts in a gather path (see "gathering an edge" below)
+  asm volatile("global_load_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(abw) : "v"(rt.ctr + 1) : "memory");
+  const bool ab = abw != 0;
   const bool to = (u64)(__builtin_amdgcn_s_memrealtime() - rt.t0) > (u64)rt.limit;
   if (ab || to) {
     if (!ab) __hip_atomic_store(rt.ctr + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -106,47 +108,80 @@ __device__ __forceinline__ bool spin_fail(Rt& rt, unsigned& spins) {
   return false;
 }
 
-// One gather thread (gt = 0..255) collects granules gt, gt + 256, ... < n of an edge: CH loads in flight, only the
-// granules whose tag has not matched yet are requested again.  sink(index, value) runs once per granule.
-template <int PER, int CH, typename Sink>
-__device__ __forceinline__ void sweep(const u64* __restrict__ g, int n, int gt, Rt& rt, Sink&& sink) {
-  // stage 1: while the edge's producers are still computing, ONE lane of each gather wave polls ONE granule (a different
-  // producer per wave) - 256 workgroups x 2560 requests per pass would otherwise compete with the producers' own weight
-  // stream and stores for the fabric (MI355X_MICROARCH "polling-cost")
-  {
+// ---- gathering an edge ----
+// The gather waves never hold a load hipcc knows about: every poll is an asm load with its own wait.  (A load the
+// compiler counts leaves "a write to these VGPRs may be pending" in its scoreboard at the join with the compute waves'
+// path, and it then guards the next reuse of those registers with s_waitcnt vmcnt(0) - in front of the compute waves'
+// LDS-DMA issue that drained the weight prefetch at every phase: 2 us per phase on the timeline.)
+__device__ __forceinline__ u32x4 ld_gran2(const u64* p) {  // two adjacent granules, one 16-byte agent-scope load
+  u32x4 x;
+  asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(x) : "v"(p) : "memory");
+  return x;
+}
+__device__ __forceinline__ u64 ld_gran1(const u64* p) {
+  u64 x;
+  asm volatile("global_load_dwordx2 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(x) : "v"(p) : "memory");
+  return x;
+}
+__device__ __forceinline__ void ld_wait() {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+// LDS counter of the compute waves' finished phases: a workgroup's own publish is the best local estimate of "the edge
+// is being published chip-wide", so a gather starts its first pass then instead of polling a sentinel over the fabric
+__device__ __forceinline__ void wait_own(unsigned ctr_lds, unsigned target, Rt& rt) {  // ctr_lds: LDS byte address
+  unsigned spins = 0;
+  while (!rt.dead) {
+    unsigned v;
+    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(ctr_lds) : "memory");
+    if (v >= target) break;
+    if (spin_fail(rt, spins)) break;
+    __builtin_amdgcn_s_sleep(1);
+  }
+}
+
+// One gather thread (gt = 0..255) collects the granule PAIRS gt, gt + 256, ... < npairs of an edge: every load of a pass
+// in flight at once, passes repeated (with a pause) until every tag matches.  sink(granule index, value) runs once per
+// granule.  SENTINEL: nothing local says when the edge will be published (the context edge on a workgroup that runs no
+// attention), so ONE lane per wave polls ONE granule first - a full pass per workgroup, repeated while the producers are
+// still computing, competes with their weight stream and stores for the fabric (MI355X_MICROARCH "polling-cost").
+template <int PER, bool SENTINEL, typename Sink>
+__device__ __forceinline__ void sweep2(const u64* __restrict__ g, int npairs, int gt, Rt& rt, Sink&& sink) {
+  if (SENTINEL) {
     const int w = gt >> 6;
-    const u64* __restrict__ p = g + min(n - 1, (n / 4) * w + n / 8);
+    const u64* __restrict__ p = g + 2 * min(npairs - 1, (npairs / 4) * w + npairs / 8);
     unsigned spins = 0;
     bool ok = rt.dead || (gt & 63) != 0;
     while (!ok) {
-      ok = (unsigned)(ld_gran(p) >> 32) == rt.tag;
+      ok = (unsigned)(ld_gran1(p) >> 32) == rt.tag;
       if (ok || spin_fail(rt, spins)) break;
       __builtin_amdgcn_s_sleep(2);
     }
   }
+  unsigned need = 0;
 #pragma unroll
-  for (int j0 = 0; j0 < PER; j0 += CH) {
-    unsigned need = 0;
+  for (int j = 0; j < PER; ++j)
+    if (gt + 256 * j < npairs) need |= 1u << j;
+  if (rt.dead) need = 0;
+  unsigned spins = 0;
+  while (need) {
+    u32x4 x[PER];
 #pragma unroll
-    for (int jj = 0; jj < CH; ++jj)
-      if (j0 + jj < PER && gt + 256 * (j0 + jj) < n) need |= 1u << jj;
-    if (rt.dead) need = 0;
-    unsigned spins = 0;
-    while (need) {
-      u64 x[CH];
+    for (int j = 0; j < PER; ++j) x[j] = ld_gran2(g + 2 * min(gt + 256 * j, npairs - 1));
+    ld_wait();
 #pragma unroll
-      for (int jj = 0; jj < CH; ++jj)
-        if (j0 + jj < PER && ((need >> jj) & 1u)) x[jj] = ld_gran(g + gt + 256 * (j0 + jj));
-#pragma unroll
-      for (int jj = 0; jj < CH; ++jj)
-        if (j0 + jj < PER && ((need >> jj) & 1u) && (unsigned)(x[jj] >> 32) == rt.tag) {
-          sink(gt + 256 * (j0 + jj), (uint32_t)x[jj]);
-          need &= ~(1u << jj);
-        }
-      if (!need) break;
-      if (spin_fail(rt, spins)) break;
-      __builtin_amdgcn_s_sleep(1);
+    for (int j = 0; j < PER; ++j) {
+      asm volatile("" : "+v"(x[j]));
+      if (((need >> j) & 1u) && x[j][1] == rt.tag && x[j][3] == rt.tag) {
+        sink(2 * (gt + 256 * j), x[j][0]);
+        sink(2 * (gt + 256 * j) + 1, x[j][2]);
+        need &= ~(1u << j);
+      }
     }
+    if (!need) break;
+    if (spin_fail(rt, spins)) break;
+    __builtin_amdgcn_s_sleep(1);
   }
 }
 
@@ -329,8 +364,10 @@ __global__ __launch_bounds__(1024) void decode_engine_kernel(EngArgs a) {
   float* slx = smx + 16;                                            // [16]
   float* po = slx + 16;                                             // [4][64] partial of each key split
   float* pml = po + NSPLIT * DH;                                    // [2][4]
+  unsigned* own = reinterpret_cast<unsigned*>(pml + 8);             // [1] phases finished by the compute waves (x NCW)
   const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
   const unsigned S0 = lds0, S1 = lds0 + SLOT;
+  const unsigned own_lds = lds0 + (unsigned)(reinterpret_cast<unsigned char*>(own) - smem);
 
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -345,20 +382,32 @@ __global__ __launch_bounds__(1024) void decode_engine_kernel(EngArgs a) {
 
   Rt rt;
   rt.t0 = __builtin_amdgcn_s_memrealtime();
+  const u64 clk0 = __builtin_amdgcn_s_memtime();
   rt.limit = a.timeout_ticks;
   rt.ctr = a.ctr;
   rt.dead = false;
-  rt.tag = a.ctr[0];
-  const EngLayerW* __restrict__ LW = a.layers;
-  const int prefix = a.prefix[0];
+  // every value the kernel loads once is read to an SGPR HERE (readfirstlane waits for it): a load still "maybe pending" at
+  // the head of the layer loop makes hipcc guard its first use in every iteration with s_waitcnt vmcnt(0) - which at run
+  // time also drains the weight prefetch this wave has just issued
+  rt.tag = __builtin_amdgcn_readfirstlane(a.ctr[0]);
+  const int prefix = __builtin_amdgcn_readfirstlane(a.prefix[0]);
+  const int my_pos = acu ? __builtin_amdgcn_readfirstlane(prefix + a.len[acu ? gm : 0]) : 0;  // cache row this step appends
+  const int my_ks = acu ? __builtin_amdgcn_readfirstlane(a.kv_start[acu ? gm : 0]) : 0;
 
-  if (!gw && qcu) dma_rows<QO, D, NCW>(LW[0].wa, LW[0].ba, an0, S0, cw, lane);
+  if (t == 0) *own = 0;
+  unsigned phase = 0;  // compute phases finished so far (every wave counts alike)
+  auto phase_done = [&](int ln_) {  // a compute wave is through a phase: its publishes are issued
+    if (!gw && ln_ == 0) __hip_atomic_fetch_add(own, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    ++phase;
+  };
+  if (!gw && qcu) dma_rows<QO, D, NCW>(a.L[0].wa, a.L[0].ba, an0, S0, cw, lane);
   if (t < NB * HO) hown[(t / HO) * 8 + t % HO] = a.h[(size_t)(t / HO) * D + cu * HO + t % HO];
 
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): nothing the compiler counts is pending at the head of the layer loop
   constexpr size_t LSTRIDE = (size_t)NB * D * 15 / 2;
   constexpr size_t OQKV = 0, OCTX = (size_t)NB * 3 * D, OH1 = OCTX + NB * D / 2, OACT = OH1 + NB * D, OH2 = OACT + NB * 2 * D;
   for (int l = 0; l < a.NL; ++l) {
-    const EngLayerW w = LW[l];
+    const EngLayerW& w = a.L[l];
     // per-thread indices re-derived from an opaque copy each layer: hipcc otherwise hoists every per-thread address of
     // the five phases out of the layer loop and spills them (53 VGPRs of scratch traffic inside the hand-off waits)
     int tl = t;
@@ -370,8 +419,10 @@ __global__ __launch_bounds__(1024) void decode_engine_kernel(EngArgs a) {
     if (gw) {
       if (l == 0) {
         for (int i = tl; i < NB * D; i += 256) xf[i] = a.h[i];
+        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): nothing the compiler counts stays pending past the gather branch
       } else {
-        sweep<(NB * D + 255) / 256, 10>(G - LSTRIDE + OH2, NB * D, tl, rt, [&](int i, uint32_t v) { xf[i] = __uint_as_float(v); });
+        wait_own(own_lds, NCW * phase, rt);
+        sweep2<(NB * D / 2 + 255) / 256, false>(G - LSTRIDE + OH2, NB * D / 2, tl, rt, [&](int i, uint32_t v) { xf[i] = __uint_as_float(v); });
       }
     } else {
       dma_wait();  // c_attn rows of this layer (requested one phase ago)
@@ -404,6 +455,7 @@ __global__ __launch_bounds__(1024) void decode_engine_kernel(EngArgs a) {
       }
     }
 
+    phase_done(ll);
     ENG_STAMP(8)
     // ================= P2: cache attention of (row gm, head gh) =================
     if (acu) {
@@ -420,9 +472,7 @@ __global__ __launch_bounds__(1024) void decode_engine_kernel(EngArgs a) {
         kr[u].load(kb + (size_t)j * DH + sub * VEC);
         vr[u].load(vb + (size_t)j * DH + sub * VEC);
       }
-      const int pos = prefix + a.len[gm];
-      const int S = pos + 1;
-      const int ks = a.kv_start[gm];
+      const int pos = my_pos, S = pos + 1, ks = my_ks;
 #pragma unroll
       for (int u = UNC; u < 2 * NIT; ++u)
         if ((u * NSPLIT + sp) * SLOTS < S) {
@@ -433,9 +483,10 @@ __global__ __launch_bounds__(1024) void decode_engine_kernel(EngArgs a) {
       __builtin_amdgcn_sched_barrier(0);
       if (gw && tl < 3 * DH) {  // q / k / v of this (row, head): 192 granules, one per thread
         const u64* __restrict__ p = G + OQKV + (size_t)gm * 3 * D + (tl / DH) * D + gh * DH + tl % DH;
+        wait_own(own_lds, NCW * phase, rt);
         unsigned spins = 0;
         while (!rt.dead) {
-          const u64 x = ld_gran(p);
+          const u64 x = ld_gran1(p);
           if ((unsigned)(x >> 32) == rt.tag) {
             qkvs[tl] = __uint_as_float((uint32_t)x);
             break;
@@ -604,13 +655,16 @@ __global__ __launch_bounds__(1024) void decode_engine_kernel(EngArgs a) {
 
     // ================= P3: context -> c_proj + residual =================
     if (gw) {
-      sweep<(NB * D / 2 + 255) / 256, 10>(G + OCTX, NB * D / 2, tl, rt, [&](int i, uint32_t v) { xc[i] = v; });
+      if (acu)
+        sweep2<(NB * D / 4 + 255) / 256, false>(G + OCTX, NB * D / 4, tl, rt, [&](int i, uint32_t v) { xc[i] = v; });
+      else
+        sweep2<(NB * D / 4 + 255) / 256, true>(G + OCTX, NB * D / 4, tl, rt, [&](int i, uint32_t v) { xc[i] = v; });
     } else {
       dma_wait();  // c_proj rows
     }
     ENG_STAMP(4)
     __syncthreads();
-    if (!gw) dma_rows<FO, D, NCW>(w.wf, w.bf, cu * FO, S0, cw, ll);  // c_fc, one phase ahead (c_attn's slot)
+    ENG_STAMP(12)
     if (!gw && cw < HO) {
       float acc[NB];
 #pragma unroll
@@ -622,6 +676,7 @@ __global__ __launch_bounds__(1024) void decode_engine_kernel(EngArgs a) {
         const float x = wave_sum_rl(acc[b]);
         mine = ll == b ? x : mine;
       }
+      ENG_STAMP(14)
       if (ll < NB) {
         const float hn = hown[ll * 8 + cw] + (mine + reinterpret_cast<const float*>(W1)[cw]);
         hown[ll * 8 + cw] = hn;
@@ -629,11 +684,16 @@ __global__ __launch_bounds__(1024) void decode_engine_kernel(EngArgs a) {
         if (a.dbg && l == a.dbg_layer) a.dbg[(size_t)NB * 3 * D + (size_t)ll * D + cu * HO + cw] = hn;
       }
     }
-
+    phase_done(ll);
     ENG_STAMP(9)
+    // c_fc, one phase ahead (into c_attn's slot), requested AFTER this phase's publish: a CU issues ~1 KiB of LDS-DMA per
+    // 10 ns, so the 50 KB of a projection hold the issuing waves for 0.5 - 0.8 us (timeline) - off the edge's critical path here
+    if (!gw) dma_rows<FO, D, NCW>(w.wf, w.bf, cu * FO, S0, cw, ll);
+    ENG_STAMP(13)
     // ================= P4: residual stream -> LN2 -> c_fc -> gelu_new =================
     if (gw) {
-      sweep<(NB * D + 255) / 256, 10>(G + OH1, NB * D, tl, rt, [&](int i, uint32_t v) { xf[i] = __uint_as_float(v); });
+      wait_own(own_lds, NCW * phase, rt);
+      sweep2<(NB * D / 2 + 255) / 256, false>(G + OH1, NB * D / 2, tl, rt, [&](int i, uint32_t v) { xf[i] = __uint_as_float(v); });
     } else {
       dma_wait();  // c_fc rows
     }
@@ -669,17 +729,18 @@ __global__ __launch_bounds__(1024) void decode_engine_kernel(EngArgs a) {
       }
     }
 
+    phase_done(ll);
     ENG_STAMP(10)
     // ================= P5: gelu(fc) -> mlp.c_proj + residual =================
     if (gw) {
-      sweep<(NB * 2 * D + 255) / 256, 10>(G + OACT, NB * 2 * D, tl, rt, [&](int i, uint32_t v) { xa[i] = v; });
+      wait_own(own_lds, NCW * phase, rt);
+      sweep2<(NB * D + 255) / 256, false>(G + OACT, NB * D, tl, rt, [&](int i, uint32_t v) { xa[i] = v; });
     } else {
       dma_wait();  // mlp.c_proj rows
     }
     ENG_STAMP(6)
     __syncthreads();
     ENG_STAMP(7)
-    if (!gw && qcu && l + 1 < a.NL) dma_rows<QO, D, NCW>(LW[l + 1].wa, LW[l + 1].ba, an0, S0, cw, ll);  // next layer's c_attn
     if (!gw && cw < HO) {
       float acc[NB];
 #pragma unroll
@@ -701,11 +762,17 @@ __global__ __launch_bounds__(1024) void decode_engine_kernel(EngArgs a) {
           a.h[(size_t)ll * D + cu * HO + cw] = hn;
       }
     }
+    phase_done(ll);
     ENG_STAMP(11)
+    if (!gw && qcu && l + 1 < a.NL) dma_rows<QO, D, NCW>(a.L[l + 1].wa, a.L[l + 1].ba, an0, S0, cw, ll);  // next layer's c_attn
   }
   // advance the step counter (never 0): every workgroup read it before its first publish, and this workgroup got here
   // only after gathering from all of them
   if (cu == 0 && t == 0) a.ctr[0] = rt.tag + 1 == 0 ? 1u : rt.tag + 1;
+  if (a.stamp && t == 0) {  // shader clock over the launch: cycles per 10 ns tick, x 1000 (stamp 15 of block 0)
+    const u64 c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    a.stamp[(size_t)cu * a.NL * 16 + 15] = (unsigned)((c1 - clk0) * 1000 / (r1 - rt.t0 + 1));
+  }
 }
 
 }  // namespace
@@ -713,7 +780,7 @@ __global__ __launch_bounds__(1024) void decode_engine_kernel(EngArgs a) {
 size_t eng_gran_count(int layers) { return (size_t)layers * 4 * ENG_D * 15 / 2; }
 
 int decode_engine_layers(const EngArgs& a, hipStream_t s) {
-  ITTS_REQUIRE(a.B >= 1 && a.B <= ENG_MAX_ROWS && a.layers && a.gran && a.h && a.kc && a.vc && a.ctr, "decode_engine: bad arguments");
+  ITTS_REQUIRE(a.B >= 1 && a.B <= ENG_MAX_ROWS && a.NL >= 1 && a.NL <= ENG_MAX_LAYERS && a.gran && a.h && a.kc && a.vc && a.ctr, "decode_engine: bad arguments");
   const size_t lds = 152 * 1024;  // weight slots + edge buffers: one workgroup per CU
 #define ITTS_ENG_GO(NB)                                                                                                         \
   {                                                                                                                             \

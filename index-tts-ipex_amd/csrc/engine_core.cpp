@@ -11,7 +11,7 @@ Engine::~Engine() {
   if (gpt_tiles) (void)hipFree(gpt_tiles);
   DecodeState& d = ds;
   void* ptrs[] = {d.kc, d.vc, d.h, d.qkv, d.ctx, d.act, d.hn, d.logits, d.len, d.prefix_dev,
-                  d.kv_start, d.cur_tok, d.ids, d.unfinished, d.seen, d.partial, d.attn_o, d.attn_ml, d.uniforms, d.forced, d.scores2, d.gran, d.fuse_err, d.eng_layers, d.eng_gran, d.eng_ctr, d.beam_ids, d.anc, d.beam_scores, d.cand_sc, d.cand_tok, d.cand_n, d.hyp_tok,
+                  d.kv_start, d.cur_tok, d.ids, d.unfinished, d.seen, d.partial, d.attn_o, d.attn_ml, d.uniforms, d.forced, d.scores2, d.gran, d.fuse_err, d.eng_gran, d.eng_ctr, d.beam_ids, d.anc, d.beam_scores, d.cand_sc, d.cand_tok, d.cand_n, d.hyp_tok,
                   d.hyp_score, d.hyp_len, d.hyp_order, d.hyp_n, d.hyp_worst, d.hyp_counter, d.beam_done};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);

@@ -5,6 +5,7 @@
 namespace itts {
 
 constexpr int ENG_D = 1280, ENG_H = 20, ENG_NCU = 256, ENG_MAX_ROWS = 2;
+constexpr int ENG_MAX_LAYERS = 24;
 constexpr bool ENG_DEFAULT_ON = false;  // ITTS_ENGINE=1 / 0 overrides  // IndexTTS-1.5 GPT on the 256 CUs of an MI355X
 
 struct EngLayerW {  // one GPT-2 block: bf16 [N][K] projections (LayerNorm affine folded in by the packer), fp32 biases
@@ -13,7 +14,9 @@ struct EngLayerW {  // one GPT-2 block: bf16 [N][K] projections (LayerNorm affin
 };
 
 struct EngArgs {
-  const EngLayerW* layers = nullptr;  // device table [NL]
+  EngLayerW L[ENG_MAX_LAYERS];        // in the kernel-argument segment: block l's pointers are scalar loads (a table in global
+                                      // memory is re-read with VECTOR loads wherever hipcc cannot prove it unaliased - a dependent
+                                      // memory latency, and a vmcnt(0) in front of the weight-prefetch issue, in every phase)
   unsigned long long* gran = nullptr; // hand-off granules: eng_gran_count(NL) words, zeroed once at allocation
   float* h = nullptr;                 // residual stream [B][D]: this step's input embedding in, last block's output out
   bf16_t* kc = nullptr;               // KV cache [NL][B][H][Smax][64]

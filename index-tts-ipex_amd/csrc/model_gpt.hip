@@ -172,7 +172,7 @@ bool Engine::engine_usable() const {
   const itts_config& c = cfg;
   if ((env_off && !ds.eng_force) || ds.eng_off || ds.eng_failed || ncu != ENG_NCU) return false;
   if (adt != BF16 || ds.B < 1 || ds.B > ENG_MAX_ROWS || ds.nb != 1) return false;
-  if (c.model_dim != ENG_D || c.heads != ENG_H || c.layers < 1 || ds.Smax > 2048 || ds.Smax % 256 != 0) return false;
+  if (c.model_dim != ENG_D || c.heads != ENG_H || c.layers < 1 || c.layers > ENG_MAX_LAYERS || ds.Smax > 2048 || ds.Smax % 256 != 0) return false;
   for (const GptLayerW& L : gpt.layers)
     for (const Lin* l : {&L.attn, &L.proj, &L.fc, &L.proj2})
       if (l->dt != BF16 || l->w8 || !l->b || l->taps != 1) return false;
@@ -181,26 +181,21 @@ bool Engine::engine_usable() const {
 
 int Engine::ensure_engine_state(hipStream_t s) {
   DecodeState& d = ds;
-  if (d.eng_layers) return OK;
+  if (d.eng_gran) return OK;
   const itts_config& c = cfg;
-  std::vector<EngLayerW> tab(c.layers);
   for (int l = 0; l < c.layers; ++l) {
     const GptLayerW& L = gpt.layers[l];
     ITTS_REQUIRE(L.attn.N == 3 * ENG_D && L.attn.Cin == ENG_D && L.proj.N == ENG_D && L.proj.Cin == ENG_D &&
                      L.fc.N == 4 * ENG_D && L.fc.Cin == ENG_D && L.proj2.N == ENG_D && L.proj2.Cin == 4 * ENG_D,
                  "decode engine: projection shapes");
-    tab[l] = {(const bf16_t*)L.attn.w, (const bf16_t*)L.proj.w, (const bf16_t*)L.fc.w, (const bf16_t*)L.proj2.w,
-              L.attn.b, L.proj.b, L.fc.b, L.proj2.b};
   }
-  ITTS_TRY(dev_alloc((void**)&d.eng_layers, tab.size() * sizeof(EngLayerW)));
   const size_t gb = eng_gran_count(c.layers) * 8;
   ITTS_TRY(dev_alloc((void**)&d.eng_gran, gb));
   ITTS_TRY(dev_alloc((void**)&d.eng_ctr, 64));
   const unsigned ctr0[16] = {1u, 0u};
-  ITTS_HIP_CHECK(hipMemcpyAsync(d.eng_layers, tab.data(), tab.size() * sizeof(EngLayerW), hipMemcpyHostToDevice, s));
   ITTS_HIP_CHECK(hipMemsetAsync(d.eng_gran, 0, gb, s));  // tag 0 is never issued
   ITTS_HIP_CHECK(hipMemcpyAsync(d.eng_ctr, ctr0, 64, hipMemcpyHostToDevice, s));
-  ITTS_HIP_CHECK(hipStreamSynchronize(s));  // tab / ctr0 are host stack buffers
+  ITTS_HIP_CHECK(hipStreamSynchronize(s));  // ctr0 is a host stack buffer
   return OK;
 }
 
@@ -677,9 +672,13 @@ int Engine::decode_step_launch(hipStream_t s) {
   ds.pend_split = 0;
   int eng_first = 0;
   if (engine_usable()) {  // <= 4 rows: the 24 blocks as ONE persistent launch, then the head + sampler launches
-    ITTS_REQUIRE(ds.eng_layers && ds.eng_gran && ds.eng_ctr, "decode engine: state not allocated (prefill first)");
+    ITTS_REQUIRE(ds.eng_gran && ds.eng_ctr, "decode engine: state not allocated (prefill first)");
     EngArgs ea;
-    ea.layers = ds.eng_layers;
+    for (int l = 0; l < c.layers; ++l) {
+      const GptLayerW& L = gpt.layers[l];
+      ea.L[l] = {(const bf16_t*)L.attn.w, (const bf16_t*)L.proj.w, (const bf16_t*)L.fc.w, (const bf16_t*)L.proj2.w,
+                 L.attn.b, L.proj.b, L.fc.b, L.proj2.b};
+    }
     ea.gran = ds.eng_gran;
     ea.h = ds.h;
     ea.kc = (bf16_t*)ds.kc;
@@ -701,9 +700,9 @@ int Engine::decode_step_launch(hipStream_t s) {
       ea.dbg_layer = e_tap;
     }
     static const bool e_stamps = getenv("ITTS_ENGINE_STAMPS") != nullptr;
-    if (debug && e_stamps && !dry) ea.stamp = (unsigned*)ds.logits + 0;  // [16][V] fp32 scratch >= 256 * 24 * 12 words; the head overwrites it later
+    if (debug && e_stamps && !dry) ea.stamp = (unsigned*)ds.logits + 0;  // [16][V] fp32 scratch >= 256 * 24 * 16 words; the head overwrites it later
     if (eng_first > 0) ITTS_TRY(decode_engine_layers(ea, s));
-    if (ea.stamp) ITTS_TRY(tap("eng_stamps", ea.stamp, F32, (int64_t)ENG_NCU * eng_first * 12, s));
+    if (ea.stamp) ITTS_TRY(tap("eng_stamps", ea.stamp, F32, (int64_t)ENG_NCU * eng_first * 16, s));
     if (ea.dbg) {
       ITTS_TRY(tap("eng_qkv", ea.dbg, F32, (int64_t)B * 3 * D, s));
       ITTS_TRY(tap("eng_h1", ea.dbg + (size_t)B * 3 * D, F32, (int64_t)B * D, s));

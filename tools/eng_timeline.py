@@ -27,7 +27,7 @@ eng.debug(taps=True, no_graph=True)
 eng.decode(1)
 eng.fetch()
 eng._exit()
-st = eng.fetch_tap("eng_stamps").view(np.uint32).reshape(256, -1, 12).astype(np.int64)
+st = eng.fetch_tap("eng_stamps").view(np.uint32).reshape(256, -1, 16).astype(np.int64)
 eng.debug()
 NL = st.shape[1]
 t0 = st[:, 0, 0].min()
@@ -44,7 +44,12 @@ for l in (1, NL // 2, NL - 2):
         if i in (2, 3):
             v = v[acu]
         print(f"   {names[i]:26s} min {v.min():6.2f}  median {np.median(v):6.2f}  max {v.max():6.2f}")
-mx = us.max(axis=0)  # [NL][12] last WG
+clk = st[:, 0, 15]
+print(f"shader clock over the launch: {np.median(clk) / 10.0:.0f} MHz (min {clk.min() / 10.0:.0f}, max {clk.max() / 10.0:.0f})")
+d = us[:, 2:NL - 1, :]
+print("-- c_proj phase of a compute wave (mean over WGs and blocks): E3 gathered -> after B3 %.2f -> dots + wave sums %.2f -> published %.2f -> c_fc DMA issued %.2f us"
+      % ((d[:, :, 12] - d[:, :, 4]).mean(), (d[:, :, 14] - d[:, :, 12]).mean(), (d[:, :, 9] - d[:, :, 14]).mean(), (d[:, :, 13] - d[:, :, 9]).mean()))
+mx = us.max(axis=0)  # [NL][16] last WG
 mx[:, 3] = us[acu][:, :, 3].max(axis=0)
 seq = [(0, "E1 all gathered"), (8, "qkv all published"), (3, "ctx all published"), (4, "E3 all gathered"), (9, "h1 all published"),
        (5, "E4 all gathered"), (10, "act all published"), (6, "E5 all gathered"), (11, "h2 all published")]
