@@ -82,6 +82,7 @@ struct Rt {
   u64 t0;
   unsigned limit;
   unsigned* ctr;  // [0] step counter (tag), [1] abort word
+  int first_delay, pass_sleep;  // s_sleep units before the first pass of a gather / between passes
 };
 
 // debugging aid (EngArgs::stamp): wall-clock (100 MHz) stamp i of block l of this workgroup
@@ -165,10 +166,13 @@ __device__ __forceinline__ void sweep2(const u64* __restrict__ g, int npairs, in
     if (gt + 256 * j < npairs) need |= 1u << j;
   if (rt.dead) need = 0;
   unsigned spins = 0;
+  // a publish needs ~0.65 us to become visible chip-wide: a pass started earlier fails AND slows the stores it waits for
+  for (int z = 0; z < rt.first_delay; ++z) __builtin_amdgcn_s_sleep(1);
   while (need) {
     u32x4 x[PER];
 #pragma unroll
-    for (int j = 0; j < PER; ++j) x[j] = ld_gran2(g + 2 * min(gt + 256 * j, npairs - 1));
+    for (int j = 0; j < PER; ++j)
+      if ((need >> j) & 1u) x[j] = ld_gran2(g + 2 * (gt + 256 * j));  // only what has not arrived yet
     ld_wait();
 #pragma unroll
     for (int j = 0; j < PER; ++j) {
@@ -181,7 +185,7 @@ __device__ __forceinline__ void sweep2(const u64* __restrict__ g, int npairs, in
     }
     if (!need) break;
     if (spin_fail(rt, spins)) break;
-    __builtin_amdgcn_s_sleep(1);
+    for (int z = 0; z < rt.pass_sleep; ++z) __builtin_amdgcn_s_sleep(1);
   }
 }
 
@@ -386,6 +390,8 @@ __global__ __launch_bounds__(1024) void decode_engine_kernel(EngArgs a) {
   rt.limit = a.timeout_ticks;
   rt.ctr = a.ctr;
   rt.dead = false;
+  rt.first_delay = a.first_delay;
+  rt.pass_sleep = a.pass_sleep;
   // every value the kernel loads once is read to an SGPR HERE (readfirstlane waits for it): a load still "maybe pending" at
   // the head of the layer loop makes hipcc guard its first use in every iteration with s_waitcnt vmcnt(0) - which at run
   // time also drains the weight prefetch this wave has just issued
@@ -430,7 +436,9 @@ __global__ __launch_bounds__(1024) void decode_engine_kernel(EngArgs a) {
     ENG_STAMP(0)
     __syncthreads();
     ENG_STAMP(1)
-    if (!gw) dma_rows<HO, D, NCW>(w.wp, w.bp, cu * HO, S1, cw, ll);  // c_proj, one phase ahead
+    // c_proj -> slot 1 (mlp.c_proj of the last block was read before B1): requested here, while the gather waves run the
+    // LayerNorm - behind the publish it would sit in front of the attention workgroups' cache loads
+    if (!gw) dma_rows<HO, D, NCW>(w.wp, w.bp, cu * HO, S1, cw, ll);
     ln_to_sxb<NB, D>(xf, xn, red, tl, a.eps);
     if (qcu && !gw) {
 #pragma unroll
@@ -457,11 +465,14 @@ __global__ __launch_bounds__(1024) void decode_engine_kernel(EngArgs a) {
 
     phase_done(ll);
     ENG_STAMP(8)
+
     // ================= P2: cache attention of (row gm, head gh) =================
     if (acu) {
       // K/V rows: requested before the q / k / v hand-off is polled, so the cache stream hides behind that hop (all 16
       // waves; the thread <-> (split, slot, sub) mapping of decode_attn2_kernel<.., 256, 4>)
-      const int sp = tl >> 8, atid = tl & 255, slot = atid / LPK, sub = atid % LPK;
+      // split = wave / 4 is an SGPR: the "was this pair of the window requested" tests below are scalar branches that skip
+      // the dead half of the window (S = 380: 3 of 6 pairs per split) instead of computing it under a select
+      const int sp = wave >> 2, atid = (wave & 3) * 64 + ll, slot = atid / LPK, sub = atid % LPK;
       KVec kr[2 * NIT], vr[2 * NIT];
       const size_t lo = ((size_t)l * a.B * H + (size_t)gm * H + gh) * a.Smax * DH;
       bf16_t* kb = a.kc + lo;
@@ -525,9 +536,11 @@ __global__ __launch_bounds__(1024) void decode_engine_kernel(EngArgs a) {
 #pragma unroll
         for (int u = 0; u < 2 * NIT; ++u) {
           const int j = (u * NSPLIT + sp) * SLOTS + slot;
-          const bool live = u < UNC || (u * NSPLIT + sp) * SLOTS < S;
-          const float tt = live ? score(kr[u]) : 0.f;
-          sc[u] = (live && j < S && j >= ks && j != pos) ? tt : -INFINITY;
+          sc[u] = -INFINITY;
+          if (u < UNC || (u * NSPLIT + sp) * SLOTS < S) {  // wave-uniform (scalar)
+            const float tt = score(kr[u]);
+            sc[u] = (j < S && j >= ks && j != pos) ? tt : -INFINITY;
+          }
         }
         {  // the row appended by this step, with the cache's rounding, from LDS
           float tt = 0.f;
@@ -664,7 +677,6 @@ __global__ __launch_bounds__(1024) void decode_engine_kernel(EngArgs a) {
     }
     ENG_STAMP(4)
     __syncthreads();
-    ENG_STAMP(12)
     if (!gw && cw < HO) {
       float acc[NB];
 #pragma unroll
@@ -676,7 +688,6 @@ __global__ __launch_bounds__(1024) void decode_engine_kernel(EngArgs a) {
         const float x = wave_sum_rl(acc[b]);
         mine = ll == b ? x : mine;
       }
-      ENG_STAMP(14)
       if (ll < NB) {
         const float hn = hown[ll * 8 + cw] + (mine + reinterpret_cast<const float*>(W1)[cw]);
         hown[ll * 8 + cw] = hn;
@@ -689,7 +700,6 @@ __global__ __launch_bounds__(1024) void decode_engine_kernel(EngArgs a) {
     // c_fc, one phase ahead (into c_attn's slot), requested AFTER this phase's publish: a CU issues ~1 KiB of LDS-DMA per
     // 10 ns, so the 50 KB of a projection hold the issuing waves for 0.5 - 0.8 us (timeline) - off the edge's critical path here
     if (!gw) dma_rows<FO, D, NCW>(w.wf, w.bf, cu * FO, S0, cw, ll);
-    ENG_STAMP(13)
     // ================= P4: residual stream -> LN2 -> c_fc -> gelu_new =================
     if (gw) {
       wait_own(own_lds, NCW * phase, rt);
@@ -699,8 +709,12 @@ __global__ __launch_bounds__(1024) void decode_engine_kernel(EngArgs a) {
     }
     ENG_STAMP(5)
     __syncthreads();
-    if (!gw) dma_rows<HO, 4 * D, NCW>(w.w2, w.b2, cu * HO, S1, cw, ll);  // mlp.c_proj, one phase ahead (c_proj's slot)
+    ENG_STAMP(12)
+    // mlp.c_proj -> slot 1 (c_proj was read before B4), requested HERE: behind this phase's publish its 50 KB (0.6 us of issue
+    // + the flight) no longer fit into the following hop and gate the next barrier (measured: 0.492 vs 0.480 ms per step)
+    if (!gw) dma_rows<HO, 4 * D, NCW>(w.w2, w.b2, cu * HO, S1, cw, ll);
     ln_to_sxb<NB, D>(xf, xn, red, tl, a.eps);
+    ENG_STAMP(13)
     if (!gw && cw < FO / 2) {  // an adjacent pair of features per wave: one bf16-pair granule per batch row
       float acc[2][NB];
 #pragma unroll
@@ -717,6 +731,7 @@ __global__ __launch_bounds__(1024) void decode_engine_kernel(EngArgs a) {
           const float x = wave_sum_rl(acc[r][b]);
           mine = ll == r * NB + b ? x : mine;
         }
+      ENG_STAMP(14)
       const float v = gelu_new_rn(mine + reinterpret_cast<const float*>(W0)[2 * cw + (ll < NB ? 0 : 1)]);
       const float v1 = __shfl_down(v, NB, 64);  // (feature 1, batch row ll) for lanes < NB
       if (ll < NB) {
@@ -731,6 +746,7 @@ __global__ __launch_bounds__(1024) void decode_engine_kernel(EngArgs a) {
 
     phase_done(ll);
     ENG_STAMP(10)
+
     // ================= P5: gelu(fc) -> mlp.c_proj + residual =================
     if (gw) {
       wait_own(own_lds, NCW * phase, rt);

@@ -28,6 +28,7 @@ struct EngArgs {
   int NL = 0, B = 0, Smax = 0;
   float scale = 0.125f, eps = 1e-5f;
   unsigned timeout_ticks = 2000000;   // wall-clock bound of every wait, 100 MHz ticks (20 ms)
+  int first_delay = 24, pass_sleep = 1; // gather pacing (s_sleep units of 64 clocks): before the first pass / between passes
   float* dbg = nullptr;               // debugging aid (ITTS_TAP_LAYER): qkv [B][3D], h1 [B][D], act [B][4D], h2 [B][D] of block dbg_layer
   int dbg_layer = -1;
   unsigned* stamp = nullptr;          // debugging aid (ITTS_ENGINE_STAMPS): [256][NL][12] wall-clock stamps (100 MHz) of one step

@@ -699,6 +699,10 @@ int Engine::decode_step_launch(hipStream_t s) {
       ea.dbg = ds.act;  // [16][4D] fp32 scratch of the launch path, unused by the engine: room for the 9 B D floats of the dump
       ea.dbg_layer = e_tap;
     }
+    static const int e_fd = getenv("ITTS_ENGINE_FIRST_DELAY") ? atoi(getenv("ITTS_ENGINE_FIRST_DELAY")) : 24;  // tools: 0.65 us - a publish needs that long to become visible; earlier passes fail AND slow the stores down (sweep in DESIGN.md)
+    static const int e_ps = getenv("ITTS_ENGINE_PASS_SLEEP") ? atoi(getenv("ITTS_ENGINE_PASS_SLEEP")) : 1;
+    ea.first_delay = e_fd;
+    ea.pass_sleep = e_ps;
     static const bool e_stamps = getenv("ITTS_ENGINE_STAMPS") != nullptr;
     if (debug && e_stamps && !dry) ea.stamp = (unsigned*)ds.logits + 0;  // [16][V] fp32 scratch >= 256 * 24 * 16 words; the head overwrites it later
     if (eng_first > 0) ITTS_TRY(decode_engine_layers(ea, s));

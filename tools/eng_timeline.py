@@ -47,8 +47,8 @@ for l in (1, NL // 2, NL - 2):
 clk = st[:, 0, 15]
 print(f"shader clock over the launch: {np.median(clk) / 10.0:.0f} MHz (min {clk.min() / 10.0:.0f}, max {clk.max() / 10.0:.0f})")
 d = us[:, 2:NL - 1, :]
-print("-- c_proj phase of a compute wave (mean over WGs and blocks): E3 gathered -> after B3 %.2f -> dots + wave sums %.2f -> published %.2f -> c_fc DMA issued %.2f us"
-      % ((d[:, :, 12] - d[:, :, 4]).mean(), (d[:, :, 14] - d[:, :, 12]).mean(), (d[:, :, 9] - d[:, :, 14]).mean(), (d[:, :, 13] - d[:, :, 9]).mean()))
+print("-- c_fc phase of a compute wave (mean over WGs and blocks): E4 gathered (wave 0) -> after B4 %.2f -> LN2 done (2 barriers; mlp.c_proj DMA issued meanwhile) %.2f -> dots + wave sums %.2f -> gelu + publish %.2f us"
+      % ((d[:, :, 12] - d[:, :, 5]).mean(), (d[:, :, 13] - d[:, :, 12]).mean(), (d[:, :, 14] - d[:, :, 13]).mean(), (d[:, :, 10] - d[:, :, 14]).mean()))
 mx = us.max(axis=0)  # [NL][16] last WG
 mx[:, 3] = us[acu][:, :, 3].max(axis=0)
 seq = [(0, "E1 all gathered"), (8, "qkv all published"), (3, "ctx all published"), (4, "E3 all gathered"), (9, "h1 all published"),
