@@ -7,13 +7,14 @@
 //
 //   * each workgroup owns a fixed slice of every projection's output features (16 of c_attn - a head's q / k / v rows are
 //     spread over the 12 workgroups of that head's group -, 5 of c_proj, 20 of c_fc, 5 of mlp.c_proj: 153.6 KB of bf16
-//     weights per layer) and streams it with nontemporal 16-byte loads straight into REGISTERS, one phase ahead of its
-//     use (the 512 KB register file of a CU holds a layer's share three times over; no LDS ring, no loader wave);
+//     weights per layer) and streams it by LDS-DMA (global_load_lds, nontemporal, no VGPR touched) into three LDS slots,
+//     one to four phases ahead of its use: ONE loader wave per workgroup issues every request, in a fixed FIFO order, as
+//     soon as the target slot's previous occupant has been read, and waits with counted vmcnt in front of the barriers;
 //   * the five all-to-all phase edges of a layer (residual stream -> LN1, q/k/v -> attention, context -> c_proj,
 //     residual stream -> LN2, gelu(fc) -> mlp.c_proj) are 8-byte {value, tag} granules: written with ONE agent-scope
 //     (sc1, write-through) store by the lane that finished the value, polled with agent-scope loads by the four GATHER
 //     waves of every consuming workgroup - waves that never issue a weight load, so a poll never queues behind the
-//     workgroup's own weight stream (vmcnt is in-order per wave); the twelve COMPUTE waves never poll;
+//     workgroup's own weight stream (vmcnt is in-order per wave); the eleven COMPUTE waves neither poll nor prefetch;
 //   * tag = a step counter kept in device memory and advanced by the kernel itself: every (layer, edge) has its own
 //     granule block, so a tag can only match a value of THIS step; nothing is reset between launches (graph replay safe);
 //   * one attention workgroup per (row, head) - workgroup `row` of the head's group - runs the four key splits of
@@ -87,7 +88,7 @@ struct Rt {
 
 // debugging aid (EngArgs::stamp): wall-clock (100 MHz) stamp i of block l of this workgroup
 #define ENG_STAMP(i)                                                                                              \
-  if (a.stamp && (tl & 63) == 0 && (i < 8 ? tl == 0 : tl == 256))                                                \
+  if (a.stamp && (tl & 63) == 0 && (i < 8 ? tl == 0 : tl == 320))                                                \
     a.stamp[((size_t)cu * a.NL + l) * 16 + (i)] = (unsigned)__builtin_amdgcn_s_memrealtime();
 
 __device__ __forceinline__ u64 ld_gran(const u64* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -208,30 +209,36 @@ __device__ __forceinline__ void dma4(const void* gsrc, unsigned lds_addr) {  // 
                : "v"(gsrc), "s"(lds_addr)
                : "memory");
 }
-__device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
-// rows [n0, n0 + ROWS) of W [N][K] -> LDS slot (compact rows of K * 2 bytes), fragments dealt round-robin to the NCW
-// compute waves; bias[n0 ..] -> the 64 floats in front of the slot (one instruction of the last compute wave)
-template <int ROWS, int K, int NCW>
-__device__ __forceinline__ void dma_rows(const bf16_t* __restrict__ W, const float* __restrict__ bias, int n0, unsigned slot,
-                                         int cw, int lane) {
-  constexpr int NF = (K + 511) / 512, TOT = ROWS * NF, TAIL = K - (NF - 1) * 512;  // elements in the last fragment
+// rows [n0, n0 + ROWS) of W [N][K] -> LDS slot (64 bias floats, then compact rows of K * 2 bytes): issued by ONE wave (the
+// loader), ROWS * ceil(K / 512) + 1 instructions - the counts the loader's waits are written in
+template <int ROWS, int K>
+struct DmaCount {
+  static constexpr int NF = (K + 511) / 512, N = ROWS * NF + 1;
+};
+template <int ROWS, int K>
+__device__ __forceinline__ void dma_rows(const bf16_t* __restrict__ W, const float* __restrict__ bias, int n0, unsigned slot, int lane) {
+  constexpr int NF = (K + 511) / 512, TAIL = K - (NF - 1) * 512;  // elements in the last fragment
   static_assert(TAIL == 512 || TAIL == 256, "whole or half last fragment");
+  for (int r = 0; r < ROWS; ++r) {
+    const bf16_t* src = W + (size_t)(n0 + r) * K + lane * 8;
+    const unsigned dst = slot + 256 + (unsigned)(r * K * 2);
 #pragma unroll
-  for (int i = 0; i < (TOT + NCW - 1) / NCW; ++i) {
-    const int f = cw + i * NCW;
-    if (f < TOT) {
-      const int r = f / NF, c = f % NF;
-      const bf16_t* src = W + (size_t)(n0 + r) * K + c * 512 + lane * 8;
-      const unsigned dst = slot + 256 + (unsigned)(r * K * 2 + c * 1024);
+    for (int c = 0; c < NF; ++c) {
       if (TAIL == 512 || c != NF - 1) {
-        dma16(src, dst);
+        dma16(src + c * 512, dst + c * 1024);
       } else if (lane < 32) {
-        dma16(src, dst);
+        dma16(src + c * 512, dst + c * 1024);
       }
     }
   }
-  if (cw == NCW - 1 && lane < ROWS) dma4(bias + n0 + lane, slot);
+  if (lane < ROWS) dma4(bias + n0 + lane, slot);
+}
+// the loader waits until at most N of its requests are outstanding: everything older has landed in LDS (vmcnt is in-order)
+template <int N>
+__device__ __forceinline__ void dma_wait_keep() {
+  static_assert(N >= 0 && N <= 63, "vmcnt field");
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
 // acc[b] += W[row] . x[b] in gemv_bf16_kernel's order (fragments ascending, four v_dot2c per fragment); W from its LDS slot
@@ -340,7 +347,7 @@ __global__ __launch_bounds__(1024) void decode_engine_kernel(EngArgs a) {
   constexpr int QO = 3 * DH / GPH;   // c_attn rows per workgroup (16)
   constexpr int HO = D / NCU;        // residual-projection rows per workgroup (5)
   constexpr int FO = 4 * D / NCU;    // c_fc rows per workgroup (20)
-  constexpr int NCW = 12;            // compute waves (4..15); gather waves 0..3
+  constexpr int NCW = 11;            // compute waves 5..15; gather waves 0..3; wave 4 = the loader (weight prefetch)
   static_assert(GPH * QO == 3 * DH && HO * NCU == D && FO * NCU == 4 * D && (FO % 2) == 0, "partition");
   static_assert(QO <= 2 * NCW && HO <= NCW && FO / 2 <= NCW, "wave assignment");
   constexpr int NIT = 3, NSPLIT = 4, SLOTS = 32, LPK = 8, VEC = 8, UNC = 2;  // decode_attn2_kernel<.., 3, 256, 4>
@@ -348,15 +355,17 @@ __global__ __launch_bounds__(1024) void decode_engine_kernel(EngArgs a) {
   static_assert(ATTN_NSPLIT == NSPLIT, "split count of the launch path");
   static_assert(NB <= ENG_MAX_ROWS, "LDS budget");
 
-  // LDS map.  Two weight slots (bias row + rows): slot 0 holds c_attn, then c_fc; slot 1 c_proj, then mlp.c_proj - the
-  // projection a slot is refilled with is requested only behind the barrier that ends the previous occupant's last use.
+  // LDS map.  Three weight slots (bias row + rows): slot A holds c_attn, then c_fc; slot B mlp.c_proj; slot C c_proj.  A slot is
+  // refilled only once every compute wave has finished the phase that read its previous occupant (the `own` counter).
   // Every edge lands in a buffer of its own: a gather may run while the compute waves still read the previous input.
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
   constexpr unsigned SLOT = 256 + FO * D * 2;  // = 256 + HO * 4D * 2
+  constexpr unsigned SLOTC = 256 + HO * D * 2;
   static_assert(SLOT >= 256 + QO * D * 2 && SLOT >= 256 + HO * 4 * D * 2, "slot size");
-  unsigned char* W0 = smem;
-  unsigned char* W1 = smem + SLOT;
-  float* xf = reinterpret_cast<float*>(smem + 2 * SLOT);            // [NB][D] gathered residual stream (fp32)
+  unsigned char* W0 = smem;                 // A
+  unsigned char* W1 = smem + SLOT;          // B
+  unsigned char* W2 = smem + 2 * SLOT;      // C
+  float* xf = reinterpret_cast<float*>(smem + 2 * SLOT + SLOTC);    // [NB][D] gathered residual stream (fp32)
   uint32_t* xn = reinterpret_cast<uint32_t*>(xf + NB * D);          // [NB][D / 2] LayerNorm output, bf16 pairs
   uint32_t* xc = xn + NB * D / 2;                                   // [NB][D / 2] attention context, bf16 pairs
   uint32_t* xa = xc + NB * D / 2;                                   // [NB][4D / 2] gelu(fc), bf16 pairs
@@ -370,14 +379,16 @@ __global__ __launch_bounds__(1024) void decode_engine_kernel(EngArgs a) {
   float* pml = po + NSPLIT * DH;                                    // [2][4]
   unsigned* own = reinterpret_cast<unsigned*>(pml + 8);             // [1] phases finished by the compute waves (x NCW)
   const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
-  const unsigned S0 = lds0, S1 = lds0 + SLOT;
+  const unsigned S0 = lds0, S1 = lds0 + SLOT, S2 = lds0 + 2 * SLOT;
   const unsigned own_lds = lds0 + (unsigned)(reinterpret_cast<unsigned char*>(own) - smem);
 
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int cu = blockIdx.x;
-  const bool gw = wave < 4;
-  const int cw = wave - 4;
+  const bool gw = wave < 4;    // gather waves
+  const bool lw = wave == 4;   // the loader: every weight byte of this workgroup goes through its LDS-DMA requests
+  const bool cwv = wave > 4;   // compute waves
+  const int cw = wave - 5;
   const int gh = cu / GPH, gm = cu % GPH;
   const bool qcu = cu < H * GPH;        // takes part in c_attn
   const bool acu = qcu && gm < NB;      // runs the attention of (row gm, head gh)
@@ -403,10 +414,19 @@ __global__ __launch_bounds__(1024) void decode_engine_kernel(EngArgs a) {
   if (t == 0) *own = 0;
   unsigned phase = 0;  // compute phases finished so far (every wave counts alike)
   auto phase_done = [&](int ln_) {  // a compute wave is through a phase: its publishes are issued
-    if (!gw && ln_ == 0) __hip_atomic_fetch_add(own, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (cwv && ln_ == 0) __hip_atomic_fetch_add(own, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     ++phase;
   };
-  if (!gw && qcu) dma_rows<QO, D, NCW>(a.L[0].wa, a.L[0].ba, an0, S0, cw, lane);
+  // The loader's requests, each right BEHIND the barrier that ends the last use of the slot's previous occupant (so the
+  // issue burst - a CU takes ~1 KiB of LDS-DMA per 10 ns - runs beside the compute waves' dot products, not beside a gather:
+  // a gather pass queued behind its own CU's refill burst takes 2 - 3 x as long, MI355X_MICROARCH "gather-pass"):
+  //   behind B1: mlp.c_proj(l) -> B    behind B3: c_fc(l) -> A    behind B4: c_proj(l + 1) -> C    behind B5: c_attn(l + 1) -> A
+  // vmcnt is in-order, so c_proj / mlp.c_proj (requested three barriers before their use) have landed whenever the request
+  // after them has; the loader waits (vmcnt(0)) only in front of B1 (c_attn) and B4 (c_fc), each 2.5 - 3 us after the request.
+  if (lw) {
+    dma_rows<HO, D>(a.L[0].wp, a.L[0].bp, cu * HO, S2, lane);
+    if (qcu) dma_rows<QO, D>(a.L[0].wa, a.L[0].ba, an0, S0, lane);
+  }
   if (t < NB * HO) hown[(t / HO) * 8 + t % HO] = a.h[(size_t)(t / HO) * D + cu * HO + t % HO];
 
   __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): nothing the compiler counts is pending at the head of the layer loop
@@ -430,17 +450,18 @@ __global__ __launch_bounds__(1024) void decode_engine_kernel(EngArgs a) {
         wait_own(own_lds, NCW * phase, rt);
         sweep2<(NB * D / 2 + 255) / 256, false>(G - LSTRIDE + OH2, NB * D / 2, tl, rt, [&](int i, uint32_t v) { xf[i] = __uint_as_float(v); });
       }
-    } else {
-      dma_wait();  // c_attn rows of this layer (requested one phase ago)
+    } else if (lw) {
+      dma_wait_keep<0>();  // c_attn (and, before it, c_proj) of this block
     }
     ENG_STAMP(0)
     __syncthreads();
     ENG_STAMP(1)
-    // c_proj -> slot 1 (mlp.c_proj of the last block was read before B1): requested here, while the gather waves run the
-    // LayerNorm - behind the publish it would sit in front of the attention workgroups' cache loads
-    if (!gw) dma_rows<HO, D, NCW>(w.wp, w.bp, cu * HO, S1, cw, ll);
     ln_to_sxb<NB, D>(xf, xn, red, tl, a.eps);
-    if (qcu && !gw) {
+    // mlp.c_proj -> B (every wave is past the last block's); behind the LayerNorm's barriers, which the loader must not hold up.
+    // Not on an attention workgroup: its loader is one of the 16 attention waves, and the cache rows it requests next would
+    // queue behind these 50 KB (vmcnt is in-order) - there mlp.c_proj follows behind the second LayerNorm
+    if (lw && !acu) dma_rows<HO, 4 * D>(w.w2, w.b2, cu * HO, S1, ll);
+    if (qcu && cwv) {
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
         const int r = cw + NCW * s;
@@ -672,16 +693,15 @@ __global__ __launch_bounds__(1024) void decode_engine_kernel(EngArgs a) {
         sweep2<(NB * D / 4 + 255) / 256, false>(G + OCTX, NB * D / 4, tl, rt, [&](int i, uint32_t v) { xc[i] = v; });
       else
         sweep2<(NB * D / 4 + 255) / 256, true>(G + OCTX, NB * D / 4, tl, rt, [&](int i, uint32_t v) { xc[i] = v; });
-    } else {
-      dma_wait();  // c_proj rows
-    }
+    }  // (c_proj is older in the loader's queue than c_attn: it landed before this block's first barrier)
     ENG_STAMP(4)
     __syncthreads();
-    if (!gw && cw < HO) {
+    if (lw) dma_rows<FO, D>(w.wf, w.bf, cu * FO, S0, ll);  // c_fc -> A: every wave is past c_attn
+    if (cwv && cw < HO) {
       float acc[NB];
 #pragma unroll
       for (int b = 0; b < NB; ++b) acc[b] = 0.f;
-      dots<NB, D>(W1 + 256 + cw * D * 2, xc, ll, acc);
+      dots<NB, D>(W2 + 256 + cw * D * 2, xc, ll, acc);
       float mine = 0.f;
 #pragma unroll
       for (int b = 0; b < NB; ++b) {
@@ -689,7 +709,7 @@ __global__ __launch_bounds__(1024) void decode_engine_kernel(EngArgs a) {
         mine = ll == b ? x : mine;
       }
       if (ll < NB) {
-        const float hn = hown[ll * 8 + cw] + (mine + reinterpret_cast<const float*>(W1)[cw]);
+        const float hn = hown[ll * 8 + cw] + (mine + reinterpret_cast<const float*>(W2)[cw]);
         hown[ll * 8 + cw] = hn;
         st_gran(G + OH1 + (size_t)ll * D + cu * HO + cw, rt.tag, __float_as_uint(hn));
         if (a.dbg && l == a.dbg_layer) a.dbg[(size_t)NB * 3 * D + (size_t)ll * D + cu * HO + cw] = hn;
@@ -697,25 +717,21 @@ __global__ __launch_bounds__(1024) void decode_engine_kernel(EngArgs a) {
     }
     phase_done(ll);
     ENG_STAMP(9)
-    // c_fc, one phase ahead (into c_attn's slot), requested AFTER this phase's publish: a CU issues ~1 KiB of LDS-DMA per
-    // 10 ns, so the 50 KB of a projection hold the issuing waves for 0.5 - 0.8 us (timeline) - off the edge's critical path here
-    if (!gw) dma_rows<FO, D, NCW>(w.wf, w.bf, cu * FO, S0, cw, ll);
     // ================= P4: residual stream -> LN2 -> c_fc -> gelu_new =================
     if (gw) {
       wait_own(own_lds, NCW * phase, rt);
       sweep2<(NB * D / 2 + 255) / 256, false>(G + OH1, NB * D / 2, tl, rt, [&](int i, uint32_t v) { xf[i] = __uint_as_float(v); });
-    } else {
-      dma_wait();  // c_fc rows
+    } else if (lw) {
+      dma_wait_keep<0>();  // c_fc (and, before it, mlp.c_proj)
     }
     ENG_STAMP(5)
     __syncthreads();
     ENG_STAMP(12)
-    // mlp.c_proj -> slot 1 (c_proj was read before B4), requested HERE: behind this phase's publish its 50 KB (0.6 us of issue
-    // + the flight) no longer fit into the following hop and gate the next barrier (measured: 0.492 vs 0.480 ms per step)
-    if (!gw) dma_rows<HO, 4 * D, NCW>(w.w2, w.b2, cu * HO, S1, cw, ll);
     ln_to_sxb<NB, D>(xf, xn, red, tl, a.eps);
+    if (lw && acu) dma_rows<HO, 4 * D>(w.w2, w.b2, cu * HO, S1, ll);
+    if (lw && l + 1 < a.NL) dma_rows<HO, D>(a.L[l + 1].wp, a.L[l + 1].bp, cu * HO, S2, ll);  // next c_proj -> C: all past this one's
     ENG_STAMP(13)
-    if (!gw && cw < FO / 2) {  // an adjacent pair of features per wave: one bf16-pair granule per batch row
+    if (cwv && cw < FO / 2) {  // an adjacent pair of features per wave: one bf16-pair granule per batch row
       float acc[2][NB];
 #pragma unroll
       for (int r = 0; r < 2; ++r) {
@@ -751,13 +767,17 @@ __global__ __launch_bounds__(1024) void decode_engine_kernel(EngArgs a) {
     if (gw) {
       wait_own(own_lds, NCW * phase, rt);
       sweep2<(NB * D + 255) / 256, false>(G + OACT, NB * D, tl, rt, [&](int i, uint32_t v) { xa[i] = v; });
-    } else {
-      dma_wait();  // mlp.c_proj rows
-    }
+    } else if (lw && acu) {  // mlp.c_proj was requested behind LN2 here; the next block's c_proj (if any) is younger
+      if (l + 1 < a.NL)
+        dma_wait_keep<DmaCount<HO, D>::N>();
+      else
+        dma_wait_keep<0>();
+    }  // (elsewhere mlp.c_proj is older in the loader's queue than c_fc: it landed before this block's c_fc barrier)
     ENG_STAMP(6)
     __syncthreads();
     ENG_STAMP(7)
-    if (!gw && cw < HO) {
+    if (lw && qcu && l + 1 < a.NL) dma_rows<QO, D>(a.L[l + 1].wa, a.L[l + 1].ba, an0, S0, ll);  // next c_attn -> A: all past c_fc
+    if (cwv && cw < HO) {
       float acc[NB];
 #pragma unroll
       for (int b = 0; b < NB; ++b) acc[b] = 0.f;
@@ -780,7 +800,6 @@ __global__ __launch_bounds__(1024) void decode_engine_kernel(EngArgs a) {
     }
     phase_done(ll);
     ENG_STAMP(11)
-    if (!gw && qcu && l + 1 < a.NL) dma_rows<QO, D, NCW>(a.L[l + 1].wa, a.L[l + 1].ba, an0, S0, cw, ll);  // next layer's c_attn
   }
   // advance the step counter (never 0): every workgroup read it before its first publish, and this workgroup got here
   // only after gathering from all of them
@@ -797,7 +816,7 @@ size_t eng_gran_count(int layers) { return (size_t)layers * 4 * ENG_D * 15 / 2; 
 
 int decode_engine_layers(const EngArgs& a, hipStream_t s) {
   ITTS_REQUIRE(a.B >= 1 && a.B <= ENG_MAX_ROWS && a.NL >= 1 && a.NL <= ENG_MAX_LAYERS && a.gran && a.h && a.kc && a.vc && a.ctr, "decode_engine: bad arguments");
-  const size_t lds = 152 * 1024;  // weight slots + edge buffers: one workgroup per CU
+  const size_t lds = 160 * 1024;  // three weight slots + edge buffers: the whole LDS of a CU, one workgroup per CU
 #define ITTS_ENG_GO(NB)                                                                                                         \
   {                                                                                                                             \
     static bool attr = false;                                                                                                   \
