@@ -164,6 +164,16 @@ int itts_gpt_set_typical(itts_engine* e, float mass);
  * itts_gpt_fetch as steps 0..n-1 (the reference strips them with trunc_index, model.py:687,704). */
 int itts_gpt_set_forced(itts_engine* e, const int32_t* ids_host, int B, int n);
 
+/* The same, with the positions of the reference's `input_tokens` path (gpt/model.py:141-155,672-686): the given tokens are
+ * part of the reference's FIRST forward, embedded with mel positions 0 .. n ([start_mel, t1 .. tn]), and the first generated
+ * token is fed at position n + 2 - so given token k (0-based) is fed at position k + 1 here, not k + 2 as a generated
+ * (or teacher-forced) token would be.  n = 0 clears. */
+int itts_gpt_set_input_tokens(itts_engine* e, const int32_t* ids_host, int B, int n);
+
+/* How the last captured / launched decode step ran: 1 = the persistent decode engine (one launch for the GPT blocks of a
+ * token step; <= 2 rows, bf16, IndexTTS-1.5 dims, no beams / fp8 copies), 0 = five launches per block. */
+int itts_gpt_decode_mode(itts_engine* e);
+
 /* G1/G3/G4 step 0: prepare_gpt_inputs (model.py:591-654) + prefill + first greedy token.
  * cond fp32 [latents, D]; text ids host int32 [B, L] (may hold start/stop padding ids, stripped per row).
  * Synchronises the stream once (uploads the row descriptors). */

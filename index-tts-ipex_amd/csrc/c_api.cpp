@@ -26,7 +26,7 @@ int gemm(const GemmArgs& g, int ta, int tw, int tc, hipStream_t s) {
 extern "C" {
 
 const char* itts_last_error(void) { return last_error(); }
-int itts_abi_version(void) { return 2; }
+int itts_abi_version(void) { return 3; }
 
 int itts_snake_aa_fwd(void* dst, const void* src, const float* up12, const float* down12, const float* log_alpha,
                       const float* log_beta, int B, int C, int T, int dtype, int layout, itts_stream stream) {
@@ -211,6 +211,11 @@ int itts_gpt_set_typical(itts_engine* e, float mass) {
   ENG(e);
   return e->e.gpt_set_typical(mass);
 }
+int itts_gpt_set_input_tokens(itts_engine* e, const int32_t* ids_host, int B, int n) {
+  ENG(e);
+  return e->e.gpt_set_input_tokens(ids_host, B, n);
+}
+int itts_gpt_decode_mode(itts_engine* e) { return e ? e->e.ds.last_mode : -1; }
 int itts_gpt_set_forced(itts_engine* e, const int32_t* ids_host, int B, int n) {
   ENG(e);
   return e->e.gpt_set_forced(ids_host, B, n);

@@ -1538,7 +1538,9 @@ __device__ __forceinline__ void sampler_commit(const SamplerArgs& a, int b, int 
     a.unfinished[b] = unf && tok != a.stop;
     a.step[b] = k + 1;
     si[0] = tok;
-    si[1] = k + 2;  // position of the token fed at the next step: 0, 2, 3, ... (model.py:153-155)
+    // position of the token fed at the next step: 0, 2, 3, ... (model.py:153-155); a given `input_tokens` token k was part of
+    // the reference's first forward, at position k + 1 (model.py:141-144)
+    si[1] = k < a.input_n ? k + 1 : k + 2;
   }
 }
 

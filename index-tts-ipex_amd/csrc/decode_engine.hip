@@ -216,7 +216,10 @@ template <int ROWS, int K>
 struct DmaCount {
   static constexpr int NF = (K + 511) / 512, N = ROWS * NF + 1;
 };
-template <int ROWS, int K>
+// THIN > 0: at most THIN requests in flight (the loader waits in between) - for the one projection that has to be
+// requested while this CU's gather waves are polling (MI355X_MICROARCH "gather-pass": a gather pass queued behind its own
+// CU's unthrottled refill burst takes 2 - 3 x as long)
+template <int ROWS, int K, int THIN = 0>
 __device__ __forceinline__ void dma_rows(const bf16_t* __restrict__ W, const float* __restrict__ bias, int n0, unsigned slot, int lane) {
   constexpr int NF = (K + 511) / 512, TAIL = K - (NF - 1) * 512;  // elements in the last fragment
   static_assert(TAIL == 512 || TAIL == 256, "whole or half last fragment");
@@ -230,6 +233,7 @@ __device__ __forceinline__ void dma_rows(const bf16_t* __restrict__ W, const flo
       } else if (lane < 32) {
         dma16(src + c * 512, dst + c * 1024);
       }
+      if (THIN > 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(THIN) : "memory");
     }
   }
   if (lane < ROWS) dma4(bias + n0 + lane, slot);
@@ -265,77 +269,81 @@ __device__ __forceinline__ void dots(const unsigned char* __restrict__ wrow, con
   }
 }
 
-// LayerNorm without affine of xf [NB][K] fp32 -> bf16 pairs sxb [NB][K/2]: the prologue of gemv_bf16_kernel<.., PRO = 1>
-// on its 256 threads (threads 0..255 here), same shifted moments, same wave / workgroup reduction order.
-template <int NB, int K>
-__device__ __forceinline__ void ln_to_sxb(const float* __restrict__ xf, uint32_t* __restrict__ sxb, float* __restrict__ red,
-                                          int t, float eps) {
-  constexpr int KCH = 2, NTHR = 256;
+// LayerNorm without affine of xf [NB][K] fp32 -> bf16 pairs sxb [NB][K/2]: the prologue of gemv_bf16_kernel<.., PRO = 1>.
+// A row is normalised by 256 threads in that kernel's thread <-> element mapping (thread t: elements [4t, 4t + 4) and, for
+// t < 64, [1024 + 4t, ..)), same shifted moments, same wave / workgroup reduction order.  Rows are independent, so row 0 is
+// taken by waves 0..3 and row 1 by waves 12..15 at the same time (the chain load -> moments -> 4 wave reductions -> LDS ->
+// barrier -> rsqrt -> normalise -> LDS is latency-bound on one wave per SIMD: 0.9 us for two rows on one group).
+template <int K>
+struct LnRow {
+  float xv[2][4], pivot;
+  bool xok[2];
+};
+template <int K>
+__device__ __forceinline__ void ln_row_stats(const float* __restrict__ x, float* __restrict__ red, int t, LnRow<K>& r) {
+  constexpr int NTHR = 256;
   static_assert(K > NTHR * 4 && K <= NTHR * 8, "two 4-element chunks per thread");
   const int lane = t & 63, wave = t >> 6;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int i = (t + j * NTHR) * 4;
+    r.xok[j] = i < K;
+    const f32x4 v = *reinterpret_cast<const f32x4*>(x + (r.xok[j] ? i : K - 4));
+#pragma unroll
+    for (int e = 0; e < 4; ++e) r.xv[j][e] = v[e];
+  }
+  r.pivot = x[0];
+  float s = 0.f, q = 0.f;
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float d = r.xok[j] ? r.xv[j][e] - r.pivot : 0.f;
+      s += d;
+      q = fmaf(d, d, q);
+    }
+  s = wave_sum_rl(s);
+  q = wave_sum_rl(q);
+  if (lane == 0) {
+    red[wave * 2] = s;
+    red[wave * 2 + 1] = q;
+  }
+}
+template <int K>
+__device__ __forceinline__ void ln_row_apply(LnRow<K>& r, const float* __restrict__ red, uint32_t* __restrict__ sx, int t, float eps) {
   const float invK = 1.f / (float)K;
-  float xv[NB][KCH][4], pivot[NB];
-  bool xok[KCH];
-  if (t < NTHR) {
+  float S = 0.f, Q = 0.f;
 #pragma unroll
-    for (int j = 0; j < KCH; ++j) {
-      const int i = (t + j * NTHR) * 4;
-      xok[j] = i < K;
-      const int ic = xok[j] ? i : K - 4;
+  for (int ww = 0; ww < 4; ++ww) {
+    S += red[ww * 2];
+    Q += red[ww * 2 + 1];
+  }
+  const float md = __fmul_rn(S, invK);
+  const float mean = __fadd_rn(r.pivot, md);
+  const float rstd = __builtin_amdgcn_rsqf(__fadd_rn(fmaxf(ln_var_rn(Q, invK, md), 0.f), eps));
 #pragma unroll
-      for (int b = 0; b < NB; ++b) {
-        const f32x4 v = *reinterpret_cast<const f32x4*>(xf + b * K + ic);
+  for (int j = 0; j < 2; ++j) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) xv[b][j][e] = v[e];
-      }
-    }
-#pragma unroll
-    for (int b = 0; b < NB; ++b) {
-      pivot[b] = xf[b * K];
-      float s = 0.f, q = 0.f;
-#pragma unroll
-      for (int j = 0; j < KCH; ++j)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float d = xok[j] ? xv[b][j][e] - pivot[b] : 0.f;
-          s += d;
-          q = fmaf(d, d, q);
-        }
-      s = wave_sum_rl(s);
-      q = wave_sum_rl(q);
-      if (lane == 0) {
-        red[wave * 2 * NB + 2 * b] = s;
-        red[wave * 2 * NB + 2 * b + 1] = q;
-      }
+    for (int e = 0; e < 4; ++e) r.xv[j][e] = (r.xv[j][e] - mean) * rstd;
+    if (r.xok[j]) {
+      uint2 p;
+      p.x = pack_bf16(r.xv[j][0], r.xv[j][1]);
+      p.y = pack_bf16(r.xv[j][2], r.xv[j][3]);
+      *reinterpret_cast<uint2*>(sx + (t + j * 256) * 2) = p;
     }
   }
+}
+// all 1024 threads call this (two workgroup barriers inside); red: [NB][4][2] floats
+template <int NB, int K>
+__device__ __forceinline__ void ln_to_sxb(const float* __restrict__ xf, uint32_t* __restrict__ sxb, float* __restrict__ red, int t,
+                                          float eps) {
+  static_assert(NB >= 1 && NB <= 2, "one group of four waves per row");
+  const int grp = t < 256 ? 0 : (NB == 2 && t >= 768 ? 1 : -1);  // which row this thread works on (-1: none)
+  const int tr = t & 255;
+  LnRow<K> r;
+  if (grp >= 0) ln_row_stats<K>(xf + grp * K, red + grp * 8, tr, r);
   __syncthreads();
-  if (t < NTHR) {
-#pragma unroll
-    for (int b = 0; b < NB; ++b) {
-      float S = 0.f, Q = 0.f;
-#pragma unroll
-      for (int ww = 0; ww < 4; ++ww) {
-        S += red[ww * 2 * NB + 2 * b];
-        Q += red[ww * 2 * NB + 2 * b + 1];
-      }
-      const float md = __fmul_rn(S, invK);
-      const float mean = __fadd_rn(pivot[b], md);
-      const float rstd = __builtin_amdgcn_rsqf(__fadd_rn(fmaxf(ln_var_rn(Q, invK, md), 0.f), eps));
-#pragma unroll
-      for (int j = 0; j < KCH; ++j) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) xv[b][j][e] = (xv[b][j][e] - mean) * rstd;
-        if (xok[j]) {
-          const int i = (t + j * NTHR) * 4;
-          uint2 p;
-          p.x = pack_bf16(xv[b][j][0], xv[b][j][1]);
-          p.y = pack_bf16(xv[b][j][2], xv[b][j][3]);
-          *reinterpret_cast<uint2*>(sxb + (b * K + i) / 2) = p;
-        }
-      }
-    }
-  }
+  if (grp >= 0) ln_row_apply<K>(r, red + grp * 8, sxb + grp * (K / 2), tr, eps);
   __syncthreads();
 }
 
@@ -696,7 +704,12 @@ __global__ __launch_bounds__(1024) void decode_engine_kernel(EngArgs a) {
     }  // (c_proj is older in the loader's queue than c_attn: it landed before this block's first barrier)
     ENG_STAMP(4)
     __syncthreads();
-    if (lw) dma_rows<FO, D>(w.wf, w.bf, cu * FO, S0, ll);  // c_fc -> A: every wave is past c_attn
+    if (lw) {  // c_fc -> A: every wave is past c_attn
+      if (a.thin_fc)
+        dma_rows<FO, D, 12>(w.wf, w.bf, cu * FO, S0, ll);
+      else
+        dma_rows<FO, D>(w.wf, w.bf, cu * FO, S0, ll);
+    }
     if (cwv && cw < HO) {
       float acc[NB];
 #pragma unroll

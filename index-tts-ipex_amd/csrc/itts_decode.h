@@ -77,6 +77,7 @@ struct SamplerArgs {
   // forced tokens (HF `input_tokens` continuation, model.py:672-686 / teacher forcing): forced[b][k] >= 0 replaces the
   // choice of step k for row b; nullptr = nothing forced (the table is only read when it exists)
   const int* forced = nullptr;  // [B][max_gen]
+  int input_n = 0;  // the first input_n forced tokens are HF `input_tokens`: token k is fed at mel position k + 1, not k + 2
   int preprocessed = 0;  // logits already went through typical_filter (penalty, stop suppression done)
 };
 

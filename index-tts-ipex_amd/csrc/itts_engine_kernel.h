@@ -6,7 +6,7 @@ namespace itts {
 
 constexpr int ENG_D = 1280, ENG_H = 20, ENG_NCU = 256, ENG_MAX_ROWS = 2;
 constexpr int ENG_MAX_LAYERS = 24;
-constexpr bool ENG_DEFAULT_ON = false;  // ITTS_ENGINE=1 / 0 overrides  // IndexTTS-1.5 GPT on the 256 CUs of an MI355X
+constexpr bool ENG_DEFAULT_ON = true;   // ITTS_ENGINE=0 keeps the five-launches-per-block path  // IndexTTS-1.5 GPT on the 256 CUs of an MI355X
 
 struct EngLayerW {  // one GPT-2 block: bf16 [N][K] projections (LayerNorm affine folded in by the packer), fp32 biases
   const bf16_t *wa, *wp, *wf, *w2;
@@ -28,7 +28,8 @@ struct EngArgs {
   int NL = 0, B = 0, Smax = 0;
   float scale = 0.125f, eps = 1e-5f;
   unsigned timeout_ticks = 2000000;   // wall-clock bound of every wait, 100 MHz ticks (20 ms)
-  int first_delay = 24, pass_sleep = 1; // gather pacing (s_sleep units of 64 clocks): before the first pass / between passes
+  int first_delay = 22, pass_sleep = 1; // gather pacing (s_sleep units of 64 clocks): before the first pass / between passes
+  int thin_fc = 0;                    // the loader keeps at most 12 c_fc requests in flight (they run beside a gather)
   float* dbg = nullptr;               // debugging aid (ITTS_TAP_LAYER): qkv [B][3D], h1 [B][D], act [B][4D], h2 [B][D] of block dbg_layer
   int dbg_layer = -1;
   unsigned* stamp = nullptr;          // debugging aid (ITTS_ENGINE_STAMPS): [256][NL][12] wall-clock stamps (100 MHz) of one step

@@ -171,6 +171,7 @@ bool Engine::engine_usable() const {
   }();
   const itts_config& c = cfg;
   if ((env_off && !ds.eng_force) || ds.eng_off || ds.eng_failed || ncu != ENG_NCU) return false;
+  if (ds.fuse && !ds.fuse_failed) return false;  // A/B switch of the fused projection + attention launch: a launch-path variant
   if (adt != BF16 || ds.B < 1 || ds.B > ENG_MAX_ROWS || ds.nb != 1) return false;
   if (c.model_dim != ENG_D || c.heads != ENG_H || c.layers < 1 || c.layers > ENG_MAX_LAYERS || ds.Smax > 2048 || ds.Smax % 256 != 0) return false;
   for (const GptLayerW& L : gpt.layers)
@@ -449,6 +450,7 @@ int Engine::gpt_prefill(const float* cond_dev, const int32_t* text_ids_in, int B
     ITTS_HIP_CHECK(hipStreamSynchronize(s));
   }
   ds.use_forced = forced_n > 0;
+  ds.input_n = forced_input ? forced_n : 0;
   if (ds.use_forced) {
     ITTS_REQUIRE(forced_B == B || forced_B == 1, "gpt_prefill: forced tokens were set for a different batch size");
     ITTS_REQUIRE(forced_n <= max_gen, "gpt_prefill: more forced tokens than max_gen");
@@ -656,6 +658,7 @@ int Engine::head_and_sample(hipStream_t s) {
   sa.temperature = ds.temperature;
   sa.uniforms = ds.uniforms;
   sa.forced = ds.use_forced ? ds.forced : nullptr;
+  sa.input_n = ds.use_forced ? ds.input_n : 0;
   sa.B = B;
   return sampler2_step(sa, B, s);
 }
@@ -670,6 +673,7 @@ int Engine::decode_step_launch(hipStream_t s) {
   const bool fast = adt == BF16 && B <= 4;  // bf16 activations between the decode kernels (ctx, act)
   const bool skinny = adt == BF16 && B > 4 && D % 32 == 0 && D <= 2048;  // weights once, batch on MFMA
   ds.pend_split = 0;
+  ds.last_mode = 0;
   int eng_first = 0;
   if (engine_usable()) {  // <= 4 rows: the 24 blocks as ONE persistent launch, then the head + sampler launches
     ITTS_REQUIRE(ds.eng_gran && ds.eng_ctr, "decode engine: state not allocated (prefill first)");
@@ -699,12 +703,15 @@ int Engine::decode_step_launch(hipStream_t s) {
       ea.dbg = ds.act;  // [16][4D] fp32 scratch of the launch path, unused by the engine: room for the 9 B D floats of the dump
       ea.dbg_layer = e_tap;
     }
-    static const int e_fd = getenv("ITTS_ENGINE_FIRST_DELAY") ? atoi(getenv("ITTS_ENGINE_FIRST_DELAY")) : 24;  // tools: 0.65 us - a publish needs that long to become visible; earlier passes fail AND slow the stores down (sweep in DESIGN.md)
+    static const int e_fd = getenv("ITTS_ENGINE_FIRST_DELAY") ? atoi(getenv("ITTS_ENGINE_FIRST_DELAY")) : 22;  // tools: 0.65 us - a publish needs that long to become visible; earlier passes fail AND slow the stores down (sweep in DESIGN.md)
     static const int e_ps = getenv("ITTS_ENGINE_PASS_SLEEP") ? atoi(getenv("ITTS_ENGINE_PASS_SLEEP")) : 1;
+    static const int e_thin = getenv("ITTS_ENGINE_THIN_FC") ? atoi(getenv("ITTS_ENGINE_THIN_FC")) : 0;
+    ea.thin_fc = e_thin;
     ea.first_delay = e_fd;
     ea.pass_sleep = e_ps;
     static const bool e_stamps = getenv("ITTS_ENGINE_STAMPS") != nullptr;
     if (debug && e_stamps && !dry) ea.stamp = (unsigned*)ds.logits + 0;  // [16][V] fp32 scratch >= 256 * 24 * 16 words; the head overwrites it later
+    ds.last_mode = eng_first > 0;
     if (eng_first > 0) ITTS_TRY(decode_engine_layers(ea, s));
     if (ea.stamp) ITTS_TRY(tap("eng_stamps", ea.stamp, F32, (int64_t)ENG_NCU * eng_first * 16, s));
     if (ea.dbg) {
@@ -905,7 +912,18 @@ int Engine::gpt_set_typical(float mass) {
 
 // Tokens that replace the sampler's choice for the first n steps of every following generation (n = 0 clears):
 // the HF `input_tokens` continuation of inference_speech (model.py:672-686) and teacher forcing for parity tests.
+// HF `input_tokens` (inference_speech, model.py:672-686): the given mel tokens are appended to the fake input ids, so the
+// reference's FIRST forward embeds [start_mel, t1 .. tn] with mel positions 0 .. n (model.py:141-144) and the first
+// generated token is fed at position n + 2 (model.py:151-155).  Same forcing as gpt_set_forced, but token k (0-based) is fed
+// at position k + 1 instead of k + 2.
+int Engine::gpt_set_input_tokens(const int32_t* ids_host, int B, int n) {
+  ITTS_TRY(gpt_set_forced(ids_host, B, n));
+  forced_input = forced_n > 0;
+  return OK;
+}
+
 int Engine::gpt_set_forced(const int32_t* ids_host, int B, int n) {
+  forced_input = 0;
   if (n <= 0 || !ids_host) {
     forced_host.clear();
     forced_B = forced_n = 0;
@@ -931,7 +949,7 @@ int Engine::gpt_decode(int nsteps, hipStream_t s) {
     // everything SamplerArgs carries by value is baked into the captured nodes: max_gen is the ids row stride and the
     // `k < max_gen` bound, so a per-request max_mel_tokens must re-capture (same B / Smax notwithstanding)
     const bool stale = !d.graph || d.graph_B != d.B || d.graph_Smax != d.Smax || d.graph_max_gen != d.max_gen ||
-                       d.graph_forced != d.use_forced || d.graph_fuse != (d.fuse && !d.fuse_failed) || d.graph_eng != (int)engine_usable() || d.graph_nb != d.nb || d.graph_beam_sample != d.beam_sample ||
+                       d.graph_forced != d.use_forced || d.graph_input_n != d.input_n || d.graph_fuse != (d.fuse && !d.fuse_failed) || d.graph_eng != (int)engine_usable() || d.graph_nb != d.nb || d.graph_beam_sample != d.beam_sample ||
                        d.graph_length_penalty != d.length_penalty || d.graph_typical != d.typical_mass || d.graph_penalty != d.penalty || d.graph_suppress != d.suppress_stop || d.graph_sample != d.do_sample ||
                        d.graph_top_k != d.top_k || d.graph_top_p != d.top_p || d.graph_temperature != d.temperature;
     // two executables: one step, and GK steps back to back (one launch per GK tokens: the gap between consecutive graph
@@ -965,6 +983,7 @@ int Engine::gpt_decode(int nsteps, hipStream_t s) {
       d.graph_Smax = d.Smax;
       d.graph_max_gen = d.max_gen;
       d.graph_forced = d.use_forced;
+      d.graph_input_n = d.input_n;
       d.graph_fuse = d.fuse && !d.fuse_failed;
       d.graph_eng = (int)engine_usable();
       d.graph_nb = d.nb;

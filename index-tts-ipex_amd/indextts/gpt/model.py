@@ -81,13 +81,13 @@ class UnifiedVoice:
                 it = input_tokens.detach().cpu().numpy() if isinstance(input_tokens, torch.Tensor) else np.asarray(input_tokens)
                 it = np.atleast_2d(it).astype(np.int32)
                 n_forced = it.shape[1]
-                self._eng.set_forced(it)
+                self._eng.set_input_tokens(it)
             try:
                 # max_length = trunc_index + max_generate_length with trunc_index counting the given tokens (model.py:687,695)
                 codes = self._eng.generate(cond, ids, max_gen + n_forced, repetition_penalty=rep, **sample_kw)
             finally:
                 if n_forced:
-                    self._eng.set_forced(None)
+                    self._eng.set_input_tokens(None)
         return torch.from_numpy(codes[:, n_forced:]).to(self._eng.device)
 
     @torch.no_grad()

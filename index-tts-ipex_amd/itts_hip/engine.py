@@ -227,6 +227,19 @@ class Engine:
         a = np.ascontiguousarray(np.atleast_2d(ids), dtype=np.int32)
         L.check(self.lib.itts_gpt_set_forced(self.h, a.ctypes.data_as(C.c_void_p), a.shape[0], a.shape[1]), "gpt_set_forced")
 
+    def set_input_tokens(self, ids: Optional[np.ndarray]):
+        """HF `input_tokens` [B or 1, n] (inference_speech, model.py:672-686) for the following generations: forced like
+        set_forced, at the reference's positions (token k at mel position k + 1); None clears."""
+        if ids is None or np.asarray(ids).size == 0:
+            L.check(self.lib.itts_gpt_set_input_tokens(self.h, None, 0, 0), "gpt_set_input_tokens")
+            return
+        a = np.ascontiguousarray(np.atleast_2d(ids), dtype=np.int32)
+        L.check(self.lib.itts_gpt_set_input_tokens(self.h, a.ctypes.data_as(C.c_void_p), a.shape[0], a.shape[1]), "gpt_set_input_tokens")
+
+    def decode_mode(self) -> int:
+        """1 if the last decode step ran on the persistent decode engine, 0 for the five-launches-per-block path."""
+        return int(self.lib.itts_gpt_decode_mode(self.h))
+
     def decode(self, nsteps: int):
         L.check(self.lib.itts_gpt_decode(self.h, nsteps, self._s()), "gpt_decode")
 

@@ -494,6 +494,26 @@ def fast_fixtures():
          max_mel_tokens=max_mel, bucket_size=2, bucket_order=np.asarray([x["idx"] for bk in buckets for x in bk]))
 
 
+@torch.no_grad()
+def input_token_fixtures():
+    """`inference_speech(..., input_tokens=...)` (model.py:672-686) through the reference's own forward: given tokens in the
+    first forward at positions 0 .. n, generation continuing at position n + 2 - micro config, one row and a 2-row batch
+    with one shared continuation prefix."""
+    cfg = icfg.micro()
+    g = cfg.gpt
+    gpt = build_ref_gpt(cfg, 1234)
+    mel = torch.from_numpy(synth.prompt_mel(61, seed=7))
+    text = torch.from_numpy(synth.text_ids(11, 11, g.number_text_tokens)).view(1, 11).int()
+    base, *_ = ref_greedy(gpt, mel, text, max_gen=24)
+    given = base[:, :5].clone()
+    given[0, 2] = (int(given[0, 2]) + 3) % (g.number_mel_codes - 2)  # not what greedy itself would have picked
+    codes, logits, *_ = ref_greedy(gpt, mel, text, max_gen=16, input_tokens=given, n_trace=6)
+    save("micro_input_tokens_b1", text=text, input_tokens=given, codes=codes, logits=logits)
+    t2 = torch.stack([text[0], torch.from_numpy(synth.text_ids(11, 12, g.number_text_tokens)).int()])
+    codes2, logits2, *_ = ref_greedy(gpt, mel, t2, max_gen=16, input_tokens=given, n_trace=3)
+    save("micro_input_tokens_b2", text=t2, input_tokens=given, codes=codes2, logits=logits2)
+
+
 def front_fixtures():
     """Known answers of the reference's text front end (indextts/utils/front.py, utils/common.py): sentence splitting on
     token lists, CJK pre-tokenisation, and TextNormalizer.normalize with the third-party written-form normalisers replaced
@@ -556,11 +576,14 @@ if __name__ == "__main__":
     ap.add_argument("--fast", action="store_true")
     ap.add_argument("--full", action="store_true")
     ap.add_argument("--skip-micro", action="store_true")
+    ap.add_argument("--input-tokens", action="store_true")
     a = ap.parse_args()
     ref_import.install()
     torch.manual_seed(0)
     if not a.skip_micro:
         micro_fixtures()
+    if a.input_tokens:
+        input_token_fixtures()
     if a.full:
         full_fixtures()
     if a.front:

@@ -115,12 +115,18 @@ def test_indextts_default_kwargs_sample_reproducibly(tts):
     b = tts.gpt.inference_speech(mel, torch.from_numpy(sents[0])[None], do_sample=True, top_k=30, top_p=0.8, temperature=1.0,
                                  num_beams=1, repetition_penalty=10.0, max_generate_length=16)
     assert torch.equal(a, b)
-    # input_tokens continuation (model.py:672-686): the given tokens are forced, the returned codes start after them
-    base = tts.gpt.inference_speech(mel, torch.from_numpy(sents[0])[None], do_sample=False, num_beams=1, repetition_penalty=10.0,
-                                    max_generate_length=12)
-    cont = tts.gpt.inference_speech(mel, torch.from_numpy(sents[0])[None], input_tokens=base[:, :5], do_sample=False, num_beams=1,
-                                    repetition_penalty=10.0, max_generate_length=7)
-    assert torch.equal(cont, base[:, 5:12])
+
+
+@pytest.mark.parametrize("name", ["micro_input_tokens_b1", "micro_input_tokens_b2"])
+def test_input_tokens_continuation_matches_reference(tts, gold, name):
+    """`inference_speech(input_tokens=...)` (model.py:672-686) against the reference's own forward: the given tokens sit at
+    mel positions 1 .. n (they are part of the reference's first forward), the first generated token is fed at n + 2; the
+    returned codes start after the given ones."""
+    g = gold(name)
+    mel = torch.from_numpy(gold("micro_conditioning")["mel"]).cuda()
+    out = tts.gpt.inference_speech(mel, torch.from_numpy(g["text"]), input_tokens=torch.from_numpy(g["input_tokens"]),
+                                   do_sample=False, num_beams=1, repetition_penalty=10.0, max_generate_length=16)
+    assert np.array_equal(out.cpu().numpy(), g["codes"])
 
 
 def test_padding_test_through_dropin(tts, gold):

@@ -71,6 +71,24 @@ def test_prefix_and_decode_b1(gold, wg):
     close(tr["logits"], g["logits"], rtol=5e-4, atol=5e-4)
 
 
+@pytest.mark.parametrize("name", ["micro_input_tokens_b1", "micro_input_tokens_b2"])
+def test_input_tokens_continuation(gold, wg, name):
+    """inference_speech(input_tokens=...) (model.py:672-686): the given tokens sit in the reference's first forward at mel
+    positions 0 .. n, the first generated token is fed at n + 2; fixture = the reference's own forward."""
+    g = gold(name)
+    mel = torch.from_numpy(gold("micro_conditioning")["mel"])
+    cond = ogpt.get_conditioning(mel, wg, CFG.gpt)
+    tr = {}
+    codes = ogpt.greedy_generate(cond, torch.from_numpy(g["text"]), wg, CFG.gpt, 16, input_tokens=torch.from_numpy(g["input_tokens"]), trace=tr)
+    assert np.array_equal(codes.numpy(), g["codes"])
+    n = g["logits"].shape[1]
+    close(tr["logits"][:, :n], g["logits"], rtol=3e-4, atol=3e-4)
+    # the positions matter: replaying the given tokens as ordinary decode steps (positions 2, 3, ..) gives other logits
+    plain = {}
+    ogpt.greedy_generate(cond, torch.from_numpy(g["text"]), wg, CFG.gpt, 4, trace=plain)
+    assert np.abs(plain["logits"][:, 0].numpy() - g["logits"][:, 0]).max() > 1e-2
+
+
 def test_sensitivity_selfcheck(gold):
     """changing ONE text id must move step-0 logits far beyond tolerance and flip an id."""
     a, b = gold("micro_decode_b1"), gold("micro_decode_b1_alt")
