@@ -309,9 +309,12 @@ def measure(eng, cfg, a, BU, steps, warmup, rank, world, product_loop=False):
             pj = json.load(open(os.path.join(ROOT, "profiles", f)))
             if (int(pj.get("decode_rows", -1)) == B * a.beams and abs(float(pj.get("mean_S", -1)) - s_bar) <= 2.0 and a.dtype == "bf16"
                     and not a.micro and not a.gpt_fp8):
+                if int(pj.get("engine", 0)) != eng.decode_mode():
+                    continue  # counters of the other decode path (persistent engine vs launches)
                 traffic = int(pj["hbm_bytes_per_step"])
-                traffic_src = (f"profiles/{f}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py --no-graph at this run's "
-                               f"mean sequence length (S = {s_bar:.0f}), 2 x FETCH_SIZE + WRITE_SIZE per decode step")
+                traffic_src = (f"STATIC, from profiles/{f} (kernels at {pj.get('kernels_head', '?')}): rocprofv3 --pmc FETCH_SIZE / "
+                               f"WRITE_SIZE passes of bench.py --no-graph at this run's mean sequence length (S = {s_bar:.0f}), "
+                               f"2 x FETCH_SIZE + WRITE_SIZE per decode step; not re-measured by this run")
                 break
     except Exception:
         traffic = None

@@ -73,7 +73,14 @@ def conformer_pe(max_len: int, d: int) -> np.ndarray:
     return pe.unsqueeze(0).numpy()
 
 
-def gpt_state_dict(cfg, seed: int = 1234) -> Dict[str, np.ndarray]:
+def gpt_state_dict(cfg, seed: int = 1234, profile: str = "sharp") -> Dict[str, np.ndarray]:
+    """profile "sharp" (default, every parity fixture): Q / K projections x 2.5, so attention is close to an arg-max and a
+    one-token change flips greedy ids (SURVEY 8c sensitivity warning) - which also amplifies bf16 weight rounding to 0.1 - 0.3
+    relative on logits / latents.  profile "smooth": Q / K gain 1 (score std ~ 1, soft attention), mel_head gain 1: the
+    conditioning of a trained checkpoint - the bf16 ACCURACY tests use it, so their bounds can be tight enough to fail."""
+    assert profile in ("sharp", "smooth"), profile
+    qk_gain = 2.5 if profile == "sharp" else 1.0
+    head_gain = 3.0 if profile == "sharp" else 1.0
     g = cfg["gpt"]
     cm = g["condition_module"]
     D, NL, H = g["model_dim"], g["layers"], g["heads"]
@@ -126,8 +133,8 @@ def gpt_state_dict(cfg, seed: int = 1234) -> Dict[str, np.ndarray]:
     for i in range(NL):
         p = f"gpt.h.{i}."
         b.ln(p + "ln_1", D)
-        def sharpen(w, D=D):  # sharper attention: larger Q,K projections
-            w[:, : 2 * D] *= np.float32(2.5)
+        def sharpen(w, D=D, gain=qk_gain):  # sharper attention: larger Q,K projections
+            w[:, : 2 * D] *= np.float32(gain)
             return w
 
         b.t(p + "attn.c_attn.weight", (D, 3 * D), std=1.0 / math.sqrt(D), post=sharpen)
@@ -142,7 +149,7 @@ def gpt_state_dict(cfg, seed: int = 1234) -> Dict[str, np.ndarray]:
     b.ln("gpt.ln_f", D)
     b.ln("final_norm", D)
     b.lin("text_head", g["number_text_tokens"] + 1, D)
-    b.lin("mel_head", g["number_mel_codes"], D, gain=3.0)
+    b.lin("mel_head", g["number_mel_codes"], D, gain=head_gain)
     return b.build()
 
 

@@ -39,11 +39,11 @@ def tt(sd):
     return {k: torch.from_numpy(np.array(v)) for k, v in sd.items()}
 
 
-def build_ref_gpt(cfg, seed):
+def build_ref_gpt(cfg, seed, profile="sharp"):
     from indextts.gpt.model import UnifiedVoice
 
     m = UnifiedVoice(**cfg.gpt)
-    sd = tt(synth.gpt_state_dict(cfg, seed))
+    sd = tt(synth.gpt_state_dict(cfg, seed, profile=profile))
     ref_sd = m.state_dict()
     assert set(sd) == set(ref_sd), (sorted(set(sd) ^ set(ref_sd))[:10])
     for k in sd:
@@ -448,6 +448,41 @@ def long_fixtures():
 
 
 @torch.no_grad()
+def smooth_fixtures():
+    """The bf16 ACCURACY fixtures: IndexTTS-1.5 sizes on the "smooth" synthetic checkpoint (itts_hip.synth profile: Q / K gain
+    1, soft attention - fp32 compute on bf16-rounded weights moves its logits / latents by < 1e-2, against 0.1 - 0.3 on the
+    "sharp" parity checkpoint), so a bound of a few percent can tell a correct bf16 kernel from a wrong one.
+      smooth_decode_b1: greedy ids for 480 steps (stop masked), top-8 logits at steps up to S = 520, margins, latent T = 480
+      smooth_decode_b6: six different sentences as one batch (the MFMA decode path), 64 free-running greedy steps + margins"""
+    cfg = icfg.indextts_1_5()
+    g = cfg.gpt
+    print("[smooth] building reference UnifiedVoice (smooth profile) ...")
+    gpt = build_ref_gpt(cfg, 1234, profile="smooth")
+    mel = torch.from_numpy(synth.prompt_mel(511, seed=7))
+    L, NS = 105, 480
+    text = torch.from_numpy(synth.text_ids(L, 11, g.number_text_tokens)).view(1, L).int()
+    s0 = 32 + L + 2 + 1
+    steps = sorted({0, 1, 2, 8, 32, 64, 128, 200, 400 - s0, 320, 520 - s0, NS - 1})
+    t0 = time.time()
+    codes, logits, *_ = ref_greedy(gpt, mel, text, max_gen=NS, suppress_eos=True, trace_steps=set(steps))
+    print(f"  {NS}-step greedy in {time.time() - t0:.1f}s")
+    top = torch.topk(logits[0], 8, dim=-1)
+    T = 480
+    latent = gpt(mel, text, torch.tensor([L]), codes[:, :T].clone(), torch.tensor([T * 1024]), cond_mel_lengths=torch.tensor([511]),
+                 return_latent=True, clip_inputs=False)
+    rows = [0, 1, 239, 478, 479]
+    save("smooth_decode_b1", text=text, codes=codes, trace_steps=np.asarray(steps), top_idx=top.indices, top_val=top.values,
+         logits_rms=logits[0].pow(2).mean(-1).sqrt(), margins=ref_greedy.last_margins[0], latent_sample=latent[0, :, :16],
+         latent_rows=latent[0, rows], latent_row_idx=np.asarray(rows), latent_rms=latent.pow(2).mean().sqrt())
+    t6 = torch.stack([torch.from_numpy(synth.text_ids(L, 60 + i, g.number_text_tokens)).int() for i in range(6)])
+    t0 = time.time()
+    c6, lg6, *_ = ref_greedy(gpt, mel, t6, max_gen=64, suppress_eos=True, n_trace=1)
+    print(f"  6-row 64-step greedy in {time.time() - t0:.1f}s")
+    top6 = torch.topk(lg6[:, 0], 8, dim=-1)
+    save("smooth_decode_b6", text=t6, codes=c6, margins=ref_greedy.last_margins, top_idx0=top6.indices, top_val0=top6.values)
+
+
+@torch.no_grad()
 def fast_fixtures():
     """`infer_fast` (infer.py:332-537) on the micro config, greedy: 5 sentences, bucket size 2 -> length-sorted buckets,
     batched AR decode per bucket, per-sentence silence fix + latent, original order restored, BigVGAN over chunks of 2
@@ -577,6 +612,7 @@ if __name__ == "__main__":
     ap.add_argument("--full", action="store_true")
     ap.add_argument("--skip-micro", action="store_true")
     ap.add_argument("--input-tokens", action="store_true")
+    ap.add_argument("--smooth", action="store_true")
     a = ap.parse_args()
     ref_import.install()
     torch.manual_seed(0)
@@ -584,6 +620,8 @@ if __name__ == "__main__":
         micro_fixtures()
     if a.input_tokens:
         input_token_fixtures()
+    if a.smooth:
+        smooth_fixtures()
     if a.full:
         full_fixtures()
     if a.front:

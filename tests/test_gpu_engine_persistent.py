@@ -77,3 +77,13 @@ def test_engine_status_reports_no_timeout(eng16, cond):
     finally:
         eng16.debug()
     assert codes.shape[0] == 1 and codes.shape[1] >= 1
+
+
+def test_launch_path_eager_full_length_equals_graph(eng16, cond):
+    """The 122-launches-per-step path at the bench's full length WITHOUT graph capture (58 k eager launches: the run the
+    r02 rocprofv3 --pmc pass died in) against its graph replay: same ids, same logits - the eager path's scratch / state
+    indexing holds for 479 steps (the older graph-vs-eager test stops at 24)."""
+    text = np.stack([synth.text_ids(105, 41 + r, CFG.gpt.number_text_tokens) for r in range(2)]).astype(np.int32)
+    ref_codes, ref_lg = run(eng16, cond, text, 480, no_engine=True, chunk=64)
+    codes, lg = run(eng16, cond, text, 480, no_engine=True, no_graph=True, chunk=64)
+    assert np.array_equal(codes, ref_codes) and np.array_equal(lg.view(np.uint32), ref_lg.view(np.uint32))
