@@ -133,8 +133,8 @@ def test_bf16_latent(eng16s, mel, gold, control, accuracy):
 def test_bf16_free_running_six_rows_mfma_path(eng16s, mel, gold, accuracy):
     """Six different sentences as ONE decode batch (> 4 rows: skinny MFMA projections, 256-thread cache attention), greedy,
     free-running, against the reference's batched greedy ids: a row may part from the reference only where the reference's
-    own top-1 / top-2 margin is below 0.08 (logit std 1.0, |top logit| ~ 4: the bf16 logits carry 3e-3 relative = ~0.01 - 0.02
-    absolute error; r03 measured margins at the parting steps: see profiles/r03_accuracy.json) - a wrong kernel parts at a
+    own top-1 / top-2 margin is below 0.04 (logit std 1.0, |top logit| ~ 4: the bf16 logits carry 3e-3 relative = ~0.01 - 0.02
+    absolute error; r03 measured 0.0005 .. 0.018 at the parting steps: profiles/r03_accuracy.json) - a wrong kernel parts at a
     step with a comfortable margin."""
     g = gold("smooth_decode_b6")
     cond = eng16s.conditioning(mel)
@@ -157,5 +157,5 @@ def test_bf16_free_running_six_rows_mfma_path(eng16s, mel, gold, accuracy):
     accuracy["smooth_bf16_rows6_free_running_steps_equal_to_reference"] = agree
     accuracy["smooth_bf16_rows6_reference_margin_at_the_parting_step"] = at
     for r in range(6):
-        assert at[r] is None or at[r] < 0.08, f"row {r}: ids part at step {agree[r]} where the reference margin is {at[r]:.3f}"
+        assert at[r] is None or at[r] < 0.04, f"row {r}: ids part at step {agree[r]} where the reference margin is {at[r]:.3f}"
     assert sum(agree) >= 6 * 8 and sorted(agree)[-2] >= 16, agree  # most rows follow the reference for a while
