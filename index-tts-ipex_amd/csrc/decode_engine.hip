@@ -149,7 +149,7 @@ __device__ __forceinline__ void wait_own(unsigned ctr_lds, unsigned target, Rt& 
 // attention), so ONE lane per wave polls ONE granule first - a full pass per workgroup, repeated while the producers are
 // still computing, competes with their weight stream and stores for the fabric (MI355X_MICROARCH "polling-cost").
 template <int PER, bool SENTINEL, typename Sink>
-__device__ __forceinline__ void sweep2(const u64* __restrict__ g, int npairs, int gt, Rt& rt, Sink&& sink) {
+__device__ __forceinline__ void sweep2(const u64* __restrict__ g, int npairs, int gt, Rt& rt, Sink&& sink, int delay) {
   if (SENTINEL) {
     const int w = gt >> 6;
     const u64* __restrict__ p = g + 2 * min(npairs - 1, (npairs / 4) * w + npairs / 8);
@@ -168,7 +168,7 @@ __device__ __forceinline__ void sweep2(const u64* __restrict__ g, int npairs, in
   if (rt.dead) need = 0;
   unsigned spins = 0;
   // a publish needs ~0.65 us to become visible chip-wide: a pass started earlier fails AND slows the stores it waits for
-  for (int z = 0; z < rt.first_delay; ++z) __builtin_amdgcn_s_sleep(1);
+  for (int z = 0; z < delay; ++z) __builtin_amdgcn_s_sleep(1);
   while (need) {
     u32x4 x[PER];
 #pragma unroll
@@ -456,7 +456,7 @@ __global__ __launch_bounds__(1024) void decode_engine_kernel(EngArgs a) {
         __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): nothing the compiler counts stays pending past the gather branch
       } else {
         wait_own(own_lds, NCW * phase, rt);
-        sweep2<(NB * D / 2 + 255) / 256, false>(G - LSTRIDE + OH2, NB * D / 2, tl, rt, [&](int i, uint32_t v) { xf[i] = __uint_as_float(v); });
+        sweep2<(NB * D / 2 + 255) / 256, false>(G - LSTRIDE + OH2, NB * D / 2, tl, rt, [&](int i, uint32_t v) { xf[i] = __uint_as_float(v); }, rt.first_delay);
       }
     } else if (lw) {
       dma_wait_keep<0>();  // c_attn (and, before it, c_proj) of this block
@@ -698,9 +698,9 @@ __global__ __launch_bounds__(1024) void decode_engine_kernel(EngArgs a) {
     // ================= P3: context -> c_proj + residual =================
     if (gw) {
       if (acu)
-        sweep2<(NB * D / 4 + 255) / 256, false>(G + OCTX, NB * D / 4, tl, rt, [&](int i, uint32_t v) { xc[i] = v; });
+        sweep2<(NB * D / 4 + 255) / 256, false>(G + OCTX, NB * D / 4, tl, rt, [&](int i, uint32_t v) { xc[i] = v; }, rt.first_delay);
       else
-        sweep2<(NB * D / 4 + 255) / 256, true>(G + OCTX, NB * D / 4, tl, rt, [&](int i, uint32_t v) { xc[i] = v; });
+        sweep2<(NB * D / 4 + 255) / 256, true>(G + OCTX, NB * D / 4, tl, rt, [&](int i, uint32_t v) { xc[i] = v; }, a.ctx_delay);
     }  // (c_proj is older in the loader's queue than c_attn: it landed before this block's first barrier)
     ENG_STAMP(4)
     __syncthreads();
@@ -733,7 +733,7 @@ __global__ __launch_bounds__(1024) void decode_engine_kernel(EngArgs a) {
     // ================= P4: residual stream -> LN2 -> c_fc -> gelu_new =================
     if (gw) {
       wait_own(own_lds, NCW * phase, rt);
-      sweep2<(NB * D / 2 + 255) / 256, false>(G + OH1, NB * D / 2, tl, rt, [&](int i, uint32_t v) { xf[i] = __uint_as_float(v); });
+      sweep2<(NB * D / 2 + 255) / 256, false>(G + OH1, NB * D / 2, tl, rt, [&](int i, uint32_t v) { xf[i] = __uint_as_float(v); }, rt.first_delay);
     } else if (lw) {
       dma_wait_keep<0>();  // c_fc (and, before it, mlp.c_proj)
     }
@@ -779,7 +779,7 @@ __global__ __launch_bounds__(1024) void decode_engine_kernel(EngArgs a) {
     // ================= P5: gelu(fc) -> mlp.c_proj + residual =================
     if (gw) {
       wait_own(own_lds, NCW * phase, rt);
-      sweep2<(NB * D + 255) / 256, false>(G + OACT, NB * D, tl, rt, [&](int i, uint32_t v) { xa[i] = v; });
+      sweep2<(NB * D + 255) / 256, false>(G + OACT, NB * D, tl, rt, [&](int i, uint32_t v) { xa[i] = v; }, a.act_delay);
     } else if (lw && acu) {  // mlp.c_proj was requested behind LN2 here; the next block's c_proj (if any) is younger
       if (l + 1 < a.NL)
         dma_wait_keep<DmaCount<HO, D>::N>();

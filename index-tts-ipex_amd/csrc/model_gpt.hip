@@ -708,6 +708,10 @@ int Engine::decode_step_launch(hipStream_t s) {
     static const int e_thin = getenv("ITTS_ENGINE_THIN_FC") ? atoi(getenv("ITTS_ENGINE_THIN_FC")) : 0;
     ea.thin_fc = e_thin;
     ea.first_delay = e_fd;
+    static const int e_cd = getenv("ITTS_ENGINE_CTX_DELAY") ? atoi(getenv("ITTS_ENGINE_CTX_DELAY")) : 0;
+    static const int e_ad = getenv("ITTS_ENGINE_ACT_DELAY") ? atoi(getenv("ITTS_ENGINE_ACT_DELAY")) : 20;
+    ea.ctx_delay = e_cd;
+    ea.act_delay = e_ad;
     ea.pass_sleep = e_ps;
     static const bool e_stamps = getenv("ITTS_ENGINE_STAMPS") != nullptr;
     if (debug && e_stamps && !dry) ea.stamp = (unsigned*)ds.logits + 0;  // [16][V] fp32 scratch >= 256 * 24 * 16 words; the head overwrites it later
