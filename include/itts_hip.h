@@ -174,6 +174,14 @@ int itts_gpt_set_input_tokens(itts_engine* e, const int32_t* ids_host, int B, in
  * token step; <= 2 rows, bf16, IndexTTS-1.5 dims, no beams / fp8 copies), 0 = five launches per block. */
 int itts_gpt_decode_mode(itts_engine* e);
 
+/* Host-side token choice, for generate() modes outside the device samplers' limits (HF warpers over the whole vocabulary:
+ * `top_k = 0 / None`, infer.py:116-124 forwards it verbatim and webui.py:393-402 offers 0): with on = 1, itts_gpt_prefill and
+ * itts_gpt_decode(e, 1, ..) stop behind the head GEMV; the caller reads the logits (itts_gpt_fetch), applies the logits
+ * processors / warpers and the draw itself, and itts_gpt_commit hands the chosen token of every row (host int32 [B]) to the
+ * sampler's bookkeeping (ids, repetition bitmap, eos state, step counter, next input embedding).  One stream sync per token. */
+int itts_gpt_set_host_sampling(itts_engine* e, int on);
+int itts_gpt_commit(itts_engine* e, const int32_t* tokens_host, itts_stream stream);
+
 /* G1/G3/G4 step 0: prepare_gpt_inputs (model.py:591-654) + prefill + first greedy token.
  * cond fp32 [latents, D]; text ids host int32 [B, L] (may hold start/stop padding ids, stripped per row).
  * Synchronises the stream once (uploads the row descriptors). */

@@ -216,6 +216,14 @@ int itts_gpt_set_input_tokens(itts_engine* e, const int32_t* ids_host, int B, in
   return e->e.gpt_set_input_tokens(ids_host, B, n);
 }
 int itts_gpt_decode_mode(itts_engine* e) { return e ? e->e.ds.last_mode : -1; }
+int itts_gpt_set_host_sampling(itts_engine* e, int on) {
+  ENG(e);
+  return e->e.gpt_set_host_sampling(on);
+}
+int itts_gpt_commit(itts_engine* e, const int32_t* tokens_host, itts_stream s) {
+  ENG(e);
+  return e->e.gpt_commit(tokens_host, (hipStream_t)s);
+}
 int itts_gpt_set_forced(itts_engine* e, const int32_t* ids_host, int B, int n) {
   ENG(e);
   return e->e.gpt_set_forced(ids_host, B, n);

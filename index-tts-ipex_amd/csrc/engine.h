@@ -165,6 +165,7 @@ struct DecodeState {
   float* scores2 = nullptr;                        // [cap_B][V] its output
   int* forced = nullptr;  // [cap_B][cap_gen] forced token per (row, step) or -1; allocated with ids
   int use_forced = 0, graph_forced = 0;
+  int host_sample = 0, graph_host_sample = 0;  // the caller picks every token (itts_gpt_commit): the step stops behind the head
   int input_n = 0, graph_input_n = 0;  // forced steps that are HF input_tokens (positions k + 1 instead of k + 2)
   int last_mode = 0;                   // 1: the last captured / launched decode step ran on the persistent engine
   float graph_penalty = 0.f;
@@ -225,6 +226,8 @@ struct Engine {
   std::vector<float> sample_uniforms;  // host copy, uploaded by the next prefill
   int gpt_set_forced(const int32_t* ids_host, int B, int n);
   int gpt_set_input_tokens(const int32_t* ids_host, int B, int n);
+  int gpt_set_host_sampling(int on);
+  int gpt_commit(const int32_t* tokens_host, hipStream_t s);
   int forced_input = 0;  // the forced tokens are HF `input_tokens`: token k sits at mel position k + 1 (model.py:141-144)
   int gpt_set_typical(float mass);
   int gpt_set_beam_sample(int num_beams, int top_k, float top_p, float temperature, const float* uniforms_host, long n);

@@ -451,6 +451,10 @@ int Engine::gpt_prefill(const float* cond_dev, const int32_t* text_ids_in, int B
   }
   ds.use_forced = forced_n > 0;
   ds.input_n = forced_input ? forced_n : 0;
+  if (ds.host_sample) {
+    ITTS_REQUIRE(forced_n == 0 && nbeam == 1 && !ds.do_sample, "gpt_prefill: host sampling excludes forced tokens, beams and the device sampler");
+    ITTS_HIP_CHECK(hipMemsetAsync(ds.forced, 0xFF, (size_t)B * max_gen * 4, s));  // -1: nothing forced yet
+  }
   if (ds.use_forced) {
     ITTS_REQUIRE(forced_B == B || forced_B == 1, "gpt_prefill: forced tokens were set for a different batch size");
     ITTS_REQUIRE(forced_n <= max_gen, "gpt_prefill: more forced tokens than max_gen");
@@ -561,6 +565,7 @@ int Engine::head_and_sample(hipStream_t s) {
     ITTS_TRY(gemv(g, gpt.head.dt, s));
   }
   ITTS_TRY(tap("logits0", ds.logits, F32, (int64_t)B * V, s));
+  if (ds.host_sample) return OK;  // the caller reads the logits, picks the tokens and commits them (gpt_commit)
   const float* lg_in = ds.logits;
   const bool typical = ds.typical_mass > 0.f && (ds.do_sample || (ds.nb > 1 && ds.beam_sample));
   if (typical) {  // TypicalLogitsWarper sits in HF's logits_processor list, right after the repetition penalty
@@ -926,6 +931,63 @@ int Engine::gpt_set_input_tokens(const int32_t* ids_host, int B, int n) {
   return OK;
 }
 
+// Host-side token choice for the generate() modes the device samplers do not cover (HF warpers over the FULL vocabulary:
+// top_k = 0 / None): prefill / decode(1) stop behind the head GEMV, the caller fetches the logits, applies the processors and
+// warpers itself and hands the chosen token of every row back with gpt_commit, which runs the sampler's bookkeeping (ids,
+// repetition bitmap, eos state, step counter, next step's input embedding) with those tokens.
+int Engine::gpt_set_host_sampling(int on) {
+  ds.host_sample = on ? 1 : 0;
+  return OK;
+}
+
+int Engine::gpt_commit(const int32_t* tokens_host, hipStream_t s) {
+  if (!ds.active || !ds.host_sample) {
+    set_error("gpt_commit: needs an active generation in host-sampling mode");
+    return E_STATE;
+  }
+  ITTS_REQUIRE(tokens_host && ds.nb == 1, "gpt_commit: tokens missing (or beams active)");
+  std::vector<int> lens(ds.B);
+  ITTS_HIP_CHECK(hipMemcpyAsync(lens.data(), ds.len, (size_t)ds.B * 4, hipMemcpyDeviceToHost, s));
+  ITTS_HIP_CHECK(hipStreamSynchronize(s));
+  for (int b = 0; b < ds.B; ++b) {
+    ITTS_REQUIRE(tokens_host[b] >= 0 && tokens_host[b] < cfg.number_mel_codes, "gpt_commit: token id out of range");
+    ITTS_REQUIRE(lens[b] < ds.max_gen, "gpt_commit: generation already at max length");
+    ITTS_HIP_CHECK(hipMemcpyAsync(ds.forced + (size_t)b * ds.max_gen + lens[b], tokens_host + b, 4, hipMemcpyHostToDevice, s));
+  }
+  ITTS_HIP_CHECK(hipStreamSynchronize(s));  // tokens_host is the caller's buffer
+  const int keep = ds.host_sample, forced = ds.use_forced;
+  ds.host_sample = 0;
+  ds.use_forced = 1;
+  const float* lg = ds.logits;
+  (void)lg;
+  // the sampler's commit path with the forced table: argmax is computed and overridden, bookkeeping as in every other mode
+  SamplerArgs sa;
+  sa.logits = ds.logits;
+  sa.seen = ds.seen;
+  sa.ids = ds.ids;
+  sa.cur_tok = ds.cur_tok;
+  sa.unfinished = ds.unfinished;
+  sa.step = ds.len;
+  sa.V = cfg.number_mel_codes;
+  sa.max_gen = ds.max_gen;
+  sa.stop = cfg.stop_mel_token;
+  sa.suppress_stop = ds.suppress_stop;
+  sa.penalty = ds.penalty;
+  sa.h_next = ds.h;
+  sa.emb = gpt.mel_emb;
+  sa.pos = gpt.mel_pos;
+  sa.D = cfg.model_dim;
+  sa.pos_rows = cfg.max_mel_tokens + 3;
+  sa.emb_bf16 = adt == BF16;
+  sa.forced = ds.forced;
+  sa.input_n = 0;
+  sa.B = ds.B;
+  const int st = sampler2_step(sa, ds.B, s);
+  ds.host_sample = keep;
+  ds.use_forced = forced;
+  return st;
+}
+
 int Engine::gpt_set_forced(const int32_t* ids_host, int B, int n) {
   forced_input = 0;
   if (n <= 0 || !ids_host) {
@@ -953,7 +1015,7 @@ int Engine::gpt_decode(int nsteps, hipStream_t s) {
     // everything SamplerArgs carries by value is baked into the captured nodes: max_gen is the ids row stride and the
     // `k < max_gen` bound, so a per-request max_mel_tokens must re-capture (same B / Smax notwithstanding)
     const bool stale = !d.graph || d.graph_B != d.B || d.graph_Smax != d.Smax || d.graph_max_gen != d.max_gen ||
-                       d.graph_forced != d.use_forced || d.graph_input_n != d.input_n || d.graph_fuse != (d.fuse && !d.fuse_failed) || d.graph_eng != (int)engine_usable() || d.graph_nb != d.nb || d.graph_beam_sample != d.beam_sample ||
+                       d.graph_forced != d.use_forced || d.graph_input_n != d.input_n || d.graph_host_sample != d.host_sample || d.graph_fuse != (d.fuse && !d.fuse_failed) || d.graph_eng != (int)engine_usable() || d.graph_nb != d.nb || d.graph_beam_sample != d.beam_sample ||
                        d.graph_length_penalty != d.length_penalty || d.graph_typical != d.typical_mass || d.graph_penalty != d.penalty || d.graph_suppress != d.suppress_stop || d.graph_sample != d.do_sample ||
                        d.graph_top_k != d.top_k || d.graph_top_p != d.top_p || d.graph_temperature != d.temperature;
     // two executables: one step, and GK steps back to back (one launch per GK tokens: the gap between consecutive graph
@@ -988,6 +1050,7 @@ int Engine::gpt_decode(int nsteps, hipStream_t s) {
       d.graph_max_gen = d.max_gen;
       d.graph_forced = d.use_forced;
       d.graph_input_n = d.input_n;
+      d.graph_host_sample = d.host_sample;
       d.graph_fuse = d.fuse && !d.fuse_failed;
       d.graph_eng = (int)engine_usable();
       d.graph_nb = d.nb;

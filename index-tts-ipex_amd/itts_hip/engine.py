@@ -268,6 +268,10 @@ class Engine:
         (not do_sample) over num_beams beams per row; returns the best finalized hypothesis per row."""
         beams = num_beams > 1
         nrow = np.asarray(text_ids).shape[0]
+        if do_sample and not beams and (not top_k or int(top_k) < 1 or int(top_k) > 128):
+            # HF: TopK warper off (top_k = 0 / None) or wider than the device sampler's 128 candidates - exact on the host
+            return self._generate_host_sampled(cond, text_ids, max_gen, repetition_penalty, suppress_stop, int(top_k or 0), top_p,
+                                               temperature, seed, uniforms, typical_mass)
         typical = bool(do_sample and typical_mass)
         if typical:  # typical_sampling=True (model.py:690-697): TypicalLogitsWarper in front of the warpers
             L.check(self.lib.itts_gpt_set_typical(self.h, float(typical_mass)), "gpt_set_typical")
@@ -308,6 +312,43 @@ class Engine:
             hit = np.nonzero(row == stop)[0]
             n = max(n, int(hit[0]) + 1 if len(hit) else step)
         return codes[:, :n]
+
+    def _generate_host_sampled(self, cond, text_ids, max_gen, repetition_penalty, suppress_stop, top_k, top_p, temperature, seed,
+                               uniforms, typical_mass) -> np.ndarray:
+        """HF sample() with the token choice on the host (infer_core.host_sample_step: warpers over the WHOLE vocabulary): the
+        step stops behind the head GEMV, the logits come back, the chosen tokens go in through itts_gpt_commit.  One stream
+        sync per token - the price of a mode the device samplers (<= 128 kept candidates) do not cover."""
+        from . import infer_core
+
+        nrow = np.asarray(text_ids).shape[0]
+        if uniforms is None:
+            uniforms = np.random.default_rng(seed).random((max_gen, nrow), dtype=np.float32)
+        stop, start = self.ccfg.stop_mel_token, self.ccfg.start_mel_token
+        seen = [{1, start} for _ in range(nrow)]  # fake prefix ids are all 1, the last one start_mel (model.py:644-653)
+        unfinished = np.ones(nrow, dtype=bool)
+        out = np.full((nrow, max_gen), stop, dtype=np.int64)
+        n = 0
+        L.check(self.lib.itts_gpt_set_host_sampling(self.h, 1), "gpt_set_host_sampling")
+        try:
+            self.prefill(cond, text_ids, max_gen, repetition_penalty, suppress_stop)
+            for k in range(max_gen):
+                _, lg = self.fetch(logits=True)
+                toks = infer_core.host_sample_step(lg, seen, float(repetition_penalty), float(temperature), top_k, top_p,
+                                                   float(typical_mass or 0.0), uniforms[k], stop, bool(suppress_stop))
+                toks = np.where(unfinished, toks, stop).astype(np.int32)
+                L.check(self.lib.itts_gpt_commit(self.h, toks.ctypes.data_as(C.c_void_p), self._s()), "gpt_commit")
+                out[:, k] = toks
+                n = k + 1
+                for r in range(nrow):
+                    seen[r].add(int(toks[r]))
+                unfinished &= toks != stop
+                if not unfinished.any() or n == max_gen:
+                    break
+                self.decode(1)
+            self._exit()
+        finally:
+            L.check(self.lib.itts_gpt_set_host_sampling(self.h, 0), "gpt_set_host_sampling")
+        return out[:, :n]
 
     def latent(self, cond: torch.Tensor, text_ids: np.ndarray, codes: np.ndarray) -> torch.Tensor:
         """-> latent [1, T, D] engine dtype."""

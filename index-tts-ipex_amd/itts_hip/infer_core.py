@@ -82,8 +82,10 @@ def sampling_kwargs(do_sample, num_beams, top_k, top_p, temperature, typical_sam
       not do_sample, num_beams == 1  greedy
       typical_sampling               the reference's TypicalLogitsWarper(typical_mass) in front of the warpers (sampling modes)
     Limits of the device samplers (the web UI offers num_beams 1..10 and top_k 0..100): num_beams <= 10; at most 128 kept
-    candidates per row, so top_k = 0 / None (HF: warper off) or > 128 is clamped to 128 with a warning.  The seed is drawn
-    from torch's global RNG so that torch.manual_seed governs the run as it does for the reference's torch.multinomial."""
+    candidates per row.  top_k = 0 / None (HF: TopK warper off) or > 128 with ONE beam is exact all the same: the token choice
+    then runs on the host over the whole vocabulary (host_sample_step below, one logits read-back per token); with several
+    beams it is clamped to 128 with a warning.  The seed is drawn from torch's global RNG so that torch.manual_seed governs
+    the run as it does for the reference's torch.multinomial."""
     import warnings
 
     import torch
@@ -99,9 +101,79 @@ def sampling_kwargs(do_sample, num_beams, top_k, top_p, temperature, typical_sam
         return dict(num_beams=nb, length_penalty=lp) if nb > 1 else {}
     k = int(top_k) if top_k else 0
     if k < 1 or k > 128:
-        warnings.warn(f"itts_hip: top_k={top_k} is outside [1, 128]; using 128", RuntimeWarning)
-        k = 128
+        if nb > 1:
+            warnings.warn(f"itts_hip: top_k={top_k} is outside [1, 128] (with num_beams > 1); using 128", RuntimeWarning)
+            k = 128
+        else:
+            k = 0 if k < 1 else k  # one beam: exact on the host (Engine.generate takes the host-sampling path)
     p = 1.0 if top_p is None else float(top_p)
     return dict(do_sample=True, top_k=k, top_p=min(max(p, 1e-6), 1.0), temperature=float(temperature or 1.0), num_beams=nb,
                 typical_mass=float(typical_mass) if typical_sampling else 0.0, length_penalty=lp,
                 seed=int(torch.randint(0, 2 ** 31 - 1, (1,)).item()))
+
+
+# ---- host-side token choice (HF GenerationMixin.sample over the whole vocabulary) ----
+def host_distribution(scores: np.ndarray, seen_ids, penalty: float, temperature: float, top_k: int, top_p: float,
+                      typical_mass: float, stop: int, suppress_stop: bool):
+    """One row of HF 4.36.2 `sample()`'s score pipeline, in the order generate() builds it for infer.py:116-124 /
+    model.py:688-703: RepetitionPenaltyLogitsProcessor over every id seen so far (fake prefix id, start token, generated
+    codes) -> [TypicalLogitsWarper] -> TemperatureLogitsWarper -> TopKLogitsWarper (off when top_k < 1) -> TopPLogitsWarper.
+    Returns (kept token ids in descending-score order - ties: lower id first -, un-normalised weights exp(s - s_max)).  fp32."""
+    s = np.asarray(scores, dtype=np.float32).copy()
+    ids = np.fromiter(seen_ids, dtype=np.int64)
+    if penalty != 1.0 and ids.size:
+        v = s[ids]
+        s[ids] = np.where(v < 0, v * np.float32(penalty), v / np.float32(penalty)).astype(np.float32)
+    if suppress_stop:
+        s[stop] = -np.inf
+    if typical_mass and 0.0 < typical_mass < 1.0:
+        s = _typical_filter(s, float(typical_mass))
+    if temperature != 1.0:
+        s = (s / np.float32(temperature)).astype(np.float32)
+    keep = np.nonzero(np.isfinite(s))[0]
+    if top_k and top_k >= 1 and top_k < keep.size:
+        kth = np.partition(s[keep], keep.size - top_k)[keep.size - top_k]
+        keep = keep[s[keep] >= kth]  # ties with the k-th largest stay (HF compares against the k-th value)
+    order = np.lexsort((keep, -s[keep].astype(np.float64)))
+    idx = keep[order]
+    e = np.exp((s[idx] - s[idx[0]]).astype(np.float32)).astype(np.float32)
+    n = idx.size
+    if top_p is not None and top_p < 1.0 and n > 1:
+        # ascending cumulative probability <= 1 - top_p is removed; the best token always stays (min_tokens_to_keep = 1)
+        z = np.float32(e.sum(dtype=np.float32))
+        tail = np.cumsum((e[::-1] / z).astype(np.float32), dtype=np.float32)  # tail[i] = mass of the i + 1 smallest
+        n -= int((tail[: n - 1] <= np.float32(1.0) - np.float32(top_p)).sum())
+    return idx[:n], e[:n]
+
+
+def host_sample_step(logits: np.ndarray, seen: Sequence[set], penalty: float, temperature: float, top_k: int, top_p: float,
+                     typical_mass: float, u: np.ndarray, stop: int, suppress_stop: bool) -> np.ndarray:
+    """One multinomial draw per row over host_distribution, taken as the inverse-CDF lookup of the caller's uniform u[row]
+    over the kept tokens in descending-score order - the convention of the device samplers."""
+    lg = np.asarray(logits, dtype=np.float32)
+    out = np.empty(lg.shape[0], dtype=np.int32)
+    for r in range(lg.shape[0]):
+        idx, e = host_distribution(lg[r], seen[r], penalty, temperature, top_k, top_p, typical_mass, stop, suppress_stop)
+        c = np.cumsum(e, dtype=np.float32)
+        target = np.float32(np.float32(u[r]) * c[-1])
+        out[r] = int(idx[min(int(np.searchsorted(c, target, side="left")), idx.size - 1)])
+    return out
+
+
+def _typical_filter(s: np.ndarray, mass: float) -> np.ndarray:
+    """The reference's TypicalLogitsWarper (indextts/utils/typical_sampling.py:9-30, min_tokens_to_keep = 1) on one fp32 row."""
+    m = s.max()
+    z = np.exp((s - m).astype(np.float32)).astype(np.float32)
+    normalized = ((s - m) - np.float32(np.log(z.sum(dtype=np.float32)))).astype(np.float32)
+    p = np.exp(normalized).astype(np.float32)
+    with np.errstate(invalid="ignore"):
+        ent = -np.nansum(normalized * p, dtype=np.float32)
+    shifted = np.abs((-normalized) - ent).astype(np.float32)
+    order = np.argsort(shifted, kind="stable")
+    so = s[order]
+    eo = np.exp((so - so.max()).astype(np.float32)).astype(np.float32)
+    cum = np.cumsum(eo / eo.sum(dtype=np.float32), dtype=np.float32)
+    last = min(int((cum < np.float32(mass)).sum()), s.size - 1)
+    out = s.copy()
+    out[order[shifted[order] > shifted[order][last]]] = -np.inf
+    return out

@@ -78,6 +78,8 @@ _PROTOS = {
     "itts_gpt_set_forced": (i32, [vp, vp, i32, i32]),
     "itts_gpt_set_input_tokens": (i32, [vp, vp, i32, i32]),
     "itts_gpt_decode_mode": (i32, [vp]),
+    "itts_gpt_set_host_sampling": (i32, [vp, i32]),
+    "itts_gpt_commit": (i32, [vp, vp, vp]),
     "itts_gpt_set_typical": (i32, [vp, f32]),
     "itts_gpt_set_beams": (i32, [vp, i32, i32, i32, f32, f32, f32, vp, i64]),
     "itts_gpt_set_beam_sample": (i32, [vp, i32, i32, f32, f32, vp, i64]),

@@ -336,3 +336,28 @@ def test_typical_sampling_single_beam_matches_oracle_fp32(eng32, gold):
     assert got.shape == want.shape and np.array_equal(got, want), (got, want)
     plain = eng32.generate(cond, g["text"], n, do_sample=True, top_k=30, top_p=0.8, temperature=0.9, uniforms=u)
     assert not np.array_equal(plain, got)  # the filter changes the distribution
+
+
+def test_sampling_with_topk_off_runs_on_the_host_exactly(gold):
+    """HF: top_k = 0 / None switches the TopK warper off (webui.py:393-402 offers 0, infer.py:116-124 forwards it): the token
+    choice then runs on the host over the whole vocabulary (Engine._generate_host_sampled -> itts_gpt_commit).  Micro config,
+    fp32: ids equal to the oracle's sample() with top_k = V (the oracle's warper restatement is pinned to transformers)."""
+    cfg = icfg.micro()
+    eng = ieng.build_engine(cfg, "fp32", parts=("gpt",))
+    g = gold("micro_decode_b1")
+    mel = torch.from_numpy(gold("micro_conditioning")["mel"])
+    cond = eng.conditioning(mel)
+    text = np.concatenate([g["text"], gold("micro_decode_b1_alt")["text"]], 0).astype(np.int32)
+    V = cfg.gpt.number_mel_codes
+    u = np.random.default_rng(17).random((20, 2), dtype=np.float32)
+    got = eng.generate(cond, text, 20, do_sample=True, top_k=0, top_p=0.8, temperature=0.9, uniforms=u)
+    wg = ogpt.to_torch(synth.gpt_state_dict(cfg, 1234))
+    ocond = ogpt.get_conditioning(mel, wg, cfg.gpt)
+    want = ogpt.greedy_generate(ocond, torch.from_numpy(text), wg, cfg.gpt, 20,
+                                sampling={"top_k": V, "top_p": 0.8, "temperature": 0.9, "uniforms": u}).numpy()
+    assert np.array_equal(got, want[:, : got.shape[1]]) and got.shape[1] >= 1
+    # and the device sampler still serves top_k <= 128
+    got2 = eng.generate(cond, text, 12, do_sample=True, top_k=30, top_p=0.8, temperature=0.9, uniforms=u)
+    want2 = ogpt.greedy_generate(ocond, torch.from_numpy(text), wg, cfg.gpt, 12,
+                                 sampling={"top_k": 30, "top_p": 0.8, "temperature": 0.9, "uniforms": u}).numpy()
+    assert np.array_equal(got2, want2[:, : got2.shape[1]])

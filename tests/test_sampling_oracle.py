@@ -164,3 +164,54 @@ def test_typical_filter_matches_reference_class(V, mass, min_keep):
         assert (kg != kw).sum() <= 4 and float(p[kg != kw].sum()) < 1e-5, (trial, int(kg.sum()), int(kw.sum()))
         both = kg & kw
         assert np.array_equal(got[both], want[both])
+
+
+@pytest.mark.parametrize("V", [66, 8194])
+@pytest.mark.parametrize("cfg", [(0, 0.8, 1.0), (0, 0.95, 0.7), (0, 1.0, 1.3), (300, 0.9, 1.0), (0, 0.3, 1.0)])
+def test_host_sampler_matches_hf_processors_over_the_whole_vocabulary(V, cfg):
+    """The product's HOST token choice (itts_hip.infer_core.host_distribution: generate() modes the device samplers do not
+    cover - top_k = 0 / None = HF's TopK warper off, or top_k > 128) against the installed transformers processors:
+    RepetitionPenalty -> Temperature -> [TopK] -> TopP, kept set and probabilities."""
+    from itts_hip import infer_core
+
+    top_k, top_p, temp = cfg
+    rng = np.random.default_rng(V * 7 + top_k + int(top_p * 100))
+    for trial in range(6):
+        scores = (rng.standard_normal(V) * (0.5 + trial)).astype(np.float32)
+        seen = set(int(x) for x in rng.integers(0, V, 5))
+        stop = V - 1
+        idx, e = infer_core.host_distribution(scores, seen, 10.0, temp, top_k, top_p, 0.0, stop, trial % 2 == 1)
+        s = torch.from_numpy(scores)[None].clone()
+        ids = torch.tensor([sorted(seen)])
+        s = tlp.RepetitionPenaltyLogitsProcessor(10.0)(ids, s)
+        if trial % 2 == 1:
+            s[0, stop] = -float("inf")
+        if temp != 1.0:
+            s = tlp.TemperatureLogitsWarper(temp)(ids, s)
+        if top_k >= 1:
+            s = tlp.TopKLogitsWarper(top_k=top_k, min_tokens_to_keep=1)(ids, s)
+        if top_p < 1.0:
+            s = tlp.TopPLogitsWarper(top_p=top_p, min_tokens_to_keep=1)(ids, s)
+        p = torch.softmax(s, -1)[0].numpy()
+        support = np.nonzero(p > 0)[0]
+        assert set(idx.tolist()) == set(support.tolist()), (trial, cfg, len(idx), len(support))
+        assert np.abs(e / e.sum() - p[idx]).max() < 2e-6
+        assert np.all(np.diff(p[idx]) <= 1e-9)
+    # the draw: inverse CDF over the kept tokens in descending order
+    toks = infer_core.host_sample_step(scores[None], [seen], 10.0, temp, top_k, top_p, 0.0, np.asarray([0.0], np.float32), stop, False)
+    idx, e = infer_core.host_distribution(scores, seen, 10.0, temp, top_k, top_p, 0.0, stop, False)
+    assert toks[0] == idx[0]
+
+
+def test_host_typical_filter_matches_reference_subclass():
+    from itts_hip import infer_core
+
+    rng = np.random.default_rng(11)
+    base = getattr(tlp, "TypicalLogitsWarper", None)
+    if base is None:
+        pytest.skip("installed transformers has no TypicalLogitsWarper")
+    for V, mass in ((66, 0.9), (8194, 0.9), (8194, 0.3)):
+        scores = (rng.standard_normal(V) * 2).astype(np.float32)
+        got = infer_core._typical_filter(scores, mass)
+        want = base(mass=mass, min_tokens_to_keep=1)(torch.zeros(1, 1, dtype=torch.long), torch.from_numpy(scores)[None].clone())[0].numpy()
+        assert np.array_equal(np.isfinite(got), np.isfinite(want)), (V, mass)
