@@ -415,6 +415,7 @@ int Engine::gpt_prefill(const float* cond_dev, const int32_t* text_ids_in, int B
   const int S0 = sp + 1;      // + start_mel_token
   const int Smax = (S0 + max_gen + 255) / 256 * 256;  // coarse, so one captured graph serves many L
   ITTS_REQUIRE(Smax <= 2048, "gpt_prefill: sequence too long for the decode attention kernel");
+  ITTS_REQUIRE(max_gen < 4095, "gpt_prefill: max_gen must stay below 4095 (12-bit step field of the fused hand-off tags)");
   ITTS_TRY(ensure_decode_state(B, Smax, max_gen, s));
   ds.prefix = sp;
   ds.penalty = penalty;
@@ -1077,6 +1078,17 @@ int Engine::gpt_decode(int nsteps, hipStream_t s) {
 // abort word of the persistent decode engine: a hand-off wait gave up, so the codes of this generation are not valid.
 // The engine is switched off for this Engine (launch path from the next generation on) and its state re-initialised.
 int Engine::engine_check(hipStream_t s) {
+  if (ds.fuse_err && (ds.fuse || ds.graph_fuse)) {  // the opt-in fused projection + attention launch: checked at fetch too
+    int ferr = 0;
+    ITTS_HIP_CHECK(hipMemcpyAsync(&ferr, ds.fuse_err, 4, hipMemcpyDeviceToHost, s));
+    ITTS_HIP_CHECK(hipStreamSynchronize(s));
+    if (ferr) {  // an attention workgroup gave up waiting for its q / k / v: the codes of this generation are not valid
+      ds.fuse_failed = 1;  // later generations take the two-launch path
+      ITTS_HIP_CHECK(hipMemsetAsync(ds.fuse_err, 0, 4, s));
+      set_error("in-launch q/k/v hand-off timed out (fused projection + attention disabled for this engine; the codes of this generation are not valid)");
+      return E_HIP;
+    }
+  }
   if (!ds.eng_ctr) return OK;
   unsigned host[2] = {0, 0};
   ITTS_HIP_CHECK(hipMemcpyAsync(host, ds.eng_ctr, 8, hipMemcpyDeviceToHost, s));
@@ -1096,18 +1108,10 @@ int Engine::gpt_status(int* steps, int* n_unf, hipStream_t s) {
     return E_STATE;
   }
   std::vector<int> host(ds.B + 1);
-  int ferr = 0;
-  if (ds.fuse_err) ITTS_HIP_CHECK(hipMemcpyAsync(&ferr, ds.fuse_err, 4, hipMemcpyDeviceToHost, s));
   ITTS_HIP_CHECK(hipMemcpyAsync(host.data(), ds.len, 4, hipMemcpyDeviceToHost, s));
   ITTS_HIP_CHECK(hipMemcpyAsync(host.data() + 1, ds.unfinished, (size_t)ds.B * 4, hipMemcpyDeviceToHost, s));
   ITTS_HIP_CHECK(hipStreamSynchronize(s));
   ITTS_TRY(engine_check(s));
-  if (ferr) {  // an attention workgroup gave up waiting for its q / k / v: the codes of this generation are not valid
-    ds.fuse_failed = 1;  // later generations take the two-launch path
-    ITTS_HIP_CHECK(hipMemsetAsync(ds.fuse_err, 0, 4, s));
-    set_error("gpt_status: in-launch q/k/v hand-off timed out (fused projection + attention disabled for this engine)");
-    return E_HIP;
-  }
   if (steps) *steps = host[0];
   if (n_unf) {
     int n = 0;

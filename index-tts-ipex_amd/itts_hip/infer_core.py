@@ -97,6 +97,9 @@ def sampling_kwargs(do_sample, num_beams, top_k, top_p, temperature, typical_sam
         warnings.warn(f"itts_hip: num_beams={nb} > 10 is not supported; using 10", RuntimeWarning)
         nb = 10
     lp = float(length_penalty or 0.0)
+    if typical_sampling and not do_sample:
+        # HF appends TypicalLogitsWarper to `logits_processor` (model.py:690-697), so it would also filter greedy / beam search
+        warnings.warn("itts_hip: typical_sampling is ignored when do_sample=False (greedy / beam search run without it)", RuntimeWarning)
     if not do_sample:
         return dict(num_beams=nb, length_penalty=lp) if nb > 1 else {}
     k = int(top_k) if top_k else 0
