@@ -61,8 +61,19 @@ class UnifiedVoice:
         search (do_sample=False, num_beams > 1) with top_k <= 128, top_p, temperature, repetition_penalty, length_penalty
         and typical_sampling run on the device.  `input_tokens` [b or 1, n] (model.py:672-686): given mel tokens the
         generation continues after; like the reference, the returned codes start after them."""
-        if num_return_sequences != 1:
-            raise NotImplementedError("num_return_sequences > 1")
+        nrs = int(num_return_sequences)
+        if nrs < 1:
+            raise ValueError("num_return_sequences has to be >= 1")
+        if nrs > 1:
+            # HF expands every input row num_return_sequences times (repeat_interleave) and samples the copies independently
+            # (model.py:655,698-703 -> GenerationMixin._expand_inputs_for_generation); greedy search with nrs > 1 is an error in
+            # HF too, and returning the n best beam hypotheses is not implemented here
+            if not hf_generate_kwargs.get("do_sample", False):
+                raise ValueError("num_return_sequences has to be 1 when doing greedy search")
+            if int(hf_generate_kwargs.get("num_beams", 1) or 1) > 1:
+                raise NotImplementedError("num_return_sequences > 1 together with num_beams > 1")
+            if input_tokens is not None:
+                raise NotImplementedError("num_return_sequences > 1 together with input_tokens")
         sample_kw = infer_core.sampling_kwargs(hf_generate_kwargs.get("do_sample", False), hf_generate_kwargs.get("num_beams", 1),
                                                hf_generate_kwargs.get("top_k", 50), hf_generate_kwargs.get("top_p", 1.0),
                                                hf_generate_kwargs.get("temperature", 1.0), typical_sampling, typical_mass,
@@ -71,6 +82,8 @@ class UnifiedVoice:
         ids = text_inputs.detach().cpu().numpy() if isinstance(text_inputs, torch.Tensor) else np.asarray(text_inputs)
         if ids.ndim == 1:
             ids = ids[None]
+        if nrs > 1:
+            ids = np.repeat(ids, nrs, axis=0)
         max_gen = self.max_mel_tokens - 1 if max_generate_length is None else int(max_generate_length)
         rep = float(hf_generate_kwargs.get("repetition_penalty", 1.0) or 1.0)
         n_forced = 0

@@ -307,3 +307,22 @@ def test_indextts_from_files(tts, tmp_path):
     _, w_str = ftts.infer(mel, text, None, **kw)
     _, w_ids = ftts.infer(mel, ids, None, **kw)
     assert np.array_equal(w_str, w_ids)
+
+
+def test_num_return_sequences_sampling(tts):
+    """`inference_speech(num_return_sequences=n, do_sample=True)` (model.py:655,698-703): every input row expanded n times
+    (repeat_interleave), the copies sampled independently; greedy with n > 1 is an error as in HF."""
+    mel = torch.from_numpy(synth.prompt_mel(61, seed=7)).cuda()
+    t = torch.from_numpy(np.stack([synth.text_ids(9, 51, CFG.gpt.number_text_tokens), synth.text_ids(9, 52, CFG.gpt.number_text_tokens)]).astype(np.int32))
+    torch.manual_seed(3)
+    out = tts.gpt.inference_speech(mel, t, do_sample=True, top_k=30, top_p=0.9, temperature=1.0, num_beams=1, num_return_sequences=3,
+                                   repetition_penalty=10.0, max_generate_length=12)
+    assert out.shape[0] == 6
+    a = out.cpu().numpy()
+    assert not (np.array_equal(a[0], a[1]) and np.array_equal(a[1], a[2]))  # independent draws
+    torch.manual_seed(3)
+    one = tts.gpt.inference_speech(mel, t.repeat_interleave(3, 0), do_sample=True, top_k=30, top_p=0.9, temperature=1.0, num_beams=1,
+                                   repetition_penalty=10.0, max_generate_length=12)
+    assert torch.equal(out, one)  # = the expanded batch, row order item0 x 3, item1 x 3
+    with pytest.raises(ValueError):
+        tts.gpt.inference_speech(mel, t, do_sample=False, num_beams=1, num_return_sequences=2, max_generate_length=4)
