@@ -120,6 +120,9 @@ int itts_engine_finalize(itts_engine* e);
 
 /* G2/C1/P1  UnifiedVoice.get_conditioning (gpt/model.py:490-502): mel [1, F, idim] -> cond fp32 [latents, D] */
 int itts_conditioning(itts_engine* e, const void* mel_bfc, int F, float* cond_out, itts_stream stream);
+/* The same for a prompt that is the first F frames of a tensor padded to F_total frames (get_conditioning with
+ * cond_mel_lengths, gpt/model.py:490-502: masked conformer + perceiver; mel_bfc holds at least F frames). */
+int itts_conditioning_padded(itts_engine* e, const void* mel_bfc, int F, int F_total, float* cond_out, itts_stream stream);
 /* V6  ECAPA_TDNN.forward (BigVGAN/ECAPA_TDNN.py:545-581): mel [B, F, num_mels] -> spk fp32 [B, spk_dim] */
 int itts_ecapa(itts_engine* e, const void* mel_bfc, int B, int F, float* spk_out, itts_stream stream);
 
@@ -180,6 +183,11 @@ int itts_gpt_decode_mode(itts_engine* e);
  * processors / warpers and the draw itself, and itts_gpt_commit hands the chosen token of every row (host int32 [B]) to the
  * sampler's bookkeeping (ids, repetition bitmap, eos state, step counter, next input embedding).  One stream sync per token. */
 int itts_gpt_set_host_sampling(itts_engine* e, int on);
+
+/* Conditioning latents per batch item: with on = 1 the `cond` of the following itts_gpt_prefill calls is [B][latents, D] (one
+ * prompt per row, UnifiedVoice.inference_speech with a batch of prompts: gpt/model.py:599-602,670) instead of one [latents, D]
+ * block shared by every row (what infer.py passes). */
+int itts_gpt_set_cond_per_row(itts_engine* e, int on);
 int itts_gpt_commit(itts_engine* e, const int32_t* tokens_host, itts_stream stream);
 
 /* G1/G3/G4 step 0: prepare_gpt_inputs (model.py:591-654) + prefill + first greedy token.

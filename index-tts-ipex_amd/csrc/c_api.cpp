@@ -183,6 +183,10 @@ int itts_conditioning(itts_engine* e, const void* mel, int F, float* cond_out, i
   ENG(e);
   return e->e.conditioning(mel, F, cond_out, (hipStream_t)s);
 }
+int itts_conditioning_padded(itts_engine* e, const void* mel, int F, int F_total, float* cond_out, itts_stream s) {
+  ENG(e);
+  return e->e.conditioning(mel, F, cond_out, (hipStream_t)s, F_total);
+}
 int itts_ecapa(itts_engine* e, const void* mel, int B, int F, float* spk_out, itts_stream s) {
   ENG(e);
   return e->e.ecapa(mel, B, F, spk_out, (hipStream_t)s);
@@ -216,6 +220,11 @@ int itts_gpt_set_input_tokens(itts_engine* e, const int32_t* ids_host, int B, in
   return e->e.gpt_set_input_tokens(ids_host, B, n);
 }
 int itts_gpt_decode_mode(itts_engine* e) { return e ? e->e.ds.last_mode : -1; }
+int itts_gpt_set_cond_per_row(itts_engine* e, int on) {
+  ENG(e);
+  e->e.cond_per_row = on ? 1 : 0;
+  return OK;
+}
 int itts_gpt_set_host_sampling(itts_engine* e, int on) {
   ENG(e);
   return e->e.gpt_set_host_sampling(on);

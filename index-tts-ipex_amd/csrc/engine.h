@@ -217,7 +217,7 @@ struct Engine {
 
   // model entry points
   int finalize();
-  int conditioning(const void* mel, int F, float* cond_out, hipStream_t s);
+  int conditioning(const void* mel, int F, float* cond_out, hipStream_t s, int F_total = 0);
   int ecapa(const void* mel, int B, int F, float* spk_out, hipStream_t s);
   int gpt_prefill(const float* cond, const int32_t* text_ids, int B, int L, int max_gen, float penalty, int suppress,
                   hipStream_t s);
@@ -227,6 +227,7 @@ struct Engine {
   int gpt_set_forced(const int32_t* ids_host, int B, int n);
   int gpt_set_input_tokens(const int32_t* ids_host, int B, int n);
   int gpt_set_host_sampling(int on);
+  int cond_per_row = 0;  // itts_gpt_set_cond_per_row: the cond passed to prefill holds one [latents, D] block per batch item
   int gpt_commit(const int32_t* tokens_host, hipStream_t s);
   int forced_input = 0;  // the forced tokens are HF `input_tokens`: token k sits at mel position k + 1 (model.py:141-144)
   int gpt_set_typical(float mass);

@@ -14,7 +14,14 @@ namespace itts {
     if (!dry) ITTS_TRY(call);    \
   } while (0)
 
-int Engine::conditioning(const void* mel, int F, float* cond_out, hipStream_t s) {
+// F_total > F: the prompt is the first F frames of a tensor padded to F_total frames (get_conditioning with cond_mel_lengths,
+// model.py:490-502).  The subsampled mask keeps row i iff 2 i + 2 < F (subsampling.py:186), i.e. exactly the rows a valid
+// 3 x 3 stride-2 convolution of the first F frames has, each computed from valid frames only; masked keys (attention.py:104-117)
+// are keys the shorter sequence does not have.  One thing differs from a plain cut: the convolution module zero-fills the
+// masked ROWS BEFORE its first pointwise convolution (conformer_encoder.py:143-146), so behind the end of the prompt its depthwise
+// convolution (k = 15, pad 7) sees GLU(pw1 bias), not zeros - reproduced by running pw1 / GLU / the depthwise convolution over
+// min(7, masked rows) extra zero rows.
+int Engine::conditioning(const void* mel, int F, float* cond_out, hipStream_t s, int F_total) {
   if (!finalized || !cond.ok) {
     set_error("conditioning: conformer/perceiver weights not bound");
     return E_STATE;
@@ -24,21 +31,24 @@ int Engine::conditioning(const void* mel, int F, float* cond_out, hipStream_t s)
   const int od = c.cond_dim, idim = c.cond_idim, H = c.cond_heads, dk = od / H, D = c.model_dim;
   const int Fo = (F - 3) / 2 + 1, fo = (idim - 3) / 2 + 1, nl = c.cond_latents;
   ITTS_REQUIRE(Fo <= cond.pe_len, "conditioning: prompt longer than the positional table");
+  ITTS_REQUIRE(F_total == 0 || F_total >= F, "conditioning: padded length shorter than the prompt");
+  const int tail = F_total > F ? std::min(7, ((F_total - 3) / 2 + 1) - Fo) : 0;  // masked rows the depthwise convolution reaches
   ITTS_REQUIRE(2 * dk <= 128 && dk <= 64, "conditioning: head dim too large");
   auto body = [&]() -> int {
     void* sub = alloc((size_t)Fo * od * fo * es);
     K(conv2d_sub2(sub, mel, cond.conv_w, cond.conv_b, 1, F, idim, od, adt, s));
     void* x = alloc((size_t)Fo * od * es);
     ITTS_TRY(lin(x, adt, sub, adt, od * fo, cond.embed_out, Fo, od, s, ACT_NONE, nullptr, 0, std::sqrt((float)od)));
-    void* xn = alloc((size_t)Fo * od * es);
+    void* xn = alloc((size_t)(Fo + tail) * od * es);
+    if (tail > 0 && !dry) ITTS_HIP_CHECK(hipMemsetAsync((char*)xn + (size_t)Fo * od * es, 0, (size_t)tail * od * es, s));  // zero-filled masked rows
     void* qkv = alloc((size_t)Fo * 3 * od * es);
     void* pp = alloc((size_t)Fo * od * es);
     void* qc = alloc((size_t)Fo * 2 * od * es);
     void* kc = alloc((size_t)Fo * 2 * od * es);
     void* ctx = alloc((size_t)Fo * od * es);
-    void* g1 = alloc((size_t)Fo * 2 * od * es);
-    void* g2 = alloc((size_t)Fo * od * es);
-    void* g3 = alloc((size_t)Fo * od * es);
+    void* g1 = alloc((size_t)(Fo + tail) * 2 * od * es);
+    void* g2 = alloc((size_t)(Fo + tail) * od * es);
+    void* g3 = alloc((size_t)(Fo + tail) * od * es);
     void* f1 = alloc((size_t)Fo * c.cond_ff * es);
     for (int i = 0; i < c.cond_blocks; ++i) {
       const ConformerLayerW& L = cond.layers[i];
@@ -65,9 +75,9 @@ int Engine::conditioning(const void* mel, int F, float* cond_out, hipStream_t s)
       ITTS_TRY(lin(x, adt, ctx, adt, od, L.out, Fo, od, s, ACT_NONE, x, od));
       // --- convolution module ---
       ITTS_TRY(ln(xn, adt, x, adt, L.norm_conv, Fo, od, s));
-      ITTS_TRY(lin(g1, adt, xn, adt, od, L.pw1, Fo, 2 * od, s));
-      K(glu(g2, g1, Fo, od, adt, s));
-      K(dwconv(g3, g2, L.dw_w, L.dw_b, 1, Fo, od, 15, adt, s));
+      ITTS_TRY(lin(g1, adt, xn, adt, od, L.pw1, Fo + tail, 2 * od, s));
+      K(glu(g2, g1, Fo + tail, od, adt, s));
+      K(dwconv(g3, g2, L.dw_w, L.dw_b, 1, Fo + tail, od, 15, adt, s));
       ITTS_TRY(ln(g2, adt, g3, adt, L.conv_norm, Fo, od, s, ACT_SILU));
       ITTS_TRY(lin(x, adt, g2, adt, od, L.pw2, Fo, od, s, ACT_NONE, x, od));
       // --- feed forward ---

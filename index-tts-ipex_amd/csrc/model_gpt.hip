@@ -483,7 +483,8 @@ int Engine::gpt_prefill(const float* cond_dev, const int32_t* text_ids_in, int B
     RowDesc* r = rd.data() + (size_t)b * S0;
     int k = 0;
     for (int i = 0; i < pad; ++i) r[k++] = {0, 0, 0, 0};
-    for (int i = 0; i < nl; ++i) r[k++] = {1, i, 0, 0};
+    // conditioning latents: one set for every row (infer.py), or one per batch item (model.py:599-602 takes [b, 32, D])
+    for (int i = 0; i < nl; ++i) r[k++] = {1, (cond_per_row ? (b / nbeam) * nl : 0) + i, 0, 0};
     r[k++] = {2, c.start_text_token, 0, 0};
     for (int i = 0; i < n; ++i) r[k++] = {2, ids[i], i + 1, 0};
     r[k++] = {2, c.stop_text_token, n + 1, 0};

@@ -37,13 +37,23 @@ class UnifiedVoice:
 
     @torch.no_grad()
     def get_conditioning(self, speech_conditioning_input, cond_mel_lengths=None):
-        """[1, n_mels, F] -> [1, 32, D]; cached per prompt tensor object (the reference recomputes it twice per sentence,
-        model.py:540,670).  Only full-length single prompts are supported (what infer.py passes)."""
+        """[b, n_mels, F] (+ lengths [b]) -> [b, 32, D] (model.py:490-502); the single full-length prompt infer.py passes is
+        cached per prompt tensor object (the reference recomputes it twice per sentence, model.py:540,670).
+        A padded prompt of length n is the prompt cut to n frames (the subsampled mask keeps exactly the rows a valid 3 x 3
+        stride-2 convolution of n frames has, masked keys are keys the shorter sequence does not have) except that the
+        convolution module's depthwise convolution sees GLU(pointwise bias) behind the end instead of zeros - handled in
+        the engine (itts_conditioning_padded)."""
         x = speech_conditioning_input
         if x.ndim == 2:
             x = x.unsqueeze(0)
-        if cond_mel_lengths is not None and int(torch.as_tensor(cond_mel_lengths).reshape(-1)[0]) != x.shape[-1]:
-            raise NotImplementedError("partial-length conditioning prompts")
+        lens = None if cond_mel_lengths is None else [int(v) for v in torch.as_tensor(cond_mel_lengths).reshape(-1).tolist()]
+        if x.shape[0] > 1 or (lens is not None and lens[0] != x.shape[-1]):
+            if lens is None:
+                lens = [x.shape[-1]] * x.shape[0]
+            if len(lens) == 1 and x.shape[0] > 1:
+                lens = lens * x.shape[0]
+            with self._eng.lock:
+                return torch.cat([self._eng.conditioning(x[i:i + 1], lens[i]) for i in range(x.shape[0])], 0)
         # cached per prompt TENSOR OBJECT: the key holds a reference to it, so its storage cannot be freed and handed to a
         # different same-shape prompt while the entry is alive (an address-only key would alias two speakers)
         with self._eng.lock:
@@ -84,6 +94,10 @@ class UnifiedVoice:
             ids = ids[None]
         if nrs > 1:
             ids = np.repeat(ids, nrs, axis=0)
+            if cond.shape[0] > 1:
+                cond = cond.repeat_interleave(nrs, 0)
+        if cond.shape[0] not in (1, ids.shape[0]):
+            raise ValueError(f"{cond.shape[0]} conditioning prompts for {ids.shape[0]} text rows")
         max_gen = self.max_mel_tokens - 1 if max_generate_length is None else int(max_generate_length)
         rep = float(hf_generate_kwargs.get("repetition_penalty", 1.0) or 1.0)
         n_forced = 0

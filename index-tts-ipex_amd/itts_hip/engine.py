@@ -159,14 +159,18 @@ class Engine:
         return x.to(device=self.device, dtype=self.tdt).contiguous()
 
     # ---- stages ----
-    def conditioning(self, mel_bcf: torch.Tensor) -> torch.Tensor:
-        """mel [1, n_mels, F] (the reference's layout) -> cond fp32 [1, latents, D]."""
+    def conditioning(self, mel_bcf: torch.Tensor, length: Optional[int] = None) -> torch.Tensor:
+        """mel [1, n_mels, F] (the reference's layout) -> cond fp32 [1, latents, D]; length < F: the prompt is the first
+        `length` frames of a padded tensor (get_conditioning with cond_mel_lengths)."""
         assert mel_bcf.ndim == 3 and mel_bcf.shape[0] == 1
         mel = self.to_act(mel_bcf.transpose(1, 2))
         F = mel.shape[1]
         out = torch.empty(1, self.ccfg.cond_latents, self.ccfg.model_dim, dtype=torch.float32, device=self.device)
         self._enter()
-        L.check(self.lib.itts_conditioning(self.h, mel.data_ptr(), F, out.data_ptr(), self._s()), "conditioning")
+        if length is not None and int(length) < F:
+            L.check(self.lib.itts_conditioning_padded(self.h, mel.data_ptr(), int(length), F, out.data_ptr(), self._s()), "conditioning")
+        else:
+            L.check(self.lib.itts_conditioning(self.h, mel.data_ptr(), F, out.data_ptr(), self._s()), "conditioning")
         self._exit()
         mel.record_stream(self.stream)
         return out
@@ -188,6 +192,9 @@ class Engine:
         assert ids.ndim == 2
         B, Lt = ids.shape
         cond = cond.to(device=self.device, dtype=torch.float32).contiguous().view(-1, self.ccfg.model_dim)
+        per_row = cond.shape[0] == B * self.ccfg.cond_latents and B > 1  # one prompt per row (a batch of prompts)
+        assert per_row or cond.shape[0] == self.ccfg.cond_latents, cond.shape
+        L.check(self.lib.itts_gpt_set_cond_per_row(self.h, int(per_row)), "gpt_set_cond_per_row")
         self._enter()
         L.check(self.lib.itts_gpt_prefill(self.h, cond.data_ptr(), ids.ctypes.data_as(C.c_void_p), B, Lt, max_gen,
                                           float(repetition_penalty), int(suppress_stop), self._s()), "gpt_prefill")

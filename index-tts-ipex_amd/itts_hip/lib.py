@@ -72,6 +72,7 @@ _PROTOS = {
     "itts_engine_bind_tensor": (i32, [vp, C.c_char_p, vp, i32, i32, C.POINTER(i64)]),
     "itts_engine_finalize": (i32, [vp]),
     "itts_conditioning": (i32, [vp, vp, i32, vp, vp]),
+    "itts_conditioning_padded": (i32, [vp, vp, i32, i32, vp, vp]),
     "itts_ecapa": (i32, [vp, vp, i32, i32, vp, vp]),
     "itts_gpt_prefill": (i32, [vp, vp, vp, i32, i32, i32, f32, i32, vp]),
     "itts_gpt_set_sampling": (i32, [vp, i32, i32, f32, f32, vp, i64]),
@@ -79,6 +80,7 @@ _PROTOS = {
     "itts_gpt_set_input_tokens": (i32, [vp, vp, i32, i32]),
     "itts_gpt_decode_mode": (i32, [vp]),
     "itts_gpt_set_host_sampling": (i32, [vp, i32]),
+    "itts_gpt_set_cond_per_row": (i32, [vp, i32]),
     "itts_gpt_commit": (i32, [vp, vp, vp]),
     "itts_gpt_set_typical": (i32, [vp, f32]),
     "itts_gpt_set_beams": (i32, [vp, i32, i32, i32, f32, f32, f32, vp, i64]),

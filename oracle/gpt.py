@@ -66,36 +66,44 @@ def rel_pos_mha(x, pos_emb, w: W, p: str, heads: int):
     return linear(o, w, p + "linear_out")
 
 
-def conformer_conv_module(x, w: W, p: str):
-    """conformer_encoder.py:112-167 ConvolutionModule.forward (non-causal, LayerNorm variant, SiLU)."""
+def conformer_conv_module(x, w: W, p: str, tail: int = 0):
+    """conformer_encoder.py:112-167 ConvolutionModule.forward (non-causal, LayerNorm variant, SiLU).  tail > 0: the sequence is
+    the valid part of a padded one; the module zero-fills the masked rows BEFORE its first pointwise convolution (:143-146), so
+    its depthwise convolution sees GLU(pw1 bias) behind the end - `tail` such rows are appended and dropped again."""
+    T = x.shape[1]
+    if tail > 0:
+        x = F.pad(x, (0, 0, 0, tail))
     x = x.transpose(1, 2)
     x = F.conv1d(x, w[p + "pointwise_conv1.weight"], w[p + "pointwise_conv1.bias"])
     x = F.glu(x, dim=1)
     c = x.shape[1]
     k = w[p + "depthwise_conv.weight"].shape[-1]
-    x = F.conv1d(x, w[p + "depthwise_conv.weight"], w[p + "depthwise_conv.bias"], padding=(k - 1) // 2, groups=c)
+    x = F.conv1d(x, w[p + "depthwise_conv.weight"], w[p + "depthwise_conv.bias"], padding=(k - 1) // 2, groups=c)[:, :, :T]
     x = F.silu(layer_norm(x.transpose(1, 2), w, p + "norm")).transpose(1, 2)
     x = F.conv1d(x, w[p + "pointwise_conv2.weight"], w[p + "pointwise_conv2.bias"])
     return x.transpose(1, 2)
 
 
-def conformer_layer(x, pos_emb, w: W, p: str, heads: int):
+def conformer_layer(x, pos_emb, w: W, p: str, heads: int, tail: int = 0):
     """conformer_encoder.py:232-313 ConformerEncoderLayer.forward (normalize_before, no macaron, ff_scale 1)."""
     x = x + rel_pos_mha(layer_norm(x, w, p + "norm_mha"), pos_emb, w, p + "self_attn.", heads)
-    x = x + conformer_conv_module(layer_norm(x, w, p + "norm_conv"), w, p + "conv_module.")
+    x = x + conformer_conv_module(layer_norm(x, w, p + "norm_conv"), w, p + "conv_module.", tail)
     y = layer_norm(x, w, p + "norm_ff")
     y = linear(F.silu(linear(y, w, p + "feed_forward.w_1")), w, p + "feed_forward.w_2")  # :20-53
     x = x + y
     return layer_norm(x, w, p + "norm_final")
 
 
-def conformer_encoder(mel_btf, w: W, cfg_gpt) -> torch.Tensor:
-    """conformer_encoder.py:400-436 BaseEncoder.forward; input [b, F, 100] -> [b, F', od] (full-length mask)."""
+def conformer_encoder(mel_btf, w: W, cfg_gpt, total_frames: int = 0) -> torch.Tensor:
+    """conformer_encoder.py:400-436 BaseEncoder.forward; input [b, F, 100] -> [b, F', od].  total_frames > F: the input is the
+    valid part of a prompt padded to total_frames (xs_lens = F): the subsampled mask (subsampling.py:186) keeps exactly the F'
+    rows computed here, masked keys are absent keys; only the convolution module sees the masked rows (conformer_conv_module)."""
     cm = cfg_gpt["condition_module"]
     p = "conditioning_encoder."
     x, pos = conv2d_subsampling2(mel_btf, w, p + "embed.")
+    tail = min(7, ((total_frames - 3) // 2 + 1) - x.shape[1]) if total_frames > mel_btf.shape[1] else 0
     for i in range(cm["num_blocks"]):
-        x = conformer_layer(x, pos, w, f"{p}encoders.{i}.", cm["attention_heads"])
+        x = conformer_layer(x, pos, w, f"{p}encoders.{i}.", cm["attention_heads"], tail)
     return layer_norm(x, w, p + "after_norm")
 
 
@@ -133,8 +141,12 @@ def perceiver(ctx, w: W, cfg_gpt) -> torch.Tensor:
     return F.normalize(lat, dim=-1) * (d ** 0.5) * w[p + "norm.gamma"]
 
 
-def get_conditioning(mel_bcf, w: W, cfg_gpt) -> torch.Tensor:
-    """model.py:490-502 get_conditioning ('conformer_perceiver'): [b,100,F] -> [b,32,D]."""
+def get_conditioning(mel_bcf, w: W, cfg_gpt, length: Optional[int] = None) -> torch.Tensor:
+    """model.py:490-502 get_conditioning ('conformer_perceiver'): [b,100,F] -> [b,32,D]; length < F = cond_mel_lengths of a
+    padded prompt (masked conformer + perceiver)."""
+    F_ = mel_bcf.shape[-1]
+    if length is not None and int(length) < F_:
+        return perceiver(conformer_encoder(mel_bcf[..., : int(length)].transpose(1, 2), w, cfg_gpt, total_frames=F_), w, cfg_gpt)
     return perceiver(conformer_encoder(mel_bcf.transpose(1, 2), w, cfg_gpt), w, cfg_gpt)
 
 

@@ -87,13 +87,15 @@ def build_ref_dvae(cfg, seed):
     return m
 
 
-def ref_greedy(gpt, cond_mel, text, max_gen, rep=10.0, n_trace=None, suppress_eos=False, trace_steps=None, input_tokens=None):
+def ref_greedy(gpt, cond_mel, text, max_gen, rep=10.0, n_trace=None, suppress_eos=False, trace_steps=None, input_tokens=None,
+               lens=None):
     """Hand-rolled HF-4.36.2-style greedy_search over the reference's own GPT2InferenceModel.forward
     (the installed transformers-5.x `generate` skips the prefill, so it is not used)."""
     from transformers import RepetitionPenaltyLogitsProcessor
 
     stop = gpt.stop_mel_token
-    lens = torch.tensor([cond_mel.shape[-1]])
+    if lens is None:
+        lens = torch.tensor([cond_mel.shape[-1]])
     conds = gpt.get_conditioning(cond_mel, lens)
     ids, emb, mask = gpt.prepare_gpt_inputs(conds, text)
     gpt.inference_model.store_mel_emb(emb)
@@ -549,6 +551,25 @@ def input_token_fixtures():
     save("micro_input_tokens_b2", text=t2, input_tokens=given, codes=codes2, logits=logits2)
 
 
+@torch.no_grad()
+def cond_batch_fixtures():
+    """A batch of prompts of different lengths (model.py:490-502 with cond_mel_lengths, :599-602 per-row conditioning): two
+    prompts padded to 61 frames, lengths 61 and 45, the padding filled with noise (it must not matter); conditioning latents
+    and the greedy ids of two sentences, each with its own prompt - all through the reference's own modules."""
+    cfg = icfg.micro()
+    g = cfg.gpt
+    gpt = build_ref_gpt(cfg, 1234)
+    m0 = torch.from_numpy(synth.prompt_mel(61, seed=7))
+    m1 = torch.from_numpy(synth.prompt_mel(61, seed=8)).clone()
+    m1[:, :, 45:] = rnd("cond_batch.pad", (1, 100, 16), std=3.0)
+    mel = torch.cat([m0, m1], 0)
+    lens = torch.tensor([61, 45])
+    cond = gpt.get_conditioning(mel, lens)
+    text = torch.stack([torch.from_numpy(synth.text_ids(11, 71 + i, g.number_text_tokens)).int() for i in range(2)])
+    codes, logits, *_ = ref_greedy(gpt, mel, text, max_gen=16, n_trace=2, lens=lens)
+    save("micro_cond_batch", mel=mel, lens=lens, cond=cond, text=text, codes=codes, logits=logits)
+
+
 def front_fixtures():
     """Known answers of the reference's text front end (indextts/utils/front.py, utils/common.py): sentence splitting on
     token lists, CJK pre-tokenisation, and TextNormalizer.normalize with the third-party written-form normalisers replaced
@@ -613,6 +634,7 @@ if __name__ == "__main__":
     ap.add_argument("--skip-micro", action="store_true")
     ap.add_argument("--input-tokens", action="store_true")
     ap.add_argument("--smooth", action="store_true")
+    ap.add_argument("--cond-batch", action="store_true")
     a = ap.parse_args()
     ref_import.install()
     torch.manual_seed(0)
@@ -622,6 +644,8 @@ if __name__ == "__main__":
         input_token_fixtures()
     if a.smooth:
         smooth_fixtures()
+    if a.cond_batch:
+        cond_batch_fixtures()
     if a.full:
         full_fixtures()
     if a.front:

@@ -326,3 +326,18 @@ def test_num_return_sequences_sampling(tts):
     assert torch.equal(out, one)  # = the expanded batch, row order item0 x 3, item1 x 3
     with pytest.raises(ValueError):
         tts.gpt.inference_speech(mel, t, do_sample=False, num_beams=1, num_return_sequences=2, max_generate_length=4)
+
+
+def test_batched_prompts_with_lengths_match_reference(tts, gold):
+    """A batch of prompts of different lengths (get_conditioning with cond_mel_lengths, model.py:490-502; one set of latents
+    per row, model.py:599-602): latents and greedy ids against the reference's own modules (fixture micro_cond_batch; the
+    padding of the shorter prompt is noise and must not matter)."""
+    g = gold("micro_cond_batch")
+    mel = torch.from_numpy(g["mel"]).cuda()
+    lens = torch.from_numpy(g["lens"])
+    cond = tts.gpt.get_conditioning(mel, lens)
+    assert tuple(cond.shape) == tuple(g["cond"].shape)
+    assert float((cond.cpu() - torch.from_numpy(g["cond"])).abs().max()) < 1e-4 * float(np.abs(g["cond"]).max())
+    out = tts.gpt.inference_speech(mel, torch.from_numpy(g["text"]), cond_mel_lengths=lens, do_sample=False, num_beams=1,
+                                   repetition_penalty=10.0, max_generate_length=16)
+    assert np.array_equal(out.cpu().numpy(), g["codes"])

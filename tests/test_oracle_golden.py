@@ -89,6 +89,23 @@ def test_input_tokens_continuation(gold, wg, name):
     assert np.abs(plain["logits"][:, 0].numpy() - g["logits"][:, 0]).max() > 1e-2
 
 
+def test_padded_prompt_conditioning(gold, wg):
+    """get_conditioning with cond_mel_lengths (model.py:490-502): the reference's masked conformer / perceiver on a prompt
+    padded from 45 to 61 frames (padding = noise) gives the latents of the prompt cut to 45 frames with the convolution
+    module's masked rows accounted for (GLU(pw1 bias) behind the end of the sequence) - what the drop-in's
+    `get_conditioning(mel, lengths)` computes - and per-row prompts drive prepare_gpt_inputs (model.py:599-602)."""
+    g = gold("micro_cond_batch")
+    mel, lens = torch.from_numpy(g["mel"]), g["lens"]
+    conds = torch.cat([ogpt.get_conditioning(mel[i:i + 1], wg, CFG.gpt, length=int(lens[i])) for i in range(2)], 0)
+    close(conds, g["cond"], rtol=3e-4, atol=3e-5)
+    cut = ogpt.get_conditioning(mel[1:2, :, : int(lens[1])], wg, CFG.gpt)  # a plain cut is NOT the same: the conv module's masked rows
+    assert float((cut - torch.from_numpy(g["cond"][1:2])).abs().max()) > 1e-3
+    tr = {}
+    codes = ogpt.greedy_generate(conds, torch.from_numpy(g["text"]), wg, CFG.gpt, 16, trace=tr)
+    assert np.array_equal(codes.numpy(), g["codes"])
+    close(tr["logits"][:, :2], g["logits"], rtol=3e-4, atol=3e-4)
+
+
 def test_sensitivity_selfcheck(gold):
     """changing ONE text id must move step-0 logits far beyond tolerance and flip an id."""
     a, b = gold("micro_decode_b1"), gold("micro_decode_b1_alt")
