@@ -423,7 +423,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_bf16_kernel(GemvArgs g) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             float v = (xv[b][j][e] - mean) * rstd;
-            if (PRO == 2 && pass == 0) v = v * gm[j][e] + bt[j][e];
+            if (PRO == 2 && pass == 0) v = ln_affine_rn(v, gm[j][e], bt[j][e]);  // pinned: the persistent engine's head repeats it
             xv[b][j][e] = v;
           }
       }

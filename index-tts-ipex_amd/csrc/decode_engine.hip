@@ -280,10 +280,9 @@ struct LnRow {
   bool xok[2];
 };
 template <int K>
-__device__ __forceinline__ void ln_row_stats(const float* __restrict__ x, float* __restrict__ red, int t, LnRow<K>& r) {
+__device__ __forceinline__ void ln_row_load(const float* __restrict__ x, int t, LnRow<K>& r) {
   constexpr int NTHR = 256;
   static_assert(K > NTHR * 4 && K <= NTHR * 8, "two 4-element chunks per thread");
-  const int lane = t & 63, wave = t >> 6;
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int i = (t + j * NTHR) * 4;
@@ -293,12 +292,17 @@ __device__ __forceinline__ void ln_row_stats(const float* __restrict__ x, float*
     for (int e = 0; e < 4; ++e) r.xv[j][e] = v[e];
   }
   r.pivot = x[0];
+}
+// shifted moments (shift pv) of this thread's elements -> per-wave sums in red [4][2]; a workgroup barrier follows
+template <int K>
+__device__ __forceinline__ void ln_row_moments(const LnRow<K>& r, float pv, float* __restrict__ red, int t) {
+  const int lane = t & 63, wave = t >> 6;
   float s = 0.f, q = 0.f;
 #pragma unroll
   for (int j = 0; j < 2; ++j)
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const float d = r.xok[j] ? r.xv[j][e] - r.pivot : 0.f;
+      const float d = r.xok[j] ? r.xv[j][e] - pv : 0.f;
       s += d;
       q = fmaf(d, d, q);
     }
@@ -310,7 +314,7 @@ __device__ __forceinline__ void ln_row_stats(const float* __restrict__ x, float*
   }
 }
 template <int K>
-__device__ __forceinline__ void ln_row_apply(LnRow<K>& r, const float* __restrict__ red, uint32_t* __restrict__ sx, int t, float eps) {
+__device__ __forceinline__ void ln_row_norm(LnRow<K>& r, float pv, const float* __restrict__ red, float eps) {
   const float invK = 1.f / (float)K;
   float S = 0.f, Q = 0.f;
 #pragma unroll
@@ -319,21 +323,25 @@ __device__ __forceinline__ void ln_row_apply(LnRow<K>& r, const float* __restric
     Q += red[ww * 2 + 1];
   }
   const float md = __fmul_rn(S, invK);
-  const float mean = __fadd_rn(r.pivot, md);
+  const float mean = __fadd_rn(pv, md);
   const float rstd = __builtin_amdgcn_rsqf(__fadd_rn(fmaxf(ln_var_rn(Q, invK, md), 0.f), eps));
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
+  for (int j = 0; j < 2; ++j)
 #pragma unroll
     for (int e = 0; e < 4; ++e) r.xv[j][e] = (r.xv[j][e] - mean) * rstd;
+}
+template <int K>
+__device__ __forceinline__ void ln_row_store(const LnRow<K>& r, uint32_t* __restrict__ sx, int t) {
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
     if (r.xok[j]) {
       uint2 p;
       p.x = pack_bf16(r.xv[j][0], r.xv[j][1]);
       p.y = pack_bf16(r.xv[j][2], r.xv[j][3]);
       *reinterpret_cast<uint2*>(sx + (t + j * 256) * 2) = p;
     }
-  }
 }
-// all 1024 threads call this (two workgroup barriers inside); red: [NB][4][2] floats
+// all 1024 threads call this (two workgroup barriers inside); red: [2 passes][NB][4][2] floats
 template <int NB, int K>
 __device__ __forceinline__ void ln_to_sxb(const float* __restrict__ xf, uint32_t* __restrict__ sxb, float* __restrict__ red, int t,
                                           float eps) {
@@ -341,9 +349,49 @@ __device__ __forceinline__ void ln_to_sxb(const float* __restrict__ xf, uint32_t
   const int grp = t < 256 ? 0 : (NB == 2 && t >= 768 ? 1 : -1);  // which row this thread works on (-1: none)
   const int tr = t & 255;
   LnRow<K> r;
-  if (grp >= 0) ln_row_stats<K>(xf + grp * K, red + grp * 8, tr, r);
+  if (grp >= 0) {
+    ln_row_load<K>(xf + grp * K, tr, r);
+    ln_row_moments<K>(r, r.pivot, red + grp * 8, tr);
+  }
   __syncthreads();
-  if (grp >= 0) ln_row_apply<K>(r, red + grp * 8, sxb + grp * (K / 2), tr, eps);
+  if (grp >= 0) {
+    ln_row_norm<K>(r, r.pivot, red + grp * 8, eps);
+    ln_row_store<K>(r, sxb + grp * (K / 2), tr);
+  }
+  __syncthreads();
+}
+// ln_f (affine) then final_norm (its affine is folded into mel_head by the packer): gemv_bf16_kernel's prologue 2
+template <int NB, int K>
+__device__ __forceinline__ void ln2_to_sxb(const float* __restrict__ xf, uint32_t* __restrict__ sxb, float* __restrict__ red, int t,
+                                           float eps, const float* __restrict__ gamma, const float* __restrict__ beta) {
+  const int grp = t < 256 ? 0 : (NB == 2 && t >= 768 ? 1 : -1);
+  const int tr = t & 255;
+  LnRow<K> r;
+  f32x4 gm[2], bt[2];
+  if (grp >= 0) {
+    ln_row_load<K>(xf + grp * K, tr, r);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int ic = r.xok[j] ? (tr + j * 256) * 4 : K - 4;
+      gm[j] = *reinterpret_cast<const f32x4*>(gamma + ic);
+      bt[j] = *reinterpret_cast<const f32x4*>(beta + ic);
+    }
+    ln_row_moments<K>(r, r.pivot, red + grp * 8, tr);
+  }
+  __syncthreads();
+  if (grp >= 0) {
+    ln_row_norm<K>(r, r.pivot, red + grp * 8, eps);
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) r.xv[j][e] = ln_affine_rn(r.xv[j][e], gm[j][e], bt[j][e]);
+    ln_row_moments<K>(r, 0.f, red + 16 + grp * 8, tr);
+  }
+  __syncthreads();
+  if (grp >= 0) {
+    ln_row_norm<K>(r, 0.f, red + 16 + grp * 8, eps);
+    ln_row_store<K>(r, sxb + grp * (K / 2), tr);
+  }
   __syncthreads();
 }
 
@@ -805,7 +853,7 @@ __global__ __launch_bounds__(1024) void decode_engine_kernel(EngArgs a) {
         const float hn = hown[ll * 8 + cw] + (mine + reinterpret_cast<const float*>(W1)[cw]);
         hown[ll * 8 + cw] = hn;
         if (a.dbg && l == a.dbg_layer) a.dbg[(size_t)NB * 8 * D + (size_t)ll * D + cu * HO + cw] = hn;
-        if (l + 1 < a.NL)
+        if (l + 1 < a.NL || a.head_w)
           st_gran(G + OH2 + (size_t)ll * D + cu * HO + cw, rt.tag, __float_as_uint(hn));
         else
           a.h[(size_t)ll * D + cu * HO + cw] = hn;
@@ -813,6 +861,79 @@ __global__ __launch_bounds__(1024) void decode_engine_kernel(EngArgs a) {
     }
     phase_done(ll);
     ENG_STAMP(11)
+  }
+  // ================= head: ln_f -> final_norm -> mel_head (lm_head, model.py:48,180) =================
+  // The workgroup's 32 (33) rows of mel_head go straight to REGISTERS of the compute waves (three rows each, requested before
+  // the gather: compute waves never poll, so the loads fly during the hop); logits leave as plain stores for the sampler launch.
+  if (a.head_w) {
+    int tl = t;
+    asm volatile("" : "+v"(tl));
+    const int ll = tl & 63;
+    const int rows_per = a.V / NCU, extra = a.V % NCU;
+    u32x4 wh[3][3];
+    float bh[3];
+    int hn_[3];
+    if (cwv) {
+      const int klast = 2 * 512 + ll * 8;
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        const int idx = cw * 3 + r;
+        hn_[r] = idx < rows_per ? cu * rows_per + idx : (idx == rows_per && cu < extra ? NCU * rows_per + cu : -1);
+        const int n = hn_[r] < 0 ? 0 : hn_[r];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          const int k = c == 2 ? (klast < D ? klast : D - 8) : c * 512 + ll * 8;
+          wh[r][c] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(a.head_w + (size_t)n * D + k));
+        }
+        bh[r] = a.head_b[n];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (gw) {
+      wait_own(own_lds, NCW * phase, rt);
+      sweep2<(NB * D / 2 + 255) / 256, false>(a.gran + (size_t)(a.NL - 1) * LSTRIDE + OH2, NB * D / 2, tl, rt,
+                                              [&](int i, uint32_t v) { xf[i] = __uint_as_float(v); }, rt.first_delay);
+    }
+    __syncthreads();
+    ln2_to_sxb<NB, D>(xf, xn, red, tl, a.eps, a.lnf_g, a.lnf_b);
+    if (cwv) {
+      const int klast = 2 * 512 + ll * 8;
+      const bool kok = klast < D;
+      float acc[3][NB];
+#pragma unroll
+      for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int b = 0; b < NB; ++b) acc[r][b] = 0.f;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const int k = c == 2 ? (kok ? klast : D - 8) : c * 512 + ll * 8;
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+          u32x4 xq = *reinterpret_cast<const u32x4*>(xn + (b * D + k) / 2);
+          if (c == 2)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) xq[e] = kok ? xq[e] : 0u;
+#pragma unroll
+          for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[r][b] = dot2(wh[r][c][e], xq[e], acc[r][b]);
+        }
+      }
+      float mine = 0.f;
+#pragma unroll
+      for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+          const float x = wave_sum_rl(acc[r][b]);
+          mine = ll == r * NB + b ? x : mine;
+        }
+      if (ll < 3 * NB) {
+        const int r = ll / NB, b = ll % NB;
+        const int n = r == 0 ? hn_[0] : (r == 1 ? hn_[1] : hn_[2]);
+        const float bias = r == 0 ? bh[0] : (r == 1 ? bh[1] : bh[2]);
+        if (n >= 0) a.logits[(size_t)b * a.V + n] = mine + bias;
+      }
+    }
   }
   // advance the step counter (never 0): every workgroup read it before its first publish, and this workgroup got here
   // only after gathering from all of them

@@ -11,6 +11,9 @@ namespace itts {
 // E[d^2] - E[d]^2 with Q = sum d^2, md = mean d
 __device__ __forceinline__ float ln_var_rn(float Q, float invK, float md) { return fmaf(-md, md, __fmul_rn(Q, invK)); }
 
+// LayerNorm affine (ln_f in front of final_norm, head GEMV prologue 2)
+__device__ __forceinline__ float ln_affine_rn(float v, float g, float b) { return fmaf(v, g, b); }
+
 // HF NewGELU: 0.5 x (1 + tanh(sqrt(2 / pi) (x + 0.044715 x^3)))
 __device__ __forceinline__ float gelu_new_rn(float x) {
   const float x3 = __fmul_rn(__fmul_rn(x, x), x);

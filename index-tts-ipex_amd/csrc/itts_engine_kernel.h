@@ -30,6 +30,13 @@ struct EngArgs {
   unsigned timeout_ticks = 2000000;   // wall-clock bound of every wait, 100 MHz ticks (20 ms)
   int first_delay = 22, pass_sleep = 1; // gather pacing (s_sleep units of 64 clocks): before the first pass / between passes
   int ctx_delay = 0, act_delay = 20;  // the same for the context edge behind its sentinel poll / the gelu(fc) edge
+  // head inside the launch (null head_w: the last block writes h and the head GEMV is its own launch)
+  const bf16_t* head_w = nullptr;     // mel_head [V][D] (final_norm's affine folded in)
+  const float* head_b = nullptr;      // [V]
+  const float* lnf_g = nullptr;       // ln_f gamma / beta [D]
+  const float* lnf_b = nullptr;
+  float* logits = nullptr;            // [B][V]
+  int V = 0;
   int thin_fc = 0;                    // the loader keeps at most 12 c_fc requests in flight (they run beside a gather)
   float* dbg = nullptr;               // debugging aid (ITTS_TAP_LAYER): qkv [B][3D], h1 [B][D], act [B][4D], h2 [B][D] of block dbg_layer
   int dbg_layer = -1;

@@ -524,9 +524,10 @@ int Engine::gpt_prefill(const float* cond_dev, const int32_t* text_ids_in, int B
 }
 
 // ln_f -> final_norm -> mel_head -> repetition penalty / argmax / bookkeeping (lm_head, model.py:48,180)
-int Engine::head_and_sample(hipStream_t s) {
+int Engine::head_and_sample(hipStream_t s, bool have_logits) {
   const itts_config& c = cfg;
   const int D = c.model_dim, V = c.number_mel_codes, B = ds.B;
+  if (have_logits) return sample_from_logits(s);  // the persistent engine ran ln_f / final_norm / mel_head itself
   GemvArgs g;
   g.W = gpt.head.w;
   g.Y = ds.logits;
@@ -566,6 +567,13 @@ int Engine::head_and_sample(hipStream_t s) {
     g.prologue = 0;
     ITTS_TRY(gemv(g, gpt.head.dt, s));
   }
+  return sample_from_logits(s);
+}
+
+// repetition penalty / argmax or the sampling / beam modes / bookkeeping on ds.logits [B][V]
+int Engine::sample_from_logits(hipStream_t s) {
+  const itts_config& c = cfg;
+  const int D = c.model_dim, V = c.number_mel_codes, B = ds.B;
   ITTS_TRY(tap("logits0", ds.logits, F32, (int64_t)B * V, s));
   if (ds.host_sample) return OK;  // the caller reads the logits, picks the tokens and commits them (gpt_commit)
   const float* lg_in = ds.logits;
@@ -723,6 +731,18 @@ int Engine::decode_step_launch(hipStream_t s) {
     static const bool e_stamps = getenv("ITTS_ENGINE_STAMPS") != nullptr;
     if (debug && e_stamps && !dry) ea.stamp = (unsigned*)ds.logits + 0;  // [16][V] fp32 scratch >= 256 * 24 * 16 words; the head overwrites it later
     ds.last_mode = eng_first > 0;
+    // the head (ln_f -> final_norm -> mel_head) inside the same launch when the engine runs every block (ITTS_ENGINE_HEAD=0: own launch)
+    static const bool e_head = !(getenv("ITTS_ENGINE_HEAD") && atoi(getenv("ITTS_ENGINE_HEAD")) == 0);
+    const bool fold_head = e_head && eng_first == c.layers && gpt.head.dt == BF16 && !gpt.head.w8 && gpt.head.b && gpt.head.Cin == ENG_D &&
+                           gpt.ln_f.g && gpt.ln_f.b && (c.number_mel_codes + ENG_NCU - 1) / ENG_NCU <= 33;
+    if (fold_head) {
+      ea.head_w = (const bf16_t*)gpt.head.w;
+      ea.head_b = gpt.head.b;
+      ea.lnf_g = gpt.ln_f.g;
+      ea.lnf_b = gpt.ln_f.b;
+      ea.logits = ds.logits;
+      ea.V = c.number_mel_codes;
+    }
     if (eng_first > 0) ITTS_TRY(decode_engine_layers(ea, s));
     if (ea.stamp) ITTS_TRY(tap("eng_stamps", ea.stamp, F32, (int64_t)ENG_NCU * eng_first * 16, s));
     if (ea.dbg) {
@@ -731,7 +751,7 @@ int Engine::decode_step_launch(hipStream_t s) {
       ITTS_TRY(tap("eng_act", ea.dbg + (size_t)B * 4 * D, F32, (int64_t)B * 4 * D, s));
       ITTS_TRY(tap("eng_h2", ea.dbg + (size_t)B * 8 * D, F32, (int64_t)B * D, s));
     }
-    if (eng_first == c.layers) return head_and_sample(s);
+    if (eng_first == c.layers) return head_and_sample(s, fold_head);
   }
   // 5-16 rows: the step is launch-bound, so the two LayerNorm launches of a layer fold into the projections they feed
   // (skinny_mfma_kernel<LNP>) and the residual projections run as half tiles without a K split (<HALF>): 5 launches a
