@@ -161,32 +161,35 @@ __device__ __forceinline__ void sweep2(const u64* __restrict__ g, int npairs, in
       __builtin_amdgcn_s_sleep(2);
     }
   }
-  unsigned need = 0;
-#pragma unroll
-  for (int j = 0; j < PER; ++j)
-    if (gt + 256 * j < npairs) need |= 1u << j;
-  if (rt.dead) need = 0;
-  unsigned spins = 0;
-  // a publish needs ~0.65 us to become visible chip-wide: a pass started earlier fails AND slows the stores it waits for
+  constexpr int CH = PER <= 10 ? PER : 8;  // loads in flight per pass (registers: 4 each)
   for (int z = 0; z < delay; ++z) __builtin_amdgcn_s_sleep(1);
-  while (need) {
-    u32x4 x[PER];
 #pragma unroll
-    for (int j = 0; j < PER; ++j)
-      if ((need >> j) & 1u) x[j] = ld_gran2(g + 2 * (gt + 256 * j));  // only what has not arrived yet
-    ld_wait();
+  for (int j0 = 0; j0 < PER; j0 += CH) {
+    unsigned need = 0;
 #pragma unroll
-    for (int j = 0; j < PER; ++j) {
-      asm volatile("" : "+v"(x[j]));
-      if (((need >> j) & 1u) && x[j][1] == rt.tag && x[j][3] == rt.tag) {
-        sink(2 * (gt + 256 * j), x[j][0]);
-        sink(2 * (gt + 256 * j) + 1, x[j][2]);
-        need &= ~(1u << j);
+    for (int j = 0; j < CH; ++j)
+      if (j0 + j < PER && gt + 256 * (j0 + j) < npairs) need |= 1u << j;
+    if (rt.dead) need = 0;
+    unsigned spins = 0;
+    while (need) {
+      u32x4 x[CH];
+#pragma unroll
+      for (int j = 0; j < CH; ++j)
+        if ((need >> j) & 1u) x[j] = ld_gran2(g + 2 * (gt + 256 * (j0 + j)));  // only what has not arrived yet
+      ld_wait();
+#pragma unroll
+      for (int j = 0; j < CH; ++j) {
+        asm volatile("" : "+v"(x[j]));
+        if (((need >> j) & 1u) && x[j][1] == rt.tag && x[j][3] == rt.tag) {
+          sink(2 * (gt + 256 * (j0 + j)), x[j][0]);
+          sink(2 * (gt + 256 * (j0 + j)) + 1, x[j][2]);
+          need &= ~(1u << j);
+        }
       }
+      if (!need) break;
+      if (spin_fail(rt, spins)) break;
+      for (int z = 0; z < rt.pass_sleep; ++z) __builtin_amdgcn_s_sleep(1);
     }
-    if (!need) break;
-    if (spin_fail(rt, spins)) break;
-    for (int z = 0; z < rt.pass_sleep; ++z) __builtin_amdgcn_s_sleep(1);
   }
 }
 
@@ -341,12 +344,15 @@ __device__ __forceinline__ void ln_row_store(const LnRow<K>& r, uint32_t* __rest
       *reinterpret_cast<uint2*>(sx + (t + j * 256) * 2) = p;
     }
 }
-// all 1024 threads call this (two workgroup barriers inside); red: [2 passes][NB][4][2] floats
+// row handled by the wave group q (= thread / 256): rows run at once on different groups; the loader wave's group (1) is used last
+__device__ __forceinline__ int ln_row_of(int nb, int q) {
+  return q == 0 ? 0 : q == 3 ? (nb == 2 ? 1 : nb >= 3 ? 2 : -1) : q == 2 ? (nb >= 3 ? 1 : -1) : (nb == 4 ? 3 : -1);
+}
+// all 1024 threads call this (two workgroup barriers inside); red: [2 passes][4 rows][4][2] floats
 template <int NB, int K>
 __device__ __forceinline__ void ln_to_sxb(const float* __restrict__ xf, uint32_t* __restrict__ sxb, float* __restrict__ red, int t,
                                           float eps) {
-  static_assert(NB >= 1 && NB <= 2, "one group of four waves per row");
-  const int grp = t < 256 ? 0 : (NB == 2 && t >= 768 ? 1 : -1);  // which row this thread works on (-1: none)
+  const int grp = ln_row_of(NB, t >> 8);  // which row this thread works on (-1: none)
   const int tr = t & 255;
   LnRow<K> r;
   if (grp >= 0) {
@@ -364,7 +370,7 @@ __device__ __forceinline__ void ln_to_sxb(const float* __restrict__ xf, uint32_t
 template <int NB, int K>
 __device__ __forceinline__ void ln2_to_sxb(const float* __restrict__ xf, uint32_t* __restrict__ sxb, float* __restrict__ red, int t,
                                            float eps, const float* __restrict__ gamma, const float* __restrict__ beta) {
-  const int grp = t < 256 ? 0 : (NB == 2 && t >= 768 ? 1 : -1);
+  const int grp = ln_row_of(NB, t >> 8);
   const int tr = t & 255;
   LnRow<K> r;
   f32x4 gm[2], bt[2];
@@ -385,11 +391,11 @@ __device__ __forceinline__ void ln2_to_sxb(const float* __restrict__ xf, uint32_
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int e = 0; e < 4; ++e) r.xv[j][e] = ln_affine_rn(r.xv[j][e], gm[j][e], bt[j][e]);
-    ln_row_moments<K>(r, 0.f, red + 16 + grp * 8, tr);
+    ln_row_moments<K>(r, 0.f, red + 32 + grp * 8, tr);
   }
   __syncthreads();
   if (grp >= 0) {
-    ln_row_norm<K>(r, 0.f, red + 16 + grp * 8, eps);
+    ln_row_norm<K>(r, 0.f, red + 32 + grp * 8, eps);
     ln_row_store<K>(r, sxb + grp * (K / 2), tr);
   }
   __syncthreads();
@@ -418,15 +424,20 @@ __global__ __launch_bounds__(1024) void decode_engine_kernel(EngArgs a) {
   constexpr unsigned SLOT = 256 + FO * D * 2;  // = 256 + HO * 4D * 2
   constexpr unsigned SLOTC = 256 + HO * D * 2;
   static_assert(SLOT >= 256 + QO * D * 2 && SLOT >= 256 + HO * 4 * D * 2, "slot size");
+  constexpr bool SLOT3 = NB <= 2;
   unsigned char* W0 = smem;                 // A
   unsigned char* W1 = smem + SLOT;          // B
-  unsigned char* W2 = smem + 2 * SLOT;      // C
-  float* xf = reinterpret_cast<float*>(smem + 2 * SLOT + SLOTC);    // [NB][D] gathered residual stream (fp32)
-  uint32_t* xn = reinterpret_cast<uint32_t*>(xf + NB * D);          // [NB][D / 2] LayerNorm output, bf16 pairs
-  uint32_t* xc = xn + NB * D / 2;                                   // [NB][D / 2] attention context, bf16 pairs
-  uint32_t* xa = xc + NB * D / 2;                                   // [NB][4D / 2] gelu(fc), bf16 pairs
-  float* red = reinterpret_cast<float*>(xa + NB * 2 * D);           // [4][2 NB]
-  float* hown = red + 4 * 2 * 4;                                    // [NB][8] this workgroup's slice of the residual stream
+  unsigned char* W2 = SLOT3 ? smem + 2 * SLOT : W1;  // C (3 - 4 rows: c_proj in slot B)
+  // 3 - 4 rows: no slot C (c_proj shares slot B with mlp.c_proj, which is then requested behind the second LayerNorm), and the
+  // fp32 residual-stream buffer and the context buffer live inside the gelu(fc) buffer: that one is written by the E5 gather
+  // and read by mlp.c_proj only, and every gather into the aliases starts behind wait_own() = after every compute wave is
+  // through the phase that read the previous content.  LDS: 147.8 KB at 3 rows, 160.6 KB of 163.8 at 4.
+  uint32_t* xn = reinterpret_cast<uint32_t*>(smem + 2 * SLOT + (SLOT3 ? SLOTC : 0));  // [NB][D / 2] LayerNorm output, bf16 pairs
+  uint32_t* xa = xn + NB * D / 2;                                   // [NB][4D / 2] gelu(fc), bf16 pairs
+  float* xf = SLOT3 ? reinterpret_cast<float*>(xa + NB * 2 * D) : reinterpret_cast<float*>(xa);             // [NB][D] fp32
+  uint32_t* xc = SLOT3 ? reinterpret_cast<uint32_t*>(xf + NB * D) : xa + NB * D;                           // [NB][D / 2]
+  float* red = reinterpret_cast<float*>(SLOT3 ? xc + NB * D / 2 : xa + NB * 2 * D);   // [2][4][4][2]
+  float* hown = red + 64;                                           // [NB][8] this workgroup's slice of the residual stream
   float* qkvs = hown + 4 * 8;                                       // [3][64] q / k / v of this (row, head)
   float* so = qkvs + 3 * DH;                                        // [16][64]
   float* smx = so + 16 * DH;                                        // [16]
@@ -435,7 +446,7 @@ __global__ __launch_bounds__(1024) void decode_engine_kernel(EngArgs a) {
   float* pml = po + NSPLIT * DH;                                    // [2][4]
   unsigned* own = reinterpret_cast<unsigned*>(pml + 8);             // [1] phases finished by the compute waves (x NCW)
   const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
-  const unsigned S0 = lds0, S1 = lds0 + SLOT, S2 = lds0 + 2 * SLOT;
+  const unsigned S0 = lds0, S1 = lds0 + SLOT, S2 = SLOT3 ? lds0 + 2 * SLOT : S1;
   const unsigned own_lds = lds0 + (unsigned)(reinterpret_cast<unsigned char*>(own) - smem);
 
   const int t = threadIdx.x, lane = t & 63;
@@ -479,8 +490,10 @@ __global__ __launch_bounds__(1024) void decode_engine_kernel(EngArgs a) {
   //   behind B1: mlp.c_proj(l) -> B    behind B3: c_fc(l) -> A    behind B4: c_proj(l + 1) -> C    behind B5: c_attn(l + 1) -> A
   // vmcnt is in-order, so c_proj / mlp.c_proj (requested three barriers before their use) have landed whenever the request
   // after them has; the loader waits (vmcnt(0)) only in front of B1 (c_attn) and B4 (c_fc), each 2.5 - 3 us after the request.
+  // (3 - 4 rows, two slots: B1 -> c_proj(l) -> B, B3 -> c_fc(l) -> A, B4 -> mlp.c_proj(l) -> B, B5 -> c_attn(l + 1) -> A, and the
+  // loader waits in front of every barrier for the one request before it)
   if (lw) {
-    dma_rows<HO, D>(a.L[0].wp, a.L[0].bp, cu * HO, S2, lane);
+    if (SLOT3) dma_rows<HO, D>(a.L[0].wp, a.L[0].bp, cu * HO, S2, lane);
     if (qcu) dma_rows<QO, D>(a.L[0].wa, a.L[0].ba, an0, S0, lane);
   }
   if (t < NB * HO) hown[(t / HO) * 8 + t % HO] = a.h[(size_t)(t / HO) * D + cu * HO + t % HO];
@@ -516,7 +529,11 @@ __global__ __launch_bounds__(1024) void decode_engine_kernel(EngArgs a) {
     // mlp.c_proj -> B (every wave is past the last block's); behind the LayerNorm's barriers, which the loader must not hold up.
     // Not on an attention workgroup: its loader is one of the 16 attention waves, and the cache rows it requests next would
     // queue behind these 50 KB (vmcnt is in-order) - there mlp.c_proj follows behind the second LayerNorm
-    if (lw && !acu) dma_rows<HO, 4 * D>(w.w2, w.b2, cu * HO, S1, ll);
+    if (SLOT3) {
+      if (lw && !acu) dma_rows<HO, 4 * D>(w.w2, w.b2, cu * HO, S1, ll);
+    } else if (lw) {
+      dma_rows<HO, D>(w.wp, w.bp, cu * HO, S1, ll);  // c_proj -> B (every wave is past the last block's mlp.c_proj)
+    }
     if (qcu && cwv) {
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
@@ -749,7 +766,9 @@ __global__ __launch_bounds__(1024) void decode_engine_kernel(EngArgs a) {
         sweep2<(NB * D / 4 + 255) / 256, false>(G + OCTX, NB * D / 4, tl, rt, [&](int i, uint32_t v) { xc[i] = v; }, rt.first_delay);
       else
         sweep2<(NB * D / 4 + 255) / 256, true>(G + OCTX, NB * D / 4, tl, rt, [&](int i, uint32_t v) { xc[i] = v; }, a.ctx_delay);
-    }  // (c_proj is older in the loader's queue than c_attn: it landed before this block's first barrier)
+    } else if (!SLOT3 && lw) {
+      dma_wait_keep<0>();  // c_proj (requested behind this block's first LayerNorm)
+    }  // (three slots: c_proj is older in the loader's queue than c_attn, it landed before this block's first barrier)
     ENG_STAMP(4)
     __syncthreads();
     if (lw) {  // c_fc -> A: every wave is past c_attn
@@ -789,8 +808,12 @@ __global__ __launch_bounds__(1024) void decode_engine_kernel(EngArgs a) {
     __syncthreads();
     ENG_STAMP(12)
     ln_to_sxb<NB, D>(xf, xn, red, tl, a.eps);
-    if (lw && acu) dma_rows<HO, 4 * D>(w.w2, w.b2, cu * HO, S1, ll);
-    if (lw && l + 1 < a.NL) dma_rows<HO, D>(a.L[l + 1].wp, a.L[l + 1].bp, cu * HO, S2, ll);  // next c_proj -> C: all past this one's
+    if (SLOT3) {
+      if (lw && acu) dma_rows<HO, 4 * D>(w.w2, w.b2, cu * HO, S1, ll);
+      if (lw && l + 1 < a.NL) dma_rows<HO, D>(a.L[l + 1].wp, a.L[l + 1].bp, cu * HO, S2, ll);  // next c_proj -> C: all past this one's
+    } else if (lw) {
+      dma_rows<HO, 4 * D>(w.w2, w.b2, cu * HO, S1, ll);  // mlp.c_proj -> B: all past c_proj
+    }
     ENG_STAMP(13)
     if (cwv && cw < FO / 2) {  // an adjacent pair of features per wave: one bf16-pair granule per batch row
       float acc[2][NB];
@@ -828,6 +851,8 @@ __global__ __launch_bounds__(1024) void decode_engine_kernel(EngArgs a) {
     if (gw) {
       wait_own(own_lds, NCW * phase, rt);
       sweep2<(NB * D + 255) / 256, false>(G + OACT, NB * D, tl, rt, [&](int i, uint32_t v) { xa[i] = v; }, a.act_delay);
+    } else if (lw && !SLOT3) {
+      dma_wait_keep<0>();  // mlp.c_proj (requested behind LN2)
     } else if (lw && acu) {  // mlp.c_proj was requested behind LN2 here; the next block's c_proj (if any) is younger
       if (l + 1 < a.NL)
         dma_wait_keep<DmaCount<HO, D>::N>();
@@ -962,7 +987,9 @@ int decode_engine_layers(const EngArgs& a, hipStream_t s) {
     hipLaunchKernelGGL((decode_engine_kernel<NB>), dim3(ENG_NCU), dim3(1024), lds, s, a);                                       \
   }
   if (a.B == 1) ITTS_ENG_GO(1)
-  else ITTS_ENG_GO(2)
+  else if (a.B == 2) ITTS_ENG_GO(2)
+  else if (a.B == 3) ITTS_ENG_GO(3)
+  else ITTS_ENG_GO(4)
 #undef ITTS_ENG_GO
   ITTS_HIP_CHECK(hipGetLastError());
   return OK;

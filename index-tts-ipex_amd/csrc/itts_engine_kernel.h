@@ -4,7 +4,7 @@
 
 namespace itts {
 
-constexpr int ENG_D = 1280, ENG_H = 20, ENG_NCU = 256, ENG_MAX_ROWS = 2;
+constexpr int ENG_D = 1280, ENG_H = 20, ENG_NCU = 256, ENG_MAX_ROWS = 4;
 constexpr int ENG_MAX_LAYERS = 24;
 constexpr bool ENG_DEFAULT_ON = true;   // ITTS_ENGINE=0 keeps the five-launches-per-block path  // IndexTTS-1.5 GPT on the 256 CUs of an MI355X
 

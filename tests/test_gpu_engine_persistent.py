@@ -1,6 +1,6 @@
-"""GPU: the persistent decode engine (csrc/decode_engine.hip: the 24 blocks of a token step as ONE launch, <= 2 rows,
+"""GPU: the persistent decode engine (csrc/decode_engine.hip: the 24 blocks of a token step as ONE launch, <= 4 rows,
 bf16) against the launch path it replaces (gemv_bf16_kernel + decode_attn2_kernel, five launches a layer): the engine
-repeats the launch path's arithmetic operation for operation, so ids AND logits have to be bit-identical - at 1 and 2
+repeats the launch path's arithmetic operation for operation, so ids AND logits have to be bit-identical - at 1 to 4
 rows, under graph replay and eager launches, through the register window of the cache attention and past it.
 Reference hot loop: indextts/gpt/model.py:115-192."""
 import numpy as np
@@ -42,7 +42,7 @@ def run(eng, cond, text, steps, no_engine, no_graph=False, chunk=8):
     return codes, lg
 
 
-@pytest.mark.parametrize("rows", [1, 2])
+@pytest.mark.parametrize("rows", [1, 2, 3, 4])
 def test_engine_equals_launch_path_bitwise(eng16, cond, rows):
     text = np.stack([synth.text_ids(105, 11 + r, CFG.gpt.number_text_tokens) for r in range(rows)]).astype(np.int32)
     ref_codes, ref_lg = run(eng16, cond, text, 64, no_engine=True)
@@ -54,15 +54,14 @@ def test_engine_equals_launch_path_bitwise(eng16, cond, rows):
     assert np.array_equal(codes2, ref_codes[:, :24])
 
 
-def test_engine_ragged_rows_and_long_sequence(eng16, cond):
-    """Two rows of different text lengths (left padding -> kv_start) decoded far past the 768-key register window of the
-    cache attention (prefix 139 + 700 steps): the streaming part of every key split runs."""
-    t0 = synth.text_ids(105, 21, CFG.gpt.number_text_tokens)
-    t1 = synth.text_ids(60, 22, CFG.gpt.number_text_tokens)
+@pytest.mark.parametrize("rows", [2, 4])
+def test_engine_ragged_rows_and_long_sequence(eng16, cond, rows):
+    """Rows of different text lengths (left padding -> kv_start) decoded far past the 768-key register window of the
+    cache attention (prefix 139 + 700 steps): the streaming part of every key split runs.  4 rows: the two-slot LDS map."""
     stop = CFG.gpt.stop_text_token
-    text = np.full((2, 105), stop, np.int32)  # start/stop text ids are stripped and left-padded by the prefix builder
-    text[0] = t0
-    text[1, :60] = t1
+    text = np.full((rows, 105), stop, np.int32)  # start/stop text ids are stripped and left-padded by the prefix builder
+    for r, n in enumerate([105, 60, 33, 90][:rows]):
+        text[r, :n] = synth.text_ids(n, 21 + r, CFG.gpt.number_text_tokens)
     ref_codes, ref_lg = run(eng16, cond, text, 700, no_engine=True, chunk=64)
     codes, lg = run(eng16, cond, text, 700, no_engine=False, chunk=64)
     assert np.array_equal(codes, ref_codes)
