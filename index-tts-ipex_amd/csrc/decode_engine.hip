@@ -402,7 +402,9 @@ __device__ __forceinline__ void ln2_to_sxb(const float* __restrict__ xf, uint32_
 }
 
 // ---------------------------------------------------------------------------------------------
-template <int NB>
+// ANC: beam rows - the cache is never re-ordered when the beams are; key j of beam row b lives in the physical row its
+// ancestry names (decode2.hip, decode_attn2_kernel<.., ANC>: the same gather, the same arithmetic)
+template <int NB, bool ANC>
 __global__ __launch_bounds__(1024) void decode_engine_kernel(EngArgs a) {
   constexpr int D = ENG_D, H = ENG_H, DH = 64, NCU = ENG_NCU;
   constexpr int GPH = NCU / H;       // workgroups per head group (12)
@@ -477,6 +479,7 @@ __global__ __launch_bounds__(1024) void decode_engine_kernel(EngArgs a) {
   const int prefix = __builtin_amdgcn_readfirstlane(a.prefix[0]);
   const int my_pos = acu ? __builtin_amdgcn_readfirstlane(prefix + a.len[acu ? gm : 0]) : 0;  // cache row this step appends
   const int my_ks = acu ? __builtin_amdgcn_readfirstlane(a.kv_start[acu ? gm : 0]) : 0;
+  const int my_par = (ANC && acu) ? __builtin_amdgcn_readfirstlane(a.len[acu ? gm : 0] & 1) : 0;  // ancestry ping-pong half
 
   if (t == 0) *own = 0;
   unsigned phase = 0;  // compute phases finished so far (every wave counts alike)
@@ -571,19 +574,33 @@ __global__ __launch_bounds__(1024) void decode_engine_kernel(EngArgs a) {
       const size_t lo = ((size_t)l * a.B * H + (size_t)gm * H + gh) * a.Smax * DH;
       bf16_t* kb = a.kc + lo;
       bf16_t* vb = a.vc + lo;
+      const uint8_t* arow = nullptr;
+      size_t lbase = 0;  // (ANC) first row of this beam's batch item in block l
+      if constexpr (ANC) {
+        arow = a.anc + ((size_t)my_par * a.B + gm) * a.Smax;
+        lbase = ((size_t)l * a.B + (size_t)(gm / a.nb) * a.nb) * H;
+      }
+      auto krow = [&](int j) -> const bf16_t* {
+        if constexpr (ANC) return a.kc + ((lbase + (size_t)min((int)arow[j], a.nb - 1) * H + gh) * a.Smax + j) * DH;
+        return kb + (size_t)j * DH;
+      };
+      auto vrow = [&](int j) -> const bf16_t* {
+        if constexpr (ANC) return a.vc + ((lbase + (size_t)min((int)arow[j], a.nb - 1) * H + gh) * a.Smax + j) * DH;
+        return vb + (size_t)j * DH;
+      };
 #pragma unroll
       for (int u = 0; u < UNC; ++u) {
         const int j = min((u * NSPLIT + sp) * SLOTS + slot, a.Smax - 1);
-        kr[u].load(kb + (size_t)j * DH + sub * VEC);
-        vr[u].load(vb + (size_t)j * DH + sub * VEC);
+        kr[u].load(krow(j) + sub * VEC);
+        vr[u].load(vrow(j) + sub * VEC);
       }
       const int pos = my_pos, S = pos + 1, ks = my_ks;
 #pragma unroll
       for (int u = UNC; u < 2 * NIT; ++u)
         if ((u * NSPLIT + sp) * SLOTS < S) {
           const int j = min((u * NSPLIT + sp) * SLOTS + slot, a.Smax - 1);
-          kr[u].load(kb + (size_t)j * DH + sub * VEC);
-          vr[u].load(vb + (size_t)j * DH + sub * VEC);
+          kr[u].load(krow(j) + sub * VEC);
+          vr[u].load(vrow(j) + sub * VEC);
         }
       __builtin_amdgcn_sched_barrier(0);
       if (gw && tl < 3 * DH) {  // q / k / v of this (row, head): 192 granules, one per thread
@@ -681,8 +698,8 @@ __global__ __launch_bounds__(1024) void decode_engine_kernel(EngArgs a) {
 #pragma unroll
         for (int u = 0; u < SD; ++u) {
           const int j = min(((cb + u) * NSPLIT + sp) * SLOTS + slot, a.Smax - 1);
-          k2[u].load(kb + (size_t)j * DH + sub * VEC);
-          v2[u].load(vb + (size_t)j * DH + sub * VEC);
+          k2[u].load(krow(j) + sub * VEC);
+          v2[u].load(vrow(j) + sub * VEC);
         }
 #pragma unroll
         for (int u = 0; u < SD; ++u) consume(k2[u], v2[u], ((cb + u) * NSPLIT + sp) * SLOTS + slot);
@@ -976,20 +993,25 @@ size_t eng_gran_count(int layers) { return (size_t)layers * 4 * ENG_D * 15 / 2; 
 int decode_engine_layers(const EngArgs& a, hipStream_t s) {
   ITTS_REQUIRE(a.B >= 1 && a.B <= ENG_MAX_ROWS && a.NL >= 1 && a.NL <= ENG_MAX_LAYERS && a.gran && a.h && a.kc && a.vc && a.ctr, "decode_engine: bad arguments");
   const size_t lds = 160 * 1024;  // three weight slots + edge buffers: the whole LDS of a CU, one workgroup per CU
-#define ITTS_ENG_GO(NB)                                                                                                         \
+#define ITTS_ENG_GO(NB, ANC_)                                                                                                   \
   {                                                                                                                             \
     static bool attr = false;                                                                                                   \
     if (!attr) {                                                                                                                \
-      ITTS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&decode_engine_kernel<NB>),                              \
+      ITTS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&decode_engine_kernel<NB, ANC_>),                        \
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                                \
       attr = true;                                                                                                              \
     }                                                                                                                           \
-    hipLaunchKernelGGL((decode_engine_kernel<NB>), dim3(ENG_NCU), dim3(1024), lds, s, a);                                       \
+    hipLaunchKernelGGL((decode_engine_kernel<NB, ANC_>), dim3(ENG_NCU), dim3(1024), lds, s, a);                                 \
   }
-  if (a.B == 1) ITTS_ENG_GO(1)
-  else if (a.B == 2) ITTS_ENG_GO(2)
-  else if (a.B == 3) ITTS_ENG_GO(3)
-  else ITTS_ENG_GO(4)
+  if (a.anc) {  // beam rows (>= 2 rows per batch item)
+    ITTS_REQUIRE(a.nb >= 2 && a.nb <= a.B && a.B % a.nb == 0, "decode_engine: beam ancestry needs B to be a multiple of 2 <= nb <= B");
+    if (a.B == 2) ITTS_ENG_GO(2, true)
+    else if (a.B == 3) ITTS_ENG_GO(3, true)
+    else ITTS_ENG_GO(4, true)
+  } else if (a.B == 1) ITTS_ENG_GO(1, false)
+  else if (a.B == 2) ITTS_ENG_GO(2, false)
+  else if (a.B == 3) ITTS_ENG_GO(3, false)
+  else ITTS_ENG_GO(4, false)
 #undef ITTS_ENG_GO
   ITTS_HIP_CHECK(hipGetLastError());
   return OK;

@@ -25,6 +25,8 @@ struct EngArgs {
   const int* kv_start = nullptr;      // [B] first valid (not left-padded) cache row
   const int* prefix = nullptr;        // [0] prefix length
   unsigned* ctr = nullptr;            // [0] step counter = hand-off tag (starts at 1, never 0), [1] abort word
+  const uint8_t* anc = nullptr;       // beam rows: ancestry [2][B][Smax] (ping-pong by the parity of len), nb rows per batch item
+  int nb = 1;
   int NL = 0, B = 0, Smax = 0;
   float scale = 0.125f, eps = 1e-5f;
   unsigned timeout_ticks = 2000000;   // wall-clock bound of every wait, 100 MHz ticks (20 ms)

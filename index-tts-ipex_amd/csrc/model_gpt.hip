@@ -159,7 +159,7 @@ int Engine::ensure_decode_tiles(hipStream_t s) {
 }
 
 // The persistent decode engine (decode_engine.hip) replaces the 120 per-layer launches of a step when the step is the
-// launch-bound small-batch bf16 one it was built for: IndexTTS-1.5 GPT dims, <= 4 rows, no beams (cache ancestry), no fp8
+// launch-bound small-batch bf16 one it was built for: IndexTTS-1.5 GPT dims, <= 4 rows (beam rows included: cache ancestry), no fp8
 // copies, a whole MI355X (256 CUs) to itself.  ITTS_ENGINE=0 (or debug bit 4) keeps the launch path.
 bool Engine::engine_usable() const {
   const char* ev = getenv("ITTS_ENGINE");  // read per call: tests flip it inside one process
@@ -172,7 +172,7 @@ bool Engine::engine_usable() const {
   const itts_config& c = cfg;
   if ((env_off && !ds.eng_force) || ds.eng_off || ds.eng_failed || ncu != ENG_NCU) return false;
   if (ds.fuse && !ds.fuse_failed) return false;  // A/B switch of the fused projection + attention launch: a launch-path variant
-  if (adt != BF16 || ds.B < 1 || ds.B > ENG_MAX_ROWS || ds.nb != 1) return false;
+  if (adt != BF16 || ds.B < 1 || ds.B > ENG_MAX_ROWS || ds.nb < 1 || ds.B % ds.nb != 0 || (ds.nb > 1 && !ds.anc)) return false;
   if (c.model_dim != ENG_D || c.heads != ENG_H || c.layers < 1 || c.layers > ENG_MAX_LAYERS || ds.Smax > 2048 || ds.Smax % 256 != 0) return false;
   for (const GptLayerW& L : gpt.layers)
     for (const Lin* l : {&L.attn, &L.proj, &L.fc, &L.proj2})
@@ -422,7 +422,6 @@ int Engine::gpt_prefill(const float* cond_dev, const int32_t* text_ids_in, int B
   ds.suppress_stop = suppress;
   gen_epoch = (gen_epoch % 0xFFFFF) + 1;  // 1 .. 2^20 - 1
   ds.nb = nbeam;
-  if (engine_usable()) ITTS_TRY(ensure_engine_state(s));  // allocations must not happen inside the graph capture of the step
   ds.beam_sample = beam_do_sample;
   ds.length_penalty = beam_length_penalty;
   if (nbeam > 1) {
@@ -433,6 +432,7 @@ int Engine::gpt_prefill(const float* cond_dev, const int32_t* text_ids_in, int B
                        ds.hyp_order, ds.hyp_n, ds.hyp_worst, ds.hyp_counter, ds.beam_done, B, nbeam, Smax, beam_do_sample);
     ITTS_HIP_CHECK(hipGetLastError());
   }
+  if (engine_usable()) ITTS_TRY(ensure_engine_state(s));  // allocations must not happen inside the graph capture of the step
   if (ds.do_sample || (nbeam > 1 && beam_do_sample)) {
     const size_t need_u = nbeam > 1 ? (size_t)max_gen * B_items * 2 * nbeam : (size_t)max_gen * B;
     ITTS_REQUIRE(sample_uniforms.size() >= need_u,
@@ -706,6 +706,8 @@ int Engine::decode_step_launch(hipStream_t s) {
     ea.kv_start = ds.kv_start;
     ea.prefix = ds.prefix_dev;
     ea.ctr = ds.eng_ctr;
+    ea.anc = ds.nb > 1 ? ds.anc : nullptr;  // beam rows gather their keys through the ancestry table (no cache re-ordering)
+    ea.nb = ds.nb;
     // ITTS_ENGINE_LAYERS=n (debugging aid): blocks [0, n) on the engine, the rest as launches
     static const int e_nl = getenv("ITTS_ENGINE_LAYERS") ? atoi(getenv("ITTS_ENGINE_LAYERS")) : -1;
     eng_first = e_nl >= 0 && e_nl < c.layers ? e_nl : c.layers;

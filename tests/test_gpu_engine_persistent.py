@@ -68,6 +68,28 @@ def test_engine_ragged_rows_and_long_sequence(eng16, cond, rows):
     assert np.array_equal(lg.view(np.uint32), ref_lg.view(np.uint32))
 
 
+@pytest.mark.parametrize("items,nb,sample", [(1, 3, True), (1, 3, False), (2, 2, True), (1, 4, True), (1, 2, False)])
+def test_engine_beam_rows_equal_launch_path(eng16, cond, items, nb, sample):
+    """The reference's default generate() mode (num_beams 3, model.py:698-703) one sentence at a time = 3 rows: the
+    engine's cache attention gathers every key through the beam's ancestry row exactly as decode_attn2_kernel<.., ANC>
+    does (the cache is never re-ordered), so the beam sampler sees the same logits bit for bit and returns the same ids,
+    past the 768-key register window (prefix 139 + 700 steps) and under graph replay."""
+    text = np.stack([synth.text_ids(105, 51 + r, CFG.gpt.number_text_tokens) for r in range(items)]).astype(np.int32)
+    n = 700 if (items, nb, sample) == (1, 3, True) else 96
+    u = np.random.default_rng(9).random((n, items, 2 * nb), dtype=np.float32)
+    kw = dict(do_sample=sample, num_beams=nb, top_k=30, top_p=0.8, temperature=1.0, uniforms=u, suppress_stop=True)
+    res, modes = [], []
+    for no_engine in (True, False):
+        eng16.debug(no_engine=no_engine, engine=not no_engine)
+        try:
+            res.append(eng16.generate(cond, text, n, **kw))
+            modes.append(eng16.decode_mode())
+        finally:
+            eng16.debug()
+    assert modes == [0, 1], modes
+    assert res[0].shape == (items, n) and np.array_equal(res[0], res[1])
+
+
 def test_engine_status_reports_no_timeout(eng16, cond):
     text = synth.text_ids(105, 31, CFG.gpt.number_text_tokens).reshape(1, -1).astype(np.int32)
     eng16.debug(engine=True)
