@@ -155,6 +155,13 @@ int itts_gpt_set_beam_sample(itts_engine* e, int num_beams, int top_k, float top
 int itts_gpt_set_beams(itts_engine* e, int num_beams, int do_sample, int top_k, float top_p, float temperature, float length_penalty,
                        const float* uniforms_host, int64_t n_uniforms);
 
+/* `num_return_sequences` of generate() under beams (gpt/model.py:655,698-703 forwards it; HF's BeamSearchScorer keeps
+ * num_beam_hyps_to_keep = num_return_sequences hypotheses per batch item): itts_gpt_fetch then returns the n best
+ * hypotheses of every batch item, best first, as codes [B * n][max_gen].  1 <= n <= num_beams (checked by
+ * itts_gpt_prefill, with HF's message); stays in force until changed.  (Without beams the caller repeats the rows, as HF
+ * does: indextts/gpt/model.py.)  ABI 4. */
+int itts_gpt_set_beam_returns(itts_engine* e, int num_return_sequences);
+
 /* `typical_sampling=True` of UnifiedVoice.inference_speech (gpt/model.py:690-697): the reference's TypicalLogitsWarper
  * (utils/typical_sampling.py:9-30, mass in (0, 1); min_tokens_to_keep 2 under beams, else 1) runs right after the repetition
  * penalty and before Temperature / TopK / TopP in the sampling and beam-sample modes.  mass = 0 switches it off. */

@@ -26,7 +26,7 @@ int gemm(const GemmArgs& g, int ta, int tw, int tc, hipStream_t s) {
 extern "C" {
 
 const char* itts_last_error(void) { return last_error(); }
-int itts_abi_version(void) { return 3; }
+int itts_abi_version(void) { return 4; }
 
 int itts_snake_aa_fwd(void* dst, const void* src, const float* up12, const float* down12, const float* log_alpha,
                       const float* log_beta, int B, int C, int T, int dtype, int layout, itts_stream stream) {
@@ -210,6 +210,10 @@ int itts_gpt_set_beams(itts_engine* e, int num_beams, int do_sample, int top_k, 
                        const float* uniforms_host, int64_t n_uniforms) {
   ENG(e);
   return e->e.gpt_set_beams(num_beams, do_sample, top_k, top_p, temperature, length_penalty, uniforms_host, (long)n_uniforms);
+}
+int itts_gpt_set_beam_returns(itts_engine* e, int num_return_sequences) {
+  ENG(e);
+  return e->e.gpt_set_beam_returns(num_return_sequences);
 }
 int itts_gpt_set_typical(itts_engine* e, float mass) {
   ENG(e);

@@ -234,10 +234,12 @@ struct Engine {
   int gpt_set_beam_sample(int num_beams, int top_k, float top_p, float temperature, const float* uniforms_host, long n);
   int gpt_set_beams(int num_beams, int do_sample, int top_k, float top_p, float temperature, float length_penalty,
                     const float* uniforms_host, long n);
+  int gpt_set_beam_returns(int n);
   int beam_do_sample = 1;
   float beam_length_penalty = 0.f;
   int gen_epoch = 0;   // generation counter: high bits of the hand-off tags (never 0)
   int beam_beams = 1;  // requested beams for the following generations (1 = off)
+  int beam_returns = 1;  // hypotheses returned per batch item (generate()'s num_return_sequences = num_beam_hyps_to_keep)
   int ensure_beam_state(int rows, int max_gen, int Smax, hipStream_t s);
   int beam_finalize(int32_t* codes_host, hipStream_t s);
   std::vector<int32_t> forced_host;  // [forced_B][forced_n], uploaded by the next prefill

@@ -293,6 +293,14 @@ int Engine::ensure_beam_state(int rows, int max_gen, int Smax, hipStream_t s) {
 
 // HF beam_sample configuration for the following generations (num_beams <= 1 switches it off): the generate() mode of
 // the reference's default kwargs (infer.py:116-124).  uniforms_host: row-major [max_gen][B][2 * num_beams] draws in [0, 1).
+// generate()'s num_return_sequences under beams: the n best hypotheses of every batch item (1 <= n <= num_beams, checked
+// against the beam count when the generation starts)
+int Engine::gpt_set_beam_returns(int n) {
+  ITTS_REQUIRE(n >= 1 && n <= 10, "gpt_set_beam_returns: num_return_sequences must be in [1, 10]");
+  beam_returns = n;
+  return OK;
+}
+
 int Engine::gpt_set_beam_sample(int num_beams, int top_k, float top_p, float temperature, const float* uniforms_host, long n) {
   return gpt_set_beams(num_beams, 1, top_k, top_p, temperature, 0.f, uniforms_host, n);
 }
@@ -325,8 +333,9 @@ int Engine::gpt_set_beams(int num_beams, int do_sample, int top_k, float top_p, 
 }
 
 // BeamSearchScorer.finalize (beam_search.py, 4.36.2) on the host: open beams of unfinished batch items join their
-// hypotheses with the running scores, the best hypothesis (highest score, the later one on ties) is returned per batch
-// item as codes [B][max_gen] padded with the stop token (eos = pad = stop_mel_token, model.py:698-700).
+// hypotheses with the running scores, the beam_returns best hypotheses (num_beam_hyps_to_keep = generate()'s
+// num_return_sequences, model.py:655,698-703; highest score first, the later one on ties) are returned per batch item as
+// codes [B * beam_returns][max_gen] padded with the stop token (eos = pad = stop_mel_token, model.py:698-700).
 int Engine::beam_finalize(int32_t* codes, hipStream_t s) {
   DecodeState& d = ds;
   const int nb = d.nb, rows = d.B, B = rows / nb, mg = d.max_gen;
@@ -380,11 +389,16 @@ int Engine::beam_finalize(int32_t* codes, hipStream_t s) {
         }
       }
     }
-    ITTS_REQUIRE(!hy.empty(), "beam_finalize: no hypothesis for a batch item");
-    size_t best = 0;  // sorted(key=score).pop(): highest score, the later insertion on ties
-    for (size_t i = 1; i < hy.size(); ++i)
-      if (hy[i].score > hy[best].score || (hy[i].score == hy[best].score && hy[i].order > hy[best].order)) best = i;
-    for (int i = 0; i < mg; ++i) codes[(size_t)b * mg + i] = i < hy[best].len ? hy[best].tok[i] : cfg.stop_mel_token;
+    const int keep = beam_returns;
+    ITTS_REQUIRE((int)hy.size() >= keep, "beam_finalize: fewer hypotheses than num_return_sequences for a batch item");
+    for (int r = 0; r < keep; ++r) {
+      size_t best = 0;  // sorted(key=score).pop(): highest score, the later insertion on ties
+      for (size_t i = 1; i < hy.size(); ++i)
+        if (hy[i].score > hy[best].score || (hy[i].score == hy[best].score && hy[i].order > hy[best].order)) best = i;
+      int32_t* out = codes + ((size_t)b * keep + r) * mg;
+      for (int i = 0; i < mg; ++i) out[i] = i < hy[best].len ? hy[best].tok[i] : cfg.stop_mel_token;
+      hy.erase(hy.begin() + best);
+    }
   }
   return OK;
 }
@@ -426,6 +440,7 @@ int Engine::gpt_prefill(const float* cond_dev, const int32_t* text_ids_in, int B
   ds.length_penalty = beam_length_penalty;
   if (nbeam > 1) {
     ITTS_REQUIRE(forced_n == 0, "gpt_prefill: forced tokens are not supported together with beams");
+    ITTS_REQUIRE(beam_returns <= nbeam, "`num_return_sequences` has to be smaller or equal to `num_beams`.");
     ITTS_TRY(ensure_beam_state(B, max_gen, Smax, s));
     const long n_init = std::max<long>(2L * B * Smax, 64);
     hipLaunchKernelGGL(beam_init_kernel, dim3((unsigned)((n_init + 255) / 256)), dim3(256), 0, s, ds.anc, ds.beam_scores,
@@ -1151,7 +1166,7 @@ int Engine::gpt_fetch(int32_t* codes, float* logits, hipStream_t s) {
   }
   ITTS_TRY(engine_check(s));
   if (codes && ds.nb > 1)
-    ITTS_TRY(beam_finalize(codes, s));  // [B / nb][max_gen]
+    ITTS_TRY(beam_finalize(codes, s));  // [B / nb * beam_returns][max_gen]
   else if (codes)
     ITTS_HIP_CHECK(hipMemcpyAsync(codes, ds.ids, (size_t)ds.B * ds.max_gen * 4, hipMemcpyDeviceToHost, s));
   if (logits)

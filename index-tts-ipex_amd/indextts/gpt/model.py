@@ -74,14 +74,17 @@ class UnifiedVoice:
         nrs = int(num_return_sequences)
         if nrs < 1:
             raise ValueError("num_return_sequences has to be >= 1")
-        if nrs > 1:
-            # HF expands every input row num_return_sequences times (repeat_interleave) and samples the copies independently
-            # (model.py:655,698-703 -> GenerationMixin._expand_inputs_for_generation); greedy search with nrs > 1 is an error in
-            # HF too, and returning the n best beam hypotheses is not implemented here
+        nbeams = int(hf_generate_kwargs.get("num_beams", 1) or 1)
+        if nrs > 1 and nbeams > 1:
+            # beam modes: HF 4.36.2 expands the rows by num_beams only and BeamSearchScorer keeps num_beam_hyps_to_keep =
+            # num_return_sequences hypotheses per row (model.py:655,698-703): the n best of every row, best first
+            if nrs > nbeams:
+                raise ValueError("`num_return_sequences` has to be smaller or equal to `num_beams`.")
+        elif nrs > 1:
+            # one beam: HF expands every input row num_return_sequences times (repeat_interleave) and samples the copies
+            # independently (GenerationMixin._expand_inputs_for_generation); greedy search with nrs > 1 is an error in HF too
             if not hf_generate_kwargs.get("do_sample", False):
                 raise ValueError("num_return_sequences has to be 1 when doing greedy search")
-            if int(hf_generate_kwargs.get("num_beams", 1) or 1) > 1:
-                raise NotImplementedError("num_return_sequences > 1 together with num_beams > 1")
             if input_tokens is not None:
                 raise NotImplementedError("num_return_sequences > 1 together with input_tokens")
         sample_kw = infer_core.sampling_kwargs(hf_generate_kwargs.get("do_sample", False), hf_generate_kwargs.get("num_beams", 1),
@@ -92,7 +95,7 @@ class UnifiedVoice:
         ids = text_inputs.detach().cpu().numpy() if isinstance(text_inputs, torch.Tensor) else np.asarray(text_inputs)
         if ids.ndim == 1:
             ids = ids[None]
-        if nrs > 1:
+        if nrs > 1 and nbeams <= 1:
             ids = np.repeat(ids, nrs, axis=0)
             if cond.shape[0] > 1:
                 cond = cond.repeat_interleave(nrs, 0)
@@ -111,7 +114,8 @@ class UnifiedVoice:
                 self._eng.set_input_tokens(it)
             try:
                 # max_length = trunc_index + max_generate_length with trunc_index counting the given tokens (model.py:687,695)
-                codes = self._eng.generate(cond, ids, max_gen + n_forced, repetition_penalty=rep, **sample_kw)
+                codes = self._eng.generate(cond, ids, max_gen + n_forced, repetition_penalty=rep,
+                                           num_return_sequences=nrs if nbeams > 1 else 1, **sample_kw)
             finally:
                 if n_forced:
                     self._eng.set_input_tokens(None)

@@ -212,14 +212,19 @@ class Engine:
                                                u.ctypes.data_as(C.c_void_p), u.size), "gpt_set_sampling")
 
     def set_beam_sample(self, num_beams: int, top_k: int = 30, top_p: float = 0.8, temperature: float = 1.0,
-                        uniforms: Optional[np.ndarray] = None, do_sample: bool = True, length_penalty: float = 0.0):
+                        uniforms: Optional[np.ndarray] = None, do_sample: bool = True, length_penalty: float = 0.0,
+                        num_return_sequences: int = 1):
         """HF beam_sample (do_sample: the reference's default generate() mode, infer.py:116-124; uniforms
         [max_gen, B, 2 * num_beams] float32 in [0, 1)) or beam_search (not do_sample: deterministic) for the following
-        generations.  num_beams <= 1 switches beams off."""
+        generations.  num_beams <= 1 switches beams off.  num_return_sequences: the n best hypotheses per row (fetch
+        returns [B * n, max_gen], best first)."""
         if num_beams <= 1:
             L.check(self.lib.itts_gpt_set_beams(self.h, 1, 1, 1, 1.0, 1.0, 0.0, None, 0), "gpt_set_beams")
-            self._nb = 1
+            L.check(self.lib.itts_gpt_set_beam_returns(self.h, 1), "gpt_set_beam_returns")
+            self._nb, self._nret = 1, 1
             return
+        L.check(self.lib.itts_gpt_set_beam_returns(self.h, int(num_return_sequences)), "gpt_set_beam_returns")
+        self._nret = int(num_return_sequences)
         u = np.ascontiguousarray(uniforms, dtype=np.float32) if do_sample else None
         L.check(self.lib.itts_gpt_set_beams(self.h, int(num_beams), int(bool(do_sample)), int(top_k), float(top_p), float(temperature),
                                             float(length_penalty), u.ctypes.data_as(C.c_void_p) if do_sample else None,
@@ -257,7 +262,7 @@ class Engine:
 
     def fetch(self, logits: bool = False):
         B, mg = self._gen
-        codes = np.empty((B, mg), dtype=np.int32)
+        codes = np.empty((B * (getattr(self, "_nret", 1) if getattr(self, "_nb", 1) > 1 else 1), mg), dtype=np.int32)
         lg = np.empty((B * getattr(self, "_nb", 1), self.ccfg.number_mel_codes), dtype=np.float32) if logits else None
         L.check(self.lib.itts_gpt_fetch(self.h, codes.ctypes.data_as(C.c_void_p),
                                         lg.ctypes.data_as(C.c_void_p) if logits else None, self._s()), "gpt_fetch")
@@ -267,13 +272,16 @@ class Engine:
                  suppress_stop: bool = False, check_every: int = 16, do_sample: bool = False, top_k: int = 30,
                  top_p: float = 0.8, temperature: float = 1.0, seed: Optional[int] = None,
                  uniforms: Optional[np.ndarray] = None, num_beams: int = 1, typical_mass: float = 0.0,
-                 length_penalty: float = 0.0) -> np.ndarray:
+                 length_penalty: float = 0.0, num_return_sequences: int = 1) -> np.ndarray:
         """Greedy decode (do_sample=False, num_beams=1 of tests/padding_test.py:35-46) or, with do_sample, HF
         GenerationMixin.sample (top-k / top-p / temperature, num_beams=1; draws from `uniforms` or a numpy Generator
         seeded with `seed`).  Returns int64 codes [B, n] with n <= max_gen: HF stops when every row has emitted stop
         or at max length.  num_beams > 1: HF beam_sample (do_sample; uniforms [max_gen, B, 2 * num_beams]) or beam_search
-        (not do_sample) over num_beams beams per row; returns the best finalized hypothesis per row."""
+        (not do_sample) over num_beams beams per row; returns the best finalized hypothesis per row, or with
+        num_return_sequences = n the n best of every row ([B * n, len], best first)."""
         beams = num_beams > 1
+        if num_return_sequences != 1 and not beams:
+            raise ValueError("num_return_sequences > 1 without beams: repeat the rows (indextts/gpt/model.py does, as HF does)")
         nrow = np.asarray(text_ids).shape[0]
         if do_sample and not beams and (not top_k or int(top_k) < 1 or int(top_k) > 128):
             # HF: TopK warper off (top_k = 0 / None) or wider than the device sampler's 128 candidates - exact on the host
@@ -285,7 +293,8 @@ class Engine:
         if beams:
             if uniforms is None and do_sample:
                 uniforms = np.random.default_rng(seed).random((max_gen, nrow, 2 * num_beams), dtype=np.float32)
-            self.set_beam_sample(num_beams, top_k, top_p, temperature, uniforms, do_sample=do_sample, length_penalty=length_penalty)
+            self.set_beam_sample(num_beams, top_k, top_p, temperature, uniforms, do_sample=do_sample, length_penalty=length_penalty,
+                                 num_return_sequences=num_return_sequences)
         elif do_sample:
             if uniforms is None:
                 uniforms = np.random.default_rng(seed).random((max_gen, nrow), dtype=np.float32)

@@ -58,6 +58,7 @@ _lib = None
 _PROTOS = {
     "itts_last_error": (C.c_char_p, []),
     "itts_abi_version": (i32, []),
+    "itts_gpt_set_beam_returns": (i32, [vp, i32]),
     "itts_snake_aa_fwd": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "itts_gemm": (i32, [C.POINTER(GemmArgs), vp]),
     "itts_layernorm": (i32, [vp, i32, vp, i32, vp, vp, i32, i32, f32, vp]),

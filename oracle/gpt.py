@@ -374,12 +374,13 @@ def latent_forward(cond, text_tokens, codes, w: W, cfg_gpt):
 def beam_sample_generate(cond, text_inputs, w: W, cfg_gpt, max_generate_length: int, num_beams: int = 3, top_k: int = 30,
                          top_p: float = 0.8, temperature: float = 1.0, repetition_penalty: float = 10.0,
                          length_penalty: float = 0.0, uniforms=None, trace: Optional[dict] = None, typical_mass: float = 0.0,
-                         do_sample: bool = True):
+                         do_sample: bool = True, num_return_sequences: int = 1):
     """UnifiedVoice.inference_speech under the reference's DEFAULT kwargs (infer.py:116-124: do_sample=True, num_beams=3,
     top_k=30, top_p=0.8, length_penalty=0.0, repetition_penalty=10.0): HF 4.36.2 GenerationMixin.beam_sample +
     BeamSearchScorer, restated in oracle/hf_beam.py, over this module's GPT-2 stack with the KV cache re-ordered by
     beam_idx every step (GPT2InferenceModel._reorder_cache, model.py:194-207).  uniforms [max_gen, b, 2*num_beams] are
-    the draws.  Returns codes [b, <= max_generate_length] (prefix stripped, model.py:704-705)."""
+    the draws.  Returns codes [b * num_return_sequences, <= max_generate_length] (prefix stripped, model.py:704-705;
+    num_return_sequences = BeamSearchScorer's num_beam_hyps_to_keep, model.py:655,698-703: the n best per text row)."""
     import numpy as np
 
     from . import hf_beam
@@ -397,7 +398,8 @@ def beam_sample_generate(cond, text_inputs, w: W, cfg_gpt, max_generate_length: 
     emb = torch.cat([prefix, mel_emb[ids[:, s:]] + mel_pos[:1]], dim=1)
     h, past = gpt2_stack(emb, w, cfg_gpt, key_mask=mask)
     prompt_len = s + 1
-    scorer = hf_beam.BeamSearchScorer(b, nb, length_penalty=length_penalty, max_length=prompt_len + max_generate_length)
+    scorer = hf_beam.BeamSearchScorer(b, nb, length_penalty=length_penalty, max_length=prompt_len + max_generate_length,
+                                      num_beam_hyps_to_keep=num_return_sequences)
     beam_scores = np.zeros(b * nb, dtype=np.float32)
     if not do_sample:  # beam_search: `beam_scores[:, 1:] = -1e9`, so that step 0 expands beam 0 only
         beam_scores.reshape(b, nb)[:, 1:] = -1e9

@@ -56,10 +56,13 @@ class BeamHypotheses:
 
 
 class BeamSearchScorer:
-    """beam_search.py BeamSearchScorer (4.36.2), one beam group, num_beam_hyps_to_keep = 1."""
+    """beam_search.py BeamSearchScorer (4.36.2), one beam group; num_beam_hyps_to_keep = generate()'s num_return_sequences."""
 
-    def __init__(self, batch_size: int, num_beams: int, length_penalty: float = 1.0, max_length: Optional[int] = None):
-        self.num_beams, self.max_length = num_beams, max_length
+    def __init__(self, batch_size: int, num_beams: int, length_penalty: float = 1.0, max_length: Optional[int] = None,
+                 num_beam_hyps_to_keep: int = 1):
+        if not 1 <= num_beam_hyps_to_keep <= num_beams:
+            raise ValueError("`num_return_sequences` has to be smaller or equal to `num_beams`.")
+        self.num_beams, self.max_length, self.keep = num_beams, max_length, num_beam_hyps_to_keep
         self.hyps = [BeamHypotheses(num_beams, length_penalty) for _ in range(batch_size)]
         self.done = [False] * batch_size
 
@@ -109,7 +112,8 @@ class BeamSearchScorer:
         best = []
         for h in self.hyps:
             srt = sorted(h.beams, key=lambda x: x[0])  # stable: the later of two equal scores is popped
-            best.append(srt.pop()[1])
+            for _ in range(self.keep):  # rows keep * b .. keep * b + keep - 1: descending score
+                best.append(srt.pop()[1])
         lens = np.asarray([len(x) for x in best])
         smax = int(lens.max()) + 1
         if self.max_length is not None:

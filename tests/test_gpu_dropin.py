@@ -326,6 +326,16 @@ def test_num_return_sequences_sampling(tts):
     assert torch.equal(out, one)  # = the expanded batch, row order item0 x 3, item1 x 3
     with pytest.raises(ValueError):
         tts.gpt.inference_speech(mel, t, do_sample=False, num_beams=1, num_return_sequences=2, max_generate_length=4)
+    # beams: the n best hypotheses per row (BeamSearchScorer num_beam_hyps_to_keep), row 0 of each item = the single best
+    kw = dict(do_sample=False, num_beams=3, repetition_penalty=10.0, length_penalty=0.0, max_generate_length=12)
+    best = tts.gpt.inference_speech(mel, t, **kw).cpu().numpy()
+    nbest = tts.gpt.inference_speech(mel, t, num_return_sequences=3, **kw).cpu().numpy()
+    assert nbest.shape[0] == 6
+    for b in range(2):
+        m = min(best.shape[1], nbest.shape[1])
+        assert np.array_equal(nbest[3 * b][:m], best[b][:m])
+    with pytest.raises(ValueError, match="num_return_sequences"):
+        tts.gpt.inference_speech(mel, t, num_return_sequences=4, **kw)
 
 
 def test_batched_prompts_with_lengths_match_reference(tts, gold):

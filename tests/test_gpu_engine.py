@@ -312,6 +312,33 @@ def test_beam_sample_matches_oracle_more_rows_fp32(eng32, gold):
         assert got.shape == want.shape and np.array_equal(got, want), (nb, got, want)
 
 
+@pytest.mark.parametrize("nb,nret,sample", [(3, 2, True), (3, 3, True), (4, 2, False)])
+def test_beam_n_best_matches_oracle_fp32(eng32, gold, nb, nret, sample):
+    """generate()'s num_return_sequences under beams (model.py:655,698-703 -> BeamSearchScorer num_beam_hyps_to_keep): the n
+    best hypotheses of every text row, best first, against the oracle; n > num_beams is HF's error."""
+    c = gold("micro_conditioning")
+    cond = torch.from_numpy(c["cond"])
+    wg = ogpt.to_torch(synth.gpt_state_dict(CFG, 1234))
+    txt = np.stack([synth.text_ids(9, 400 + i, CFG.gpt.number_text_tokens) for i in range(2)]).astype(np.int32)
+    n = 18
+    u = np.random.default_rng(nb + nret).random((n, 2, 2 * nb), dtype=np.float32)
+    got = eng32.generate(cond, txt, n, do_sample=sample, num_beams=nb, top_k=30, top_p=0.8, temperature=1.0, uniforms=u,
+                         num_return_sequences=nret)
+    with torch.no_grad():
+        want = ogpt.beam_sample_generate(cond, torch.from_numpy(txt).long(), wg, CFG.gpt, n, num_beams=nb, top_k=30, top_p=0.8,
+                                         temperature=1.0, uniforms=u, do_sample=sample, num_return_sequences=nret).numpy()
+    assert got.shape[0] == 2 * nret
+    m = min(got.shape[1], want.shape[1])
+    stop = CFG.gpt.stop_mel_token
+    assert np.array_equal(got[:, :m], want[:, :m]) and (got[:, m:] == stop).all() and (want[:, m:] == stop).all(), (got, want)
+    # the next generation is single-best again
+    one = eng32.generate(cond, txt, n, do_sample=sample, num_beams=nb, top_k=30, top_p=0.8, temperature=1.0, uniforms=u)
+    assert one.shape[0] == 2 and np.array_equal(one[:, :m][0], got[0, :one.shape[1]][:m])
+    with pytest.raises(RuntimeError, match="num_return_sequences"):
+        eng32.generate(cond, txt, n, do_sample=sample, num_beams=nb, top_k=30, top_p=0.8, temperature=1.0, uniforms=u,
+                       num_return_sequences=nb + 1)
+
+
 def test_beam_sample_bf16_runs_and_is_deterministic(eng16, gold):
     c, g = gold("micro_conditioning"), gold("micro_beam_a")
     cond = torch.from_numpy(c["cond"])

@@ -42,7 +42,7 @@ def test_bucket_sentences():
 
 def test_library_loads_and_exports_header_symbols():
     l = lib.load()
-    assert l.itts_abi_version() == 3
+    assert l.itts_abi_version() == 4
     hdr = open(os.path.join(os.path.dirname(__file__), "..", "include", "itts_hip.h")).read()
     declared = set(re.findall(r"\b(itts_[a-z0-9_]+)\s*\(", hdr))
     assert declared, "no declarations parsed"

@@ -114,6 +114,43 @@ def test_beam_hypotheses_bookkeeping():
     assert len(h) == 2
 
 
+def test_beam_scorer_keeps_n_best_in_descending_order():
+    """BeamSearchScorer.finalize with num_beam_hyps_to_keep = n (generate()'s num_return_sequences under beams): rows
+    n * b .. n * b + n - 1 are batch item b's hypotheses by descending score, the later insertion first on equal scores
+    (sorted() is stable and finalize pops from the end); n > num_beams is HF's ValueError."""
+    sc = hf_beam.BeamSearchScorer(2, 3, length_penalty=0.0, max_length=12, num_beam_hyps_to_keep=2)
+    for b, scores in enumerate(([-3.0, -1.0, -1.0], [-0.5, -4.0, -2.0])):
+        for j, s in enumerate(scores):
+            sc.hyps[b].add(np.full(4 + j, 10 * b + j), s, 1)
+    sc.done = [True, True]
+    out = sc.finalize(np.zeros((6, 3), dtype=np.int64), np.zeros(6, np.float32), pad=99, eos=98, prompt_len=3)
+    assert out.shape == (4, 7)
+    assert [int(r[0]) for r in out] == [2, 1, 10, 12]  # item 0: the two -1.0s, later first; item 1: -0.5 then -2.0
+    assert list(out[1][:7]) == [1] * 5 + [98, 99]
+    with pytest.raises(ValueError):
+        hf_beam.BeamSearchScorer(1, 3, num_beam_hyps_to_keep=4)
+
+
+def test_beam_generate_n_best_first_row_is_the_single_best(gold):
+    """num_return_sequences = 3 of 3 beams: row 0 of every item is what num_return_sequences = 1 returns (the reference
+    fixture micro_beam_a), all three rows differ."""
+    cfg = icfg.micro()
+    g = gold("micro_beam_a")
+    w = ogpt.to_torch(synth.gpt_state_dict(cfg, 1234))
+    mel = torch.from_numpy(synth.prompt_mel(61, seed=7))
+    with torch.no_grad():
+        cond = ogpt.get_conditioning(mel, w, cfg.gpt)
+        out = ogpt.beam_sample_generate(cond, torch.from_numpy(g["text"]).long(), w, cfg.gpt, int(g["max_gen"]), num_beams=3,
+                                        top_k=int(g["top_k"]), top_p=float(g["top_p"]), temperature=float(g["temperature"]),
+                                        uniforms=g["uniforms"], num_return_sequences=3).numpy()
+    B = g["text"].shape[0]
+    assert out.shape[0] == 3 * B
+    for b in range(B):
+        n = min(out.shape[1], g["codes"].shape[1])
+        assert np.array_equal(out[3 * b][:n], g["codes"][b][:n])
+        assert len({tuple(r) for r in out[3 * b:3 * b + 3]}) == 3
+
+
 @pytest.mark.parametrize("tag", ["a", "b", "c", "typical", "search3", "search5_lp", "sample5_lp"])
 def test_beam_sample_generate_matches_reference_fixture(gold, tag):
     """oracle.gpt.beam_sample_generate (own GPT-2 stack + own warper restatement) against the fixture produced by the
