@@ -161,6 +161,7 @@ struct DecodeState {
   int eng_force = 0;                     // debug bit 5: use the engine whatever ITTS_ENGINE / the default says
   int eng_failed = 0;                    // a hand-off timed out: launch path from then on
   int graph_eng = 0;
+  int graph_mode = 0;                    // last_mode of the captured step
   float typical_mass = 0.f, graph_typical = 0.f;  // TypicalLogitsWarper pre-pass (0 = off)
   float* scores2 = nullptr;                        // [cap_B][V] its output
   int* forced = nullptr;  // [cap_B][cap_gen] forced token per (row, step) or -1; allocated with ids

@@ -745,6 +745,7 @@ int Engine::decode_step_launch(hipStream_t s) {
     ea.ctx_delay = e_cd;
     ea.act_delay = e_ad;
     ea.pass_sleep = e_ps;
+    if (const char* tt = getenv("ITTS_ENGINE_TIMEOUT_TICKS")) ea.timeout_ticks = (unsigned)atol(tt);  // tests: force the give-up path (read per call)
     static const bool e_stamps = getenv("ITTS_ENGINE_STAMPS") != nullptr;
     if (debug && e_stamps && !dry) ea.stamp = (unsigned*)ds.logits + 0;  // [16][V] fp32 scratch >= 256 * 24 * 16 words; the head overwrites it later
     ds.last_mode = eng_first > 0;
@@ -1092,6 +1093,7 @@ int Engine::gpt_decode(int nsteps, hipStream_t s) {
       d.graph_host_sample = d.host_sample;
       d.graph_fuse = d.fuse && !d.fuse_failed;
       d.graph_eng = (int)engine_usable();
+      d.graph_mode = d.last_mode;  // what the captured step runs on
       d.graph_nb = d.nb;
       d.graph_beam_sample = d.beam_sample;
       d.graph_length_penalty = d.length_penalty;
@@ -1103,6 +1105,7 @@ int Engine::gpt_decode(int nsteps, hipStream_t s) {
       d.graph_top_p = d.top_p;
       d.graph_temperature = d.temperature;
     }
+    d.last_mode = d.graph_mode;  // a replayed graph: the mode it was captured with
     int left = nsteps;
     if (d.graphK)
       for (; left >= GK; left -= GK) ITTS_HIP_CHECK(hipGraphLaunch(d.graphK, s));

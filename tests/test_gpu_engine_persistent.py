@@ -100,6 +100,26 @@ def test_engine_status_reports_no_timeout(eng16, cond):
     assert codes.shape[0] == 1 and codes.shape[1] >= 1
 
 
+def test_engine_timeout_is_reported_and_the_launch_path_takes_over(cond, monkeypatch):
+    """Failure detection: every in-launch wait is bounded by a wall clock (20 ms).  With the bound forced to 10 ns every
+    hand-off gives up, the launch drains, the abort word is set: status() / fetch() raise, the engine object disables its
+    persistent engine and the next generation runs on the five-launches-per-block path with the right ids."""
+    eng = ieng.build_engine(CFG, "bf16", parts=("gpt",))
+    text = synth.text_ids(105, 61, CFG.gpt.number_text_tokens).reshape(1, -1).astype(np.int32)
+    eng.debug(no_engine=True)
+    want = eng.generate(cond, text, 12, suppress_stop=True)
+    monkeypatch.setenv("ITTS_ENGINE_TIMEOUT_TICKS", "1")
+    eng.debug(engine=True, no_graph=True)
+    with pytest.raises(RuntimeError, match="hand-off timed out"):
+        eng.generate(cond, text, 12, suppress_stop=True)
+    monkeypatch.delenv("ITTS_ENGINE_TIMEOUT_TICKS")
+    eng.debug(engine=True)
+    got = eng.generate(cond, text, 12, suppress_stop=True)
+    assert eng.decode_mode() == 0  # disabled for this engine object after the failure
+    assert np.array_equal(got, want)
+    eng.debug()
+
+
 def test_launch_path_eager_full_length_equals_graph(eng16, cond):
     """The 122-launches-per-step path at the bench's full length WITHOUT graph capture (58 k eager launches: the run the
     r02 rocprofv3 --pmc pass died in) against its graph replay: same ids, same logits - the eager path's scratch / state
