@@ -30,8 +30,8 @@ struct EngArgs {
   int NL = 0, B = 0, Smax = 0;
   float scale = 0.125f, eps = 1e-5f;
   unsigned timeout_ticks = 2000000;   // wall-clock bound of every wait, 100 MHz ticks (20 ms)
-  int first_delay = 22, pass_sleep = 1; // gather pacing (s_sleep units of 64 clocks): before the first pass / between passes
-  int ctx_delay = 0, act_delay = 20;  // the same for the context edge behind its sentinel poll / the gelu(fc) edge
+  int first_delay = 14, pass_sleep = 1; // gather pacing (s_sleep units of 64 clocks): before the first pass / between passes
+  int ctx_delay = 0, act_delay = 16;  // the same for the context edge behind its sentinel poll / the gelu(fc) edge
   // head inside the launch (null head_w: the last block writes h and the head GEMV is its own launch)
   const bf16_t* head_w = nullptr;     // mel_head [V][D] (final_norm's affine folded in)
   const float* head_b = nullptr;      // [V]

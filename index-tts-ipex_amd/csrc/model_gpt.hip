@@ -735,13 +735,18 @@ int Engine::decode_step_launch(hipStream_t s) {
       ea.dbg = ds.act;  // [16][4D] fp32 scratch of the launch path, unused by the engine: room for the 9 B D floats of the dump
       ea.dbg_layer = e_tap;
     }
-    static const int e_fd = getenv("ITTS_ENGINE_FIRST_DELAY") ? atoi(getenv("ITTS_ENGINE_FIRST_DELAY")) : 22;  // tools: 0.65 us - a publish needs that long to become visible; earlier passes fail AND slow the stores down (sweep in DESIGN.md)
+    // gather pacing (s_sleep units of 64 clocks): a publish needs ~0.4 us to become visible; earlier passes fail AND slow the
+    // stores down.  Defaults from tools/eng_pacing_rows.sh (profiles/r03_engine_pacing_sweep.txt): 14 / 16 at <= 2 rows, 12 / 8
+    // at 3 - 4 rows (more granules per pass: the first pass itself takes longer)
+    static const int e_fd_env = getenv("ITTS_ENGINE_FIRST_DELAY") ? atoi(getenv("ITTS_ENGINE_FIRST_DELAY")) : -1;
+    static const int e_ad_env = getenv("ITTS_ENGINE_ACT_DELAY") ? atoi(getenv("ITTS_ENGINE_ACT_DELAY")) : -1;
+    const int e_fd = e_fd_env >= 0 ? e_fd_env : (B <= 2 ? 14 : 12);
+    const int e_ad = e_ad_env >= 0 ? e_ad_env : (B <= 2 ? 16 : 8);
     static const int e_ps = getenv("ITTS_ENGINE_PASS_SLEEP") ? atoi(getenv("ITTS_ENGINE_PASS_SLEEP")) : 1;
     static const int e_thin = getenv("ITTS_ENGINE_THIN_FC") ? atoi(getenv("ITTS_ENGINE_THIN_FC")) : 0;
     ea.thin_fc = e_thin;
     ea.first_delay = e_fd;
     static const int e_cd = getenv("ITTS_ENGINE_CTX_DELAY") ? atoi(getenv("ITTS_ENGINE_CTX_DELAY")) : 0;
-    static const int e_ad = getenv("ITTS_ENGINE_ACT_DELAY") ? atoi(getenv("ITTS_ENGINE_ACT_DELAY")) : 20;
     ea.ctx_delay = e_cd;
     ea.act_delay = e_ad;
     ea.pass_sleep = e_ps;
