@@ -326,7 +326,8 @@ def measure(eng, cfg, a, BU, steps, warmup, rank, world, product_loop=False):
                                 (BU, NS, L, T, a.prompt_frames, ("sample" if a.sample else "greedy") if a.beams == 1 else "beam-sample x%d" % a.beams)
                                 + (", product loop (status() every 16 steps)" if product_loop else "")),
                    "utterances_per_gpu": BU, "decode_batch": B * a.beams, "audio_sec_per_step_per_gpu": round(audio_s / steps / world, 3)},
-        "roofline": {"bound": "hbm", "kernel": ("gpt decode step (hipGraph: persistent decode engine - ONE launch for the 24 blocks - + head gemv + sampler)"
+        "roofline": {"bound": "hbm", "kernel": (("gpt decode step = decode_engine_kernel: ONE persistent launch for the 24 blocks, the head and the greedy sampler" if a.beams == 1 and not a.sample else
+                                                 "gpt decode step (hipGraph: decode_engine_kernel - ONE persistent launch for the 24 blocks + head - then the sampler kernels)")
                                                 if eng.decode_mode() == 1 else
                                                 "gpt decode step (hipGraph: 97 gemv + 24 cache-attention + sampler)" if B <= 4 else
                                                 "gpt decode step (hipGraph: 97 skinny MFMA gemm + 49 layernorm + 24 cache-attention + sampler)"),

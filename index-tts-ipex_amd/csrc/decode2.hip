@@ -7,6 +7,7 @@
 #include <cstdlib>
 
 #include "itts_decode.h"
+#include "itts_sampler_dev.h"
 #include "decode_pinned.h"
 
 namespace itts {
@@ -1523,42 +1524,6 @@ __global__ __launch_bounds__(256) void qkv_attn_fused_kernel(FusedQkvAttn f) {
   }
 }
 
-// bookkeeping shared by the greedy and the sampling kernels (thread 0 of the row's block)
-__device__ __forceinline__ void sampler_commit(const SamplerArgs& a, int b, int choice, int* si, int k, int unf) {
-  si[1] = -1;
-  if (k < a.max_gen) {  // graph replays past the end are no-ops
-    if (a.forced) {
-      const int f = a.forced[(size_t)b * a.max_gen + k];
-      choice = f >= 0 ? f : choice;
-    }
-    const int tok = unf ? choice : a.stop;
-    a.ids[(size_t)b * a.max_gen + k] = tok;
-    a.cur_tok[b] = tok;
-    a.seen[(size_t)b * a.V + tok] = 1;
-    a.unfinished[b] = unf && tok != a.stop;
-    a.step[b] = k + 1;
-    si[0] = tok;
-    // position of the token fed at the next step: 0, 2, 3, ... (model.py:153-155); a given `input_tokens` token k was part of
-    // the reference's first forward, at position k + 1 (model.py:141-144)
-    si[1] = k < a.input_n ? k + 1 : k + 2;
-  }
-}
-
-// next step's input row h[b] = mel_emb[tok] + mel_pos[k + 2], fused here (one launch less per token)
-__device__ __forceinline__ void sampler_next_embedding(const SamplerArgs& a, int b, const int* si, int tid) {
-  if (a.h_next && si[1] > 0) {
-    const int tok = si[0], p = min(si[1], a.pos_rows - 1);
-    for (int i = tid; i < a.D; i += 1024) {
-      float v;
-      if (a.emb_bf16)
-        v = (float)((const bf16_t*)a.emb)[(size_t)tok * a.D + i] + (float)((const bf16_t*)a.pos)[(size_t)p * a.D + i];
-      else
-        v = ((const float*)a.emb)[(size_t)tok * a.D + i] + ((const float*)a.pos)[(size_t)p * a.D + i];
-      a.h_next[(size_t)b * a.D + i] = v;
-    }
-  }
-}
-
 // ---------------------------------------------------------------------------------------------
 // sampler2: repetition penalty + argmax + bookkeeping, one 1024-thread block per row; the per-row length
 // counter is advanced by the row's own block (no cross-block step counter, no extra launch).
@@ -1578,12 +1543,7 @@ __global__ __launch_bounds__(1024) void sampler2_kernel(SamplerArgs a) {
       bi = i;
     }
   };
-  auto score = [&](float v, int i) {
-    if (a.preprocessed) return v;
-    if (a.penalty != 1.f && seen[i]) v = v < 0.f ? v * a.penalty : v / a.penalty;
-    if (a.suppress_stop && i == a.stop) v = -INFINITY;
-    return v;
-  };
+  auto score = [&](float v, int i) { return sampler_score(a, seen, v, i); };
   // 8 consecutive logits per thread as two 16-byte loads (rows are dword aligned), the tail scalar
   const int nvec = a.V >> 3;
   for (int c = tid; c < nvec; c += 1024) {

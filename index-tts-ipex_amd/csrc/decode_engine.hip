@@ -31,6 +31,7 @@
 
 #include "itts_decode.h"
 #include "itts_engine_kernel.h"
+#include "itts_sampler_dev.h"
 #include "decode_pinned.h"
 
 namespace itts {
@@ -975,6 +976,106 @@ __global__ __launch_bounds__(1024) void decode_engine_kernel(EngArgs a) {
         const float bias = r == 0 ? bh[0] : (r == 1 ? bh[1] : bh[2]);
         if (n >= 0) a.logits[(size_t)b * a.V + n] = mine + bias;
       }
+      if (a.fold_sampler && ll < 3 * NB) {  // this lane's candidate of row b: penalty / stop suppression as sampler2_kernel
+        const int r = ll / NB, b = ll % NB;
+        const int n = r == 0 ? hn_[0] : (r == 1 ? hn_[1] : hn_[2]);
+        const float bias = r == 0 ? bh[0] : (r == 1 ? bh[1] : bh[2]);
+        float* cv = so;                                      // [NB][36] candidate scores (the attention scratch is idle)
+        int* ci = reinterpret_cast<int*>(so + 4 * 36);       // [NB][36] ids
+        cv[b * 36 + cw * 3 + r] = n >= 0 ? sampler_score(a.samp, a.samp.seen + (size_t)b * a.V, mine + bias, n) : -INFINITY;
+        ci[b * 36 + cw * 3 + r] = n >= 0 ? n : 0x7fffffff;
+      }
+    }
+    if (a.fold_sampler) {
+      // ---- greedy sampler: arg-max over the vocabulary = over every workgroup's best (larger score, lower id on ties:
+      //      the rule of sampler2_kernel, independent of the reduction order) ----
+      const float* cv = so;
+      const int* ci = reinterpret_cast<const int*>(so + 4 * 36);
+      __syncthreads();
+      if (tl < NB) {
+        float best = -INFINITY;
+        int bi = 0x7fffffff;
+        for (int q = 0; q < 3 * NCW; ++q) {
+          const float v = cv[tl * 36 + q];
+          const int i = ci[tl * 36 + q];
+          if (v > best || (v == best && i < bi)) {
+            best = v;
+            bi = i;
+          }
+        }
+        st_gran(a.cand + ((size_t)tl * NCU + cu) * 2, rt.tag, __float_as_uint(best));
+        st_gran(a.cand + ((size_t)tl * NCU + cu) * 2 + 1, rt.tag, (uint32_t)bi);
+      }
+      if (cu < NB) {  // workgroup b finishes row b
+        const int b = cu;
+        const int k_pre = a.samp.step[b], unf_pre = a.samp.unfinished[b];
+        float* sv = red;                                  // [4] wave bests
+        int* si = reinterpret_cast<int*>(red + 8);        // [4] ... and, afterwards, [0] token [1] next position
+        float best = -INFINITY;
+        int bi = 0x7fffffff;
+        if (gw) {  // thread tl: the candidate of workgroup tl
+          const u64* p = a.cand + ((size_t)b * NCU + tl) * 2;
+          unsigned spins = 0;
+          bool have_v = false, have_i = false;
+          while (!rt.dead && !(have_v && have_i)) {
+            const u64 x = ld_gran1(p), y = ld_gran1(p + 1);
+            if ((unsigned)(x >> 32) == rt.tag) {
+              best = __uint_as_float((uint32_t)x);
+              have_v = true;
+            }
+            if ((unsigned)(y >> 32) == rt.tag) {
+              bi = (int)(uint32_t)y;
+              have_i = true;
+            }
+            if (have_v && have_i) break;
+            if (spin_fail(rt, spins)) break;
+            __builtin_amdgcn_s_sleep(1);
+          }
+          if (!(have_v && have_i)) {
+            best = -INFINITY;
+            bi = 0x7fffffff;
+          }
+          auto merge = [&](float ov, int oi) {
+            if (ov > best || (ov == best && oi < bi)) {
+              best = ov;
+              bi = oi;
+            }
+          };
+#define ENG_ARGMAX_DPP(CTRL)                                                                          \
+  merge(__int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(best), CTRL, 0xf, 0xf, true)),  \
+        __builtin_amdgcn_update_dpp(0, bi, CTRL, 0xf, 0xf, true))
+          ENG_ARGMAX_DPP(0xB1);
+          ENG_ARGMAX_DPP(0x4E);
+          ENG_ARGMAX_DPP(0x141);
+          ENG_ARGMAX_DPP(0x140);
+#undef ENG_ARGMAX_DPP
+          const u32x2 v16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(best), __float_as_uint(best), false, false);
+          const u32x2 i16 = __builtin_amdgcn_permlane16_swap((unsigned)bi, (unsigned)bi, false, false);
+          best = __uint_as_float(v16[0]);
+          bi = (int)i16[0];
+          merge(__uint_as_float(v16[1]), (int)i16[1]);
+          const u32x2 v32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(best), __float_as_uint(best), false, false);
+          const u32x2 i32 = __builtin_amdgcn_permlane32_swap((unsigned)bi, (unsigned)bi, false, false);
+          best = __uint_as_float(v32[0]);
+          bi = (int)i32[0];
+          merge(__uint_as_float(v32[1]), (int)i32[1]);
+          if (ll == 0) {
+            sv[wave] = best;
+            si[wave] = bi;
+          }
+        }
+        __syncthreads();
+        if (t == 0) {
+          for (int w = 1; w < 4; ++w)
+            if (sv[w] > best || (sv[w] == best && si[w] < bi)) {
+              best = sv[w];
+              bi = si[w];
+            }
+          sampler_commit(a.samp, b, bi, si, k_pre, unf_pre);
+        }
+        __syncthreads();
+        sampler_next_embedding(a.samp, b, si, t);
+      }
     }
   }
   // advance the step counter (never 0): every workgroup read it before its first publish, and this workgroup got here
@@ -988,7 +1089,7 @@ __global__ __launch_bounds__(1024) void decode_engine_kernel(EngArgs a) {
 
 }  // namespace
 
-size_t eng_gran_count(int layers) { return (size_t)layers * 4 * ENG_D * 15 / 2; }
+size_t eng_gran_count(int layers) { return (size_t)layers * 4 * ENG_D * 15 / 2 + ENG_CAND_WORDS; }
 
 int decode_engine_layers(const EngArgs& a, hipStream_t s) {
   ITTS_REQUIRE(a.B >= 1 && a.B <= ENG_MAX_ROWS && a.NL >= 1 && a.NL <= ENG_MAX_LAYERS && a.gran && a.h && a.kc && a.vc && a.ctr, "decode_engine: bad arguments");

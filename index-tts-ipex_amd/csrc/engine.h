@@ -261,8 +261,9 @@ struct Engine {
   bool engine_usable() const;
   int ensure_engine_state(hipStream_t s);
   int engine_check(hipStream_t s);
-  int head_and_sample(hipStream_t s, bool have_logits = false);
-  int sample_from_logits(hipStream_t s);
+  int head_and_sample(hipStream_t s, bool have_logits = false, bool sampled = false);
+  int sample_from_logits(hipStream_t s, bool sampled = false);
+  SamplerArgs greedy_sampler_args(const float* lg_in, bool typical) const;
   int ensure_decode_state(int B, int Smax, int max_gen, hipStream_t s);
   template <typename F>
   int two_pass(F&& body, hipStream_t s) {

@@ -1,6 +1,7 @@
 // Persistent decode engine (decode_engine.hip): one launch for the 24 GPT-2 blocks of a token step, decode batches <= 4.
 #pragma once
 #include "itts_common.h"
+#include "itts_decode.h"
 
 namespace itts {
 
@@ -39,13 +40,19 @@ struct EngArgs {
   const float* lnf_b = nullptr;
   float* logits = nullptr;            // [B][V]
   int V = 0;
+  // greedy sampler inside the launch (needs the head inside it): every workgroup publishes its best (score, id) per row,
+  // workgroup b picks row b's token, does sampler2_kernel's bookkeeping and writes the next step's input embedding
+  int fold_sampler = 0;
+  SamplerArgs samp;
+  unsigned long long* cand = nullptr;  // [B][256][2] hand-off granules of the candidates (tail of the granule buffer)
   int thin_fc = 0;                    // the loader keeps at most 12 c_fc requests in flight (they run beside a gather)
   float* dbg = nullptr;               // debugging aid (ITTS_TAP_LAYER): qkv [B][3D], h1 [B][D], act [B][4D], h2 [B][D] of block dbg_layer
   int dbg_layer = -1;
   unsigned* stamp = nullptr;          // debugging aid (ITTS_ENGINE_STAMPS): [256][NL][12] wall-clock stamps (100 MHz) of one step
 };
 
-size_t eng_gran_count(int layers);  // 8-byte words of the granule buffer (sized for 4 rows)
+size_t eng_gran_count(int layers);  // 8-byte words of the granule buffer (sized for 4 rows; the last ENG_CAND_WORDS: sampler candidates)
+constexpr size_t ENG_CAND_WORDS = (size_t)ENG_MAX_ROWS * ENG_NCU * 2;
 int decode_engine_layers(const EngArgs& a, hipStream_t s);
 
 }  // namespace itts

@@ -539,10 +539,10 @@ int Engine::gpt_prefill(const float* cond_dev, const int32_t* text_ids_in, int B
 }
 
 // ln_f -> final_norm -> mel_head -> repetition penalty / argmax / bookkeeping (lm_head, model.py:48,180)
-int Engine::head_and_sample(hipStream_t s, bool have_logits) {
+int Engine::head_and_sample(hipStream_t s, bool have_logits, bool sampled) {
   const itts_config& c = cfg;
   const int D = c.model_dim, V = c.number_mel_codes, B = ds.B;
-  if (have_logits) return sample_from_logits(s);  // the persistent engine ran ln_f / final_norm / mel_head itself
+  if (have_logits) return sample_from_logits(s, sampled);  // the persistent engine ran ln_f / final_norm / mel_head itself
   GemvArgs g;
   g.W = gpt.head.w;
   g.Y = ds.logits;
@@ -586,10 +586,11 @@ int Engine::head_and_sample(hipStream_t s, bool have_logits) {
 }
 
 // repetition penalty / argmax or the sampling / beam modes / bookkeeping on ds.logits [B][V]
-int Engine::sample_from_logits(hipStream_t s) {
+int Engine::sample_from_logits(hipStream_t s, bool sampled) {
   const itts_config& c = cfg;
   const int D = c.model_dim, V = c.number_mel_codes, B = ds.B;
   ITTS_TRY(tap("logits0", ds.logits, F32, (int64_t)B * V, s));
+  if (sampled) return OK;  // the persistent engine's in-launch greedy sampler committed this step's tokens
   if (ds.host_sample) return OK;  // the caller reads the logits, picks the tokens and commits them (gpt_commit)
   const float* lg_in = ds.logits;
   const bool typical = ds.typical_mass > 0.f && (ds.do_sample || (ds.nb > 1 && ds.beam_sample));
@@ -663,6 +664,14 @@ int Engine::sample_from_logits(hipStream_t s) {
     ba.emb_bf16 = adt == BF16;
     return beam_sample_step(ba, s);
   }
+  SamplerArgs sa = greedy_sampler_args(lg_in, typical);
+  return sampler2_step(sa, B, s);
+}
+
+// arguments of the greedy / sampling kernels (sampler2_step) - also what the persistent engine's in-launch sampler runs on
+SamplerArgs Engine::greedy_sampler_args(const float* lg_in, bool typical) const {
+  const itts_config& c = cfg;
+  const int D = c.model_dim, V = c.number_mel_codes, B = ds.B;
   SamplerArgs sa;
   sa.logits = lg_in;
   sa.preprocessed = typical;
@@ -690,7 +699,7 @@ int Engine::sample_from_logits(hipStream_t s) {
   sa.forced = ds.use_forced ? ds.forced : nullptr;
   sa.input_n = ds.use_forced ? ds.input_n : 0;
   sa.B = B;
-  return sampler2_step(sa, B, s);
+  return sa;
 }
 
 // one decode step: 24 x {LN+QKV gemv, cache attention (+append), proj gemv (+res),
@@ -758,6 +767,15 @@ int Engine::decode_step_launch(hipStream_t s) {
     static const bool e_head = !(getenv("ITTS_ENGINE_HEAD") && atoi(getenv("ITTS_ENGINE_HEAD")) == 0);
     const bool fold_head = e_head && eng_first == c.layers && gpt.head.dt == BF16 && !gpt.head.w8 && gpt.head.b && gpt.head.Cin == ENG_D &&
                            gpt.ln_f.g && gpt.ln_f.b && (c.number_mel_codes + ENG_NCU - 1) / ENG_NCU <= 33;
+    // ... and the greedy sampler behind it (ITTS_ENGINE_SAMPLER=0: own launch): plain greedy search only - sampling, beams,
+    // typical filtering and host-side sampling keep their kernels
+    static const bool e_samp = !(getenv("ITTS_ENGINE_SAMPLER") && atoi(getenv("ITTS_ENGINE_SAMPLER")) == 0);
+    const bool fold_samp = fold_head && e_samp && !ds.do_sample && ds.nb == 1 && !ds.host_sample;
+    if (fold_samp) {
+      ea.fold_sampler = 1;
+      ea.samp = greedy_sampler_args(ds.logits, false);
+      ea.cand = ds.eng_gran + eng_gran_count(c.layers) - ENG_CAND_WORDS;
+    }
     if (fold_head) {
       ea.head_w = (const bf16_t*)gpt.head.w;
       ea.head_b = gpt.head.b;
@@ -774,7 +792,7 @@ int Engine::decode_step_launch(hipStream_t s) {
       ITTS_TRY(tap("eng_act", ea.dbg + (size_t)B * 4 * D, F32, (int64_t)B * 4 * D, s));
       ITTS_TRY(tap("eng_h2", ea.dbg + (size_t)B * 8 * D, F32, (int64_t)B * D, s));
     }
-    if (eng_first == c.layers) return head_and_sample(s, fold_head);
+    if (eng_first == c.layers) return head_and_sample(s, fold_head, fold_samp);
   }
   // 5-16 rows: the step is launch-bound, so the two LayerNorm launches of a layer fold into the projections they feed
   // (skinny_mfma_kernel<LNP>) and the residual projections run as half tiles without a K split (<HALF>): 5 launches a
