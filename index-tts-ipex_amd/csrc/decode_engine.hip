@@ -1084,6 +1084,10 @@ __global__ __launch_bounds__(1024) void decode_engine_kernel(EngArgs a) {
   if (a.stamp && t == 0) {  // shader clock over the launch: cycles per 10 ns tick, x 1000 (stamp 15 of block 0)
     const u64 c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
     a.stamp[(size_t)cu * a.NL * 16 + 15] = (unsigned)((c1 - clk0) * 1000 / (r1 - rt.t0 + 1));
+    if (a.NL >= 3) {  // wall clock at this workgroup's start / end (stamp 15 of blocks 1 / 2)
+      a.stamp[((size_t)cu * a.NL + 1) * 16 + 15] = (unsigned)rt.t0;
+      a.stamp[((size_t)cu * a.NL + 2) * 16 + 15] = (unsigned)r1;
+    }
   }
 }
 

@@ -761,7 +761,7 @@ int Engine::decode_step_launch(hipStream_t s) {
     ea.pass_sleep = e_ps;
     if (const char* tt = getenv("ITTS_ENGINE_TIMEOUT_TICKS")) ea.timeout_ticks = (unsigned)atol(tt);  // tests: force the give-up path (read per call)
     static const bool e_stamps = getenv("ITTS_ENGINE_STAMPS") != nullptr;
-    if (debug && e_stamps && !dry) ea.stamp = (unsigned*)ds.logits + 0;  // [16][V] fp32 scratch >= 256 * 24 * 16 words; the head overwrites it later
+    if (debug && e_stamps && !dry) ea.stamp = (unsigned*)ds.scores2;  // [16][V] fp32 scratch of the typical filter (off in this mode) >= 256 * 24 * 16 words
     ds.last_mode = eng_first > 0;
     // the head (ln_f -> final_norm -> mel_head) inside the same launch when the engine runs every block (ITTS_ENGINE_HEAD=0: own launch)
     static const bool e_head = !(getenv("ITTS_ENGINE_HEAD") && atoi(getenv("ITTS_ENGINE_HEAD")) == 0);

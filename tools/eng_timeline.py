@@ -44,6 +44,10 @@ for l in (1, NL // 2, NL - 2):
         if i in (2, 3):
             v = v[acu]
         print(f"   {names[i]:26s} min {v.min():6.2f}  median {np.median(v):6.2f}  max {v.max():6.2f}")
+k0, k1 = (st[:, 1, 15] - t0) / 100.0, (st[:, 2, 15] - t0) / 100.0
+print(f"-- launch: workgroups start {k0.min():.2f} .. {k0.max():.2f} us, first block's E1 gathered at 0 .. {us[:, 0, 0].max():.2f}; last h2 published "
+      f"{us[:, -1, 11].max():.2f}, workgroups end {k1.min():.2f} .. {k1.max():.2f} us (head + sampler: {k1.max() - us[:, -1, 11].max():.2f} us; "
+      f"whole launch {k1.max() - k0.min():.2f} us)")
 clk = st[:, 0, 15]
 print(f"shader clock over the launch: {np.median(clk) / 10.0:.0f} MHz (min {clk.min() / 10.0:.0f}, max {clk.max() / 10.0:.0f})")
 d = us[:, 2:NL - 1, :]
