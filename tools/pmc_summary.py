@@ -19,8 +19,10 @@ for k, v in sorted(tot.items(), key=lambda kv: -kv[1])[:25]:
     print(f"{k:62s} n={cnt[k]:6d} total={v:14.1f} per_launch={v / cnt[k]:12.2f}")
 # decode-step kernels only: gemv / cache attention / sampler launches of the per-token loop.  The prefill's head gemv
 # and sampler (one launch each) are excluded by counting per kernel: launches_per_step * steps.
+# (greedy steps of the persistent engine have no sampler launch - the sampler runs inside decode_engine_kernel: one launch a step)
+neng = max((c for k, c in cnt.items() if "decode_engine" in k), default=0)
 nsamp = max((c for k, c in cnt.items() if "sampler" in k), default=1)
-steps = max(nsamp - 1, 1)
+steps = neng if neng > nsamp else max(nsamp - 1, 1)
 dec = 0.0
 for k, v in tot.items():
     if "gemv" in k or "decode_attn" in k or "sampler" in k or "decode_engine" in k:
