@@ -242,6 +242,32 @@ __device__ __forceinline__ void dma_rows(const bf16_t* __restrict__ W, const flo
   }
   if (lane < ROWS) dma4(bias + n0 + lane, slot);
 }
+// rows [n0, n0 + ROWS) of W [N][K] -> compact rows at LDS address dst, no bias row (5 - 6 rows: c_attn arrives in two parts)
+template <int ROWS, int K>
+__device__ __forceinline__ void dma_rows_at(const bf16_t* __restrict__ W, int n0, unsigned dst0, int lane) {
+  constexpr int NF = (K + 511) / 512, TAIL = K - (NF - 1) * 512;
+  static_assert(TAIL == 512 || TAIL == 256, "whole or half last fragment");
+  for (int r = 0; r < ROWS; ++r) {
+    const bf16_t* src = W + (size_t)(n0 + r) * K + lane * 8;
+    const unsigned dst = dst0 + (unsigned)(r * K * 2);
+#pragma unroll
+    for (int c = 0; c < NF; ++c)
+      if (TAIL == 512 || c != NF - 1 || lane < 32) dma16(src + c * 512, dst + c * 1024);
+  }
+}
+// columns [K0, K0 + KN) of rows [n0, n0 + ROWS) of W [N][KTOT] -> compact rows of KN * 2 bytes (5 - 6 rows: mlp.c_proj comes
+// in two K halves, the second into slot A once c_fc has been read); the bias row travels with the first part
+template <int ROWS, int KTOT, int K0, int KN>
+__device__ __forceinline__ void dma_rows_part(const bf16_t* __restrict__ W, const float* __restrict__ bias, int n0, unsigned slot, int lane) {
+  static_assert(KN % 512 == 0 && K0 % 512 == 0, "whole fragments");
+  for (int r = 0; r < ROWS; ++r) {
+    const bf16_t* src = W + (size_t)(n0 + r) * KTOT + K0 + lane * 8;
+    const unsigned dst = slot + 256 + (unsigned)(r * KN * 2);
+#pragma unroll
+    for (int c = 0; c < KN / 512; ++c) dma16(src + c * 512, dst + c * 1024);
+  }
+  if (bias && lane < ROWS) dma4(bias + n0 + lane, slot);
+}
 // the loader waits until at most N of its requests are outstanding: everything older has landed in LDS (vmcnt is in-order)
 template <int N>
 __device__ __forceinline__ void dma_wait_keep() {
@@ -267,6 +293,23 @@ __device__ __forceinline__ void dots(const unsigned char* __restrict__ wrow, con
       if (c == NCH - 1)
 #pragma unroll
         for (int e = 0; e < 4; ++e) xq[e] = kok ? xq[e] : 0u;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[b] = dot2(w[e], xq[e], acc[b]);
+    }
+  }
+}
+
+// the same over fragments [C0, C0 + NC) of a K = KTOT row whose part lies compact at wpart (whole fragments only)
+template <int NB, int KTOT, int C0, int NC>
+__device__ __forceinline__ void dots_part(const unsigned char* __restrict__ wpart, const uint32_t* __restrict__ sxb, int lane,
+                                          float (&acc)[NB]) {
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    const int k = (C0 + c) * 512 + lane * 8;
+    const u32x4 w = *reinterpret_cast<const u32x4*>(wpart + c * 1024 + lane * 16);
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      const u32x4 xq = *reinterpret_cast<const u32x4*>(sxb + (b * KTOT + k) / 2);
 #pragma unroll
       for (int e = 0; e < 4; ++e) acc[b] = dot2(w[e], xq[e], acc[b]);
     }
@@ -349,21 +392,31 @@ __device__ __forceinline__ void ln_row_store(const LnRow<K>& r, uint32_t* __rest
 __device__ __forceinline__ int ln_row_of(int nb, int q) {
   return q == 0 ? 0 : q == 3 ? (nb == 2 ? 1 : nb >= 3 ? 2 : -1) : q == 2 ? (nb >= 3 ? 1 : -1) : (nb == 4 ? 3 : -1);
 }
-// all 1024 threads call this (two workgroup barriers inside); red: [2 passes][4 rows][4][2] floats
+// all 1024 threads call this (two workgroup barriers inside); red: [2 passes][4 or 8 rows][4][2] floats.  5 - 6 rows: a wave
+// group takes a second row (rows 4, 5) between the same two barriers.
 template <int NB, int K>
 __device__ __forceinline__ void ln_to_sxb(const float* __restrict__ xf, uint32_t* __restrict__ sxb, float* __restrict__ red, int t,
                                           float eps) {
-  const int grp = ln_row_of(NB, t >> 8);  // which row this thread works on (-1: none)
+  const int grp = ln_row_of(NB < 4 ? NB : 4, t >> 8);  // which row this thread works on (-1: none)
+  const int grp2 = NB > 4 ? (ln_row_of(NB - 4, t >> 8) < 0 ? -1 : ln_row_of(NB - 4, t >> 8) + 4) : -1;
   const int tr = t & 255;
-  LnRow<K> r;
+  LnRow<K> r, r2;
   if (grp >= 0) {
     ln_row_load<K>(xf + grp * K, tr, r);
     ln_row_moments<K>(r, r.pivot, red + grp * 8, tr);
+  }
+  if (NB > 4 && grp2 >= 0) {
+    ln_row_load<K>(xf + grp2 * K, tr, r2);
+    ln_row_moments<K>(r2, r2.pivot, red + grp2 * 8, tr);
   }
   __syncthreads();
   if (grp >= 0) {
     ln_row_norm<K>(r, r.pivot, red + grp * 8, eps);
     ln_row_store<K>(r, sxb + grp * (K / 2), tr);
+  }
+  if (NB > 4 && grp2 >= 0) {
+    ln_row_norm<K>(r2, r2.pivot, red + grp2 * 8, eps);
+    ln_row_store<K>(r2, sxb + grp2 * (K / 2), tr);
   }
   __syncthreads();
 }
@@ -371,19 +424,27 @@ __device__ __forceinline__ void ln_to_sxb(const float* __restrict__ xf, uint32_t
 template <int NB, int K>
 __device__ __forceinline__ void ln2_to_sxb(const float* __restrict__ xf, uint32_t* __restrict__ sxb, float* __restrict__ red, int t,
                                            float eps, const float* __restrict__ gamma, const float* __restrict__ beta) {
-  const int grp = ln_row_of(NB, t >> 8);
+  const int grp = ln_row_of(NB < 4 ? NB : 4, t >> 8);
+  const int grp2 = NB > 4 ? (ln_row_of(NB - 4, t >> 8) < 0 ? -1 : ln_row_of(NB - 4, t >> 8) + 4) : -1;
+  constexpr int RED2 = NB > 4 ? 64 : 32;  // second pass's sums
   const int tr = t & 255;
-  LnRow<K> r;
+  LnRow<K> r, r2;
   f32x4 gm[2], bt[2];
-  if (grp >= 0) {
-    ln_row_load<K>(xf + grp * K, tr, r);
+  if (grp >= 0 || (NB > 4 && grp2 >= 0)) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      const int ic = r.xok[j] ? (tr + j * 256) * 4 : K - 4;
+      const int ic = (tr + j * 256) * 4 < K ? (tr + j * 256) * 4 : K - 4;
       gm[j] = *reinterpret_cast<const f32x4*>(gamma + ic);
       bt[j] = *reinterpret_cast<const f32x4*>(beta + ic);
     }
+  }
+  if (grp >= 0) {
+    ln_row_load<K>(xf + grp * K, tr, r);
     ln_row_moments<K>(r, r.pivot, red + grp * 8, tr);
+  }
+  if (NB > 4 && grp2 >= 0) {
+    ln_row_load<K>(xf + grp2 * K, tr, r2);
+    ln_row_moments<K>(r2, r2.pivot, red + grp2 * 8, tr);
   }
   __syncthreads();
   if (grp >= 0) {
@@ -392,12 +453,24 @@ __device__ __forceinline__ void ln2_to_sxb(const float* __restrict__ xf, uint32_
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int e = 0; e < 4; ++e) r.xv[j][e] = ln_affine_rn(r.xv[j][e], gm[j][e], bt[j][e]);
-    ln_row_moments<K>(r, 0.f, red + 32 + grp * 8, tr);
+    ln_row_moments<K>(r, 0.f, red + RED2 + grp * 8, tr);
+  }
+  if (NB > 4 && grp2 >= 0) {
+    ln_row_norm<K>(r2, r2.pivot, red + grp2 * 8, eps);
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) r2.xv[j][e] = ln_affine_rn(r2.xv[j][e], gm[j][e], bt[j][e]);
+    ln_row_moments<K>(r2, 0.f, red + RED2 + grp2 * 8, tr);
   }
   __syncthreads();
   if (grp >= 0) {
-    ln_row_norm<K>(r, 0.f, red + 32 + grp * 8, eps);
+    ln_row_norm<K>(r, 0.f, red + RED2 + grp * 8, eps);
     ln_row_store<K>(r, sxb + grp * (K / 2), tr);
+  }
+  if (NB > 4 && grp2 >= 0) {
+    ln_row_norm<K>(r2, 0.f, red + RED2 + grp2 * 8, eps);
+    ln_row_store<K>(r2, sxb + grp2 * (K / 2), tr);
   }
   __syncthreads();
 }
@@ -428,20 +501,30 @@ __global__ __launch_bounds__(1024) void decode_engine_kernel(EngArgs a) {
   constexpr unsigned SLOTC = 256 + HO * D * 2;
   static_assert(SLOT >= 256 + QO * D * 2 && SLOT >= 256 + HO * 4 * D * 2, "slot size");
   constexpr bool SLOT3 = NB <= 2;
+  // 5 - 6 rows: slot B holds HALF of mlp.c_proj (the first 2560 columns of its 5 rows, requested behind the second LayerNorm);
+  // the second half goes into slot A once every compute wave is through c_fc, and the next block's c_attn follows into A
+  // when they are through mlp.c_proj (waited for in front of the next block's first barrier, behind the E1 hop).
+  constexpr bool HALFB = NB >= 5;
+  constexpr unsigned SLOTB = HALFB ? 256 + HO * 2 * D * 2 : SLOT;
+  constexpr int QA1 = 10;                              // HALFB: c_attn rows 0..9 at A + QOFF1, rows 10..15 at A + 256
+  constexpr unsigned QOFF1 = 256 + HO * 2 * D * 2;     // behind the second half of mlp.c_proj
+  static_assert(QOFF1 + QA1 * D * 2 <= SLOT && (QO - QA1) * D * 2 <= HO * 2 * D * 2, "c_attn parts fit slot A");
+  static_assert(SLOTB >= SLOTC, "c_proj fits slot B");
   unsigned char* W0 = smem;                 // A
   unsigned char* W1 = smem + SLOT;          // B
-  unsigned char* W2 = SLOT3 ? smem + 2 * SLOT : W1;  // C (3 - 4 rows: c_proj in slot B)
+  unsigned char* W2 = SLOT3 ? smem + 2 * SLOT : W1;  // C (3 - 6 rows: c_proj in slot B)
   // 3 - 4 rows: no slot C (c_proj shares slot B with mlp.c_proj, which is then requested behind the second LayerNorm), and the
   // fp32 residual-stream buffer and the context buffer live inside the gelu(fc) buffer: that one is written by the E5 gather
   // and read by mlp.c_proj only, and every gather into the aliases starts behind wait_own() = after every compute wave is
   // through the phase that read the previous content.  LDS: 147.8 KB at 3 rows, 160.6 KB of 163.8 at 4.
-  uint32_t* xn = reinterpret_cast<uint32_t*>(smem + 2 * SLOT + (SLOT3 ? SLOTC : 0));  // [NB][D / 2] LayerNorm output, bf16 pairs
+  // 5 - 6 rows: 149.1 / 160.9 KB.
+  uint32_t* xn = reinterpret_cast<uint32_t*>(smem + SLOT + SLOTB + (SLOT3 ? SLOTC : 0));  // [NB][D / 2] LayerNorm output, bf16 pairs
   uint32_t* xa = xn + NB * D / 2;                                   // [NB][4D / 2] gelu(fc), bf16 pairs
   float* xf = SLOT3 ? reinterpret_cast<float*>(xa + NB * 2 * D) : reinterpret_cast<float*>(xa);             // [NB][D] fp32
   uint32_t* xc = SLOT3 ? reinterpret_cast<uint32_t*>(xf + NB * D) : xa + NB * D;                           // [NB][D / 2]
   float* red = reinterpret_cast<float*>(SLOT3 ? xc + NB * D / 2 : xa + NB * 2 * D);   // [2][4][4][2]
-  float* hown = red + 64;                                           // [NB][8] this workgroup's slice of the residual stream
-  float* qkvs = hown + 4 * 8;                                       // [3][64] q / k / v of this (row, head)
+  float* hown = red + (NB > 4 ? 128 : 64);                          // [NB][8] this workgroup's slice of the residual stream
+  float* qkvs = hown + (NB > 4 ? NB : 4) * 8;                                       // [3][64] q / k / v of this (row, head)
   float* so = qkvs + 3 * DH;                                        // [16][64]
   float* smx = so + 16 * DH;                                        // [16]
   float* slx = smx + 16;                                            // [16]
@@ -450,6 +533,8 @@ __global__ __launch_bounds__(1024) void decode_engine_kernel(EngArgs a) {
   unsigned* own = reinterpret_cast<unsigned*>(pml + 8);             // [1] phases finished by the compute waves (x NCW)
   const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
   const unsigned S0 = lds0, S1 = lds0 + SLOT, S2 = SLOT3 ? lds0 + 2 * SLOT : S1;
+  static_assert(SLOT + SLOTB + (SLOT3 ? SLOTC : 0) + NB * D * 2 + NB * 4 * D * 2 + (SLOT3 ? NB * D * 4 + NB * D * 2 : 0) + (NB > 4 ? 512 : 256) +
+                        (NB > 4 ? NB : 4) * 32 + (3 * DH + 16 * DH + 32 + NSPLIT * DH + 8 + 1) * 4 <= 160 * 1024, "LDS budget");
   const unsigned own_lds = lds0 + (unsigned)(reinterpret_cast<unsigned char*>(own) - smem);
 
   const int t = threadIdx.x, lane = t & 63;
@@ -498,7 +583,13 @@ __global__ __launch_bounds__(1024) void decode_engine_kernel(EngArgs a) {
   // loader waits in front of every barrier for the one request before it)
   if (lw) {
     if (SLOT3) dma_rows<HO, D>(a.L[0].wp, a.L[0].bp, cu * HO, S2, lane);
-    if (qcu) dma_rows<QO, D>(a.L[0].wa, a.L[0].ba, an0, S0, lane);
+    if (qcu && HALFB) {  // (5 - 6 rows: c_attn lives in two parts - rows 0..9 behind the half of mlp.c_proj that shares slot A)
+      dma_rows_at<QA1, D>(a.L[0].wa, an0, S0 + QOFF1, lane);
+      dma_rows_at<QO - QA1, D>(a.L[0].wa, an0 + QA1, S0 + 256, lane);
+      if (lane < QO) dma4(a.L[0].ba + an0 + lane, S0);
+    } else if (qcu) {
+      dma_rows<QO, D>(a.L[0].wa, a.L[0].ba, an0, S0, lane);
+    }
   }
   if (t < NB * HO) hown[(t / HO) * 8 + t % HO] = a.h[(size_t)(t / HO) * D + cu * HO + t % HO];
 
@@ -524,6 +615,10 @@ __global__ __launch_bounds__(1024) void decode_engine_kernel(EngArgs a) {
         sweep2<(NB * D / 2 + 255) / 256, false>(G - LSTRIDE + OH2, NB * D / 2, tl, rt, [&](int i, uint32_t v) { xf[i] = __uint_as_float(v); }, rt.first_delay);
       }
     } else if (lw) {
+      if (HALFB && l > 0 && qcu) {  // the rest of this block's c_attn -> A: every compute wave is through the last block's mlp.c_proj
+        wait_own(own_lds, NCW * phase, rt);
+        dma_rows_at<QO - QA1, D>(w.wa, an0 + QA1, S0 + 256, ll);
+      }
       dma_wait_keep<0>();  // c_attn (and, before it, c_proj) of this block
     }
     ENG_STAMP(0)
@@ -546,7 +641,7 @@ __global__ __launch_bounds__(1024) void decode_engine_kernel(EngArgs a) {
           float acc[NB];
 #pragma unroll
           for (int b = 0; b < NB; ++b) acc[b] = 0.f;
-          dots<NB, D>(W0 + 256 + r * D * 2, xn, ll, acc);
+          dots<NB, D>(HALFB ? (r < QA1 ? W0 + QOFF1 + r * D * 2 : W0 + 256 + (r - QA1) * D * 2) : W0 + 256 + r * D * 2, xn, ll, acc);
           float mine = 0.f;
 #pragma unroll
           for (int b = 0; b < NB; ++b) {
@@ -829,6 +924,8 @@ __global__ __launch_bounds__(1024) void decode_engine_kernel(EngArgs a) {
     if (SLOT3) {
       if (lw && acu) dma_rows<HO, 4 * D>(w.w2, w.b2, cu * HO, S1, ll);
       if (lw && l + 1 < a.NL) dma_rows<HO, D>(a.L[l + 1].wp, a.L[l + 1].bp, cu * HO, S2, ll);  // next c_proj -> C: all past this one's
+    } else if (lw && HALFB) {
+      dma_rows_part<HO, 4 * D, 0, 2 * D>(w.w2, w.b2, cu * HO, S1, ll);  // first half of mlp.c_proj -> B: all past c_proj
     } else if (lw) {
       dma_rows<HO, 4 * D>(w.w2, w.b2, cu * HO, S1, ll);  // mlp.c_proj -> B: all past c_proj
     }
@@ -869,6 +966,10 @@ __global__ __launch_bounds__(1024) void decode_engine_kernel(EngArgs a) {
     if (gw) {
       wait_own(own_lds, NCW * phase, rt);
       sweep2<(NB * D + 255) / 256, false>(G + OACT, NB * D, tl, rt, [&](int i, uint32_t v) { xa[i] = v; }, a.act_delay);
+    } else if (lw && HALFB) {
+      wait_own(own_lds, NCW * phase, rt);  // every compute wave is through c_fc: slot A is free
+      dma_rows_part<HO, 4 * D, 2 * D, 2 * D>(w.w2, nullptr, cu * HO, S0, ll);  // second half of mlp.c_proj -> A
+      dma_wait_keep<0>();
     } else if (lw && !SLOT3) {
       dma_wait_keep<0>();  // mlp.c_proj (requested behind LN2)
     } else if (lw && acu) {  // mlp.c_proj was requested behind LN2 here; the next block's c_proj (if any) is younger
@@ -880,12 +981,24 @@ __global__ __launch_bounds__(1024) void decode_engine_kernel(EngArgs a) {
     ENG_STAMP(6)
     __syncthreads();
     ENG_STAMP(7)
-    if (lw && qcu && l + 1 < a.NL) dma_rows<QO, D>(a.L[l + 1].wa, a.L[l + 1].ba, an0, S0, ll);  // next c_attn -> A: all past c_fc
+    if (HALFB) {  // rows 0..9 of the next c_attn -> the part of A that the second half of mlp.c_proj leaves free (+ its bias row)
+      if (lw && qcu && l + 1 < a.NL) {
+        dma_rows_at<QA1, D>(a.L[l + 1].wa, an0, S0 + QOFF1, ll);
+        if (ll < QO) dma4(a.L[l + 1].ba + an0 + ll, S0);
+      }
+    } else if (lw && qcu && l + 1 < a.NL) {
+      dma_rows<QO, D>(a.L[l + 1].wa, a.L[l + 1].ba, an0, S0, ll);  // next c_attn -> A: all past c_fc
+    }
     if (cwv && cw < HO) {
       float acc[NB];
 #pragma unroll
       for (int b = 0; b < NB; ++b) acc[b] = 0.f;
-      dots<NB, 4 * D>(W1 + 256 + cw * 4 * D * 2, xa, ll, acc);
+      if (HALFB) {
+        dots_part<NB, 4 * D, 0, 5>(W1 + 256 + cw * 2 * D * 2, xa, ll, acc);
+        dots_part<NB, 4 * D, 5, 5>(W0 + 256 + cw * 2 * D * 2, xa, ll, acc);
+      } else {
+        dots<NB, 4 * D>(W1 + 256 + cw * 4 * D * 2, xa, ll, acc);
+      }
       float mine = 0.f;
 #pragma unroll
       for (int b = 0; b < NB; ++b) {
@@ -981,7 +1094,7 @@ __global__ __launch_bounds__(1024) void decode_engine_kernel(EngArgs a) {
         const int n = r == 0 ? hn_[0] : (r == 1 ? hn_[1] : hn_[2]);
         const float bias = r == 0 ? bh[0] : (r == 1 ? bh[1] : bh[2]);
         float* cv = so;                                      // [NB][36] candidate scores (the attention scratch is idle)
-        int* ci = reinterpret_cast<int*>(so + 4 * 36);       // [NB][36] ids
+        int* ci = reinterpret_cast<int*>(so + ENG_MAX_ROWS * 36);       // [NB][36] ids
         cv[b * 36 + cw * 3 + r] = n >= 0 ? sampler_score(a.samp, a.samp.seen + (size_t)b * a.V, mine + bias, n) : -INFINITY;
         ci[b * 36 + cw * 3 + r] = n >= 0 ? n : 0x7fffffff;
       }
@@ -990,7 +1103,7 @@ __global__ __launch_bounds__(1024) void decode_engine_kernel(EngArgs a) {
       // ---- greedy sampler: arg-max over the vocabulary = over every workgroup's best (larger score, lower id on ties:
       //      the rule of sampler2_kernel, independent of the reduction order) ----
       const float* cv = so;
-      const int* ci = reinterpret_cast<const int*>(so + 4 * 36);
+      const int* ci = reinterpret_cast<const int*>(so + ENG_MAX_ROWS * 36);
       __syncthreads();
       if (tl < NB) {
         float best = -INFINITY;
@@ -1093,7 +1206,7 @@ __global__ __launch_bounds__(1024) void decode_engine_kernel(EngArgs a) {
 
 }  // namespace
 
-size_t eng_gran_count(int layers) { return (size_t)layers * 4 * ENG_D * 15 / 2 + ENG_CAND_WORDS; }
+size_t eng_gran_count(int layers) { return (size_t)layers * ENG_MAX_ROWS * ENG_D * 15 / 2 + ENG_CAND_WORDS; }
 
 int decode_engine_layers(const EngArgs& a, hipStream_t s) {
   ITTS_REQUIRE(a.B >= 1 && a.B <= ENG_MAX_ROWS && a.NL >= 1 && a.NL <= ENG_MAX_LAYERS && a.gran && a.h && a.kc && a.vc && a.ctr, "decode_engine: bad arguments");
@@ -1112,11 +1225,15 @@ int decode_engine_layers(const EngArgs& a, hipStream_t s) {
     ITTS_REQUIRE(a.nb >= 2 && a.nb <= a.B && a.B % a.nb == 0, "decode_engine: beam ancestry needs B to be a multiple of 2 <= nb <= B");
     if (a.B == 2) ITTS_ENG_GO(2, true)
     else if (a.B == 3) ITTS_ENG_GO(3, true)
-    else ITTS_ENG_GO(4, true)
+    else if (a.B == 4) ITTS_ENG_GO(4, true)
+    else if (a.B == 5) ITTS_ENG_GO(5, true)
+    else ITTS_ENG_GO(6, true)
   } else if (a.B == 1) ITTS_ENG_GO(1, false)
   else if (a.B == 2) ITTS_ENG_GO(2, false)
   else if (a.B == 3) ITTS_ENG_GO(3, false)
-  else ITTS_ENG_GO(4, false)
+  else if (a.B == 4) ITTS_ENG_GO(4, false)
+  else if (a.B == 5) ITTS_ENG_GO(5, false)
+  else ITTS_ENG_GO(6, false)
 #undef ITTS_ENG_GO
   ITTS_HIP_CHECK(hipGetLastError());
   return OK;

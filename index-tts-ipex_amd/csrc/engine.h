@@ -154,7 +154,7 @@ struct DecodeState {
   int* fuse_err = nullptr;
   int fuse_failed = 0;                 // a hand-off timed out: two launches from then on
   int fuse = 0, graph_fuse = 0;        // opt-in (ITTS_FUSE_QKV_ATTN=1 / debug bit 3): measured 1.5 % slower than two launches; 0 again after a hand-off timeout
-  // persistent decode engine (decode_engine.hip): the blocks of a step as one launch, <= 4 rows, bf16, no beams / fp8
+  // persistent decode engine (decode_engine.hip): the step as one launch, <= 6 rows (beam rows included), bf16, no fp8
   unsigned long long* eng_gran = nullptr;
   unsigned* eng_ctr = nullptr;           // [0] step counter, [1] abort word
   int eng_off = 0;                       // debug bit 4 / ITTS_ENGINE=0: keep the five-launches-per-layer path (A/B)

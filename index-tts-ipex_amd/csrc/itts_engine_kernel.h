@@ -5,7 +5,7 @@
 
 namespace itts {
 
-constexpr int ENG_D = 1280, ENG_H = 20, ENG_NCU = 256, ENG_MAX_ROWS = 4;
+constexpr int ENG_D = 1280, ENG_H = 20, ENG_NCU = 256, ENG_MAX_ROWS = 6;
 constexpr int ENG_MAX_LAYERS = 24;
 constexpr bool ENG_DEFAULT_ON = true;   // ITTS_ENGINE=0 keeps the five-launches-per-block path  // IndexTTS-1.5 GPT on the 256 CUs of an MI355X
 
@@ -51,7 +51,7 @@ struct EngArgs {
   unsigned* stamp = nullptr;          // debugging aid (ITTS_ENGINE_STAMPS): [256][NL][12] wall-clock stamps (100 MHz) of one step
 };
 
-size_t eng_gran_count(int layers);  // 8-byte words of the granule buffer (sized for 4 rows; the last ENG_CAND_WORDS: sampler candidates)
+size_t eng_gran_count(int layers);  // 8-byte words of the granule buffer (sized for ENG_MAX_ROWS rows; the last ENG_CAND_WORDS: sampler candidates)
 constexpr size_t ENG_CAND_WORDS = (size_t)ENG_MAX_ROWS * ENG_NCU * 2;
 int decode_engine_layers(const EngArgs& a, hipStream_t s);
 

@@ -159,7 +159,7 @@ int Engine::ensure_decode_tiles(hipStream_t s) {
 }
 
 // The persistent decode engine (decode_engine.hip) replaces the 120 per-layer launches of a step when the step is the
-// launch-bound small-batch bf16 one it was built for: IndexTTS-1.5 GPT dims, <= 4 rows (beam rows included: cache ancestry), no fp8
+// launch-bound small-batch bf16 one it was built for: IndexTTS-1.5 GPT dims, <= 6 rows (beam rows included: cache ancestry), no fp8
 // copies, a whole MI355X (256 CUs) to itself.  ITTS_ENGINE=0 (or debug bit 4) keeps the launch path.
 bool Engine::engine_usable() const {
   const char* ev = getenv("ITTS_ENGINE");  // read per call: tests flip it inside one process
@@ -714,7 +714,7 @@ int Engine::decode_step_launch(hipStream_t s) {
   ds.pend_split = 0;
   ds.last_mode = 0;
   int eng_first = 0;
-  if (engine_usable()) {  // <= 4 rows: the 24 blocks as ONE persistent launch, then the head + sampler launches
+  if (engine_usable()) {  // <= 6 rows: the 24 blocks (+ head, + greedy sampler) as ONE persistent launch
     ITTS_REQUIRE(ds.eng_gran && ds.eng_ctr, "decode engine: state not allocated (prefill first)");
     EngArgs ea;
     for (int l = 0; l < c.layers; ++l) {
@@ -746,11 +746,11 @@ int Engine::decode_step_launch(hipStream_t s) {
     }
     // gather pacing (s_sleep units of 64 clocks): a publish needs ~0.4 us to become visible; earlier passes fail AND slow the
     // stores down.  Defaults from tools/eng_pacing_rows.sh (profiles/r03_engine_pacing_sweep.txt): 14 / 16 at <= 2 rows, 12 / 8
-    // at 3 - 4 rows (more granules per pass: the first pass itself takes longer)
+    // at 3 - 4 rows, 12 / 4 at 5 - 6 (more granules per pass: the first pass itself takes longer)
     static const int e_fd_env = getenv("ITTS_ENGINE_FIRST_DELAY") ? atoi(getenv("ITTS_ENGINE_FIRST_DELAY")) : -1;
     static const int e_ad_env = getenv("ITTS_ENGINE_ACT_DELAY") ? atoi(getenv("ITTS_ENGINE_ACT_DELAY")) : -1;
     const int e_fd = e_fd_env >= 0 ? e_fd_env : (B <= 2 ? 14 : 12);
-    const int e_ad = e_ad_env >= 0 ? e_ad_env : (B <= 2 ? 16 : 8);
+    const int e_ad = e_ad_env >= 0 ? e_ad_env : (B <= 2 ? 16 : B <= 4 ? 8 : 4);
     static const int e_ps = getenv("ITTS_ENGINE_PASS_SLEEP") ? atoi(getenv("ITTS_ENGINE_PASS_SLEEP")) : 1;
     static const int e_thin = getenv("ITTS_ENGINE_THIN_FC") ? atoi(getenv("ITTS_ENGINE_THIN_FC")) : 0;
     ea.thin_fc = e_thin;

@@ -130,23 +130,30 @@ def test_bf16_latent(eng16s, mel, gold, control, accuracy):
     assert abs(float(np.sqrt((lat.astype(np.float64) ** 2).mean())) - float(g["latent_rms"])) < 1e-2 * float(g["latent_rms"])
 
 
-def test_bf16_free_running_six_rows_mfma_path(eng16s, mel, gold, accuracy):
-    """Six different sentences as ONE decode batch (> 4 rows: skinny MFMA projections, 256-thread cache attention), greedy,
-    free-running, against the reference's batched greedy ids: a row may part from the reference only where the reference's
+@pytest.mark.parametrize("path", ["mfma", "engine"])
+def test_bf16_free_running_six_rows(eng16s, mel, gold, accuracy, path):
+    """Six different sentences as ONE decode batch, greedy, free-running, on both six-row paths - "mfma": the launch path
+    (skinny MFMA projections, 256-thread cache attention), "engine": the persistent decode engine (the default at <= 6 rows
+    from r03 on; GEMV arithmetic) - against the reference's batched greedy ids: a row may part from the reference only where the reference's
     own top-1 / top-2 margin is below 0.04 (logit std 1.0, |top logit| ~ 4: the bf16 logits carry 3e-3 relative = ~0.01 - 0.02
     absolute error; r03 measured 0.0005 .. 0.018 at the parting steps: profiles/r03_accuracy.json) - a wrong kernel parts at a
     step with a comfortable margin."""
     g = gold("smooth_decode_b6")
     cond = eng16s.conditioning(mel)
     ns = g["codes"].shape[1]
-    eng16s.prefill(cond, g["text"].astype(np.int32), ns, 10.0, True)
-    _, lg0 = eng16s.fetch(logits=True)
-    eng16s.decode(ns - 1)
-    codes = eng16s.fetch()
-    eng16s._exit()
-    assert eng16s.decode_mode() == 0  # six rows: the batched launch path, not the persistent engine
+    eng16s.debug(no_engine=path == "mfma", engine=path == "engine")
+    try:
+        eng16s.prefill(cond, g["text"].astype(np.int32), ns, 10.0, True)
+        _, lg0 = eng16s.fetch(logits=True)
+        eng16s.decode(ns - 1)
+        codes = eng16s.fetch()
+        eng16s._exit()
+        assert eng16s.decode_mode() == (1 if path == "engine" else 0)
+    finally:
+        eng16s.debug()
+    tag = "" if path == "mfma" else "_engine"
     e0 = [rms_rel(lg0[r, g["top_idx0"][r]], g["top_val0"][r]) for r in range(6)]
-    accuracy["smooth_bf16_rows6_first_step_top8_logits_rel_rms"] = max(e0)
+    accuracy[f"smooth_bf16_rows6{tag}_first_step_top8_logits_rel_rms"] = max(e0)
     assert max(e0) < BOUND, e0
     agree, at = [], []
     for r in range(6):
@@ -154,8 +161,8 @@ def test_bf16_free_running_six_rows_mfma_path(eng16s, mel, gold, accuracy):
         k = ns if same.all() else int(np.argmin(same))
         agree.append(k)
         at.append(float(g["margins"][r, k]) if k < ns else None)
-    accuracy["smooth_bf16_rows6_free_running_steps_equal_to_reference"] = agree
-    accuracy["smooth_bf16_rows6_reference_margin_at_the_parting_step"] = at
+    accuracy[f"smooth_bf16_rows6{tag}_free_running_steps_equal_to_reference"] = agree
+    accuracy[f"smooth_bf16_rows6{tag}_reference_margin_at_the_parting_step"] = at
     for r in range(6):
         assert at[r] is None or at[r] < 0.04, f"row {r}: ids part at step {agree[r]} where the reference margin is {at[r]:.3f}"
     assert sum(agree) >= 6 * 8 and sorted(agree)[-2] >= 16, agree  # most rows follow the reference for a while

@@ -152,6 +152,7 @@ def test_rows_5_to_16_layernorm_in_projection_and_half_tiles(mel, accuracy):
     texts = np.stack([synth.text_ids(105, 700 + i, CFG.gpt.number_text_tokens) for i in range(16)]).astype(np.int32)
     n = 20
     eng = ieng.build_engine(CFG, "bf16", parts=("gpt",), max_batch=16)
+    eng.debug(no_engine=True)  # the launch path's MFMA kernels are the subject (5 - 6 rows default to the persistent engine)
     cond = eng.conditioning(mel)
     out = {}
     for rows in (16, 9, 5, 2):

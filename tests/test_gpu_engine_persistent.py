@@ -1,6 +1,6 @@
-"""GPU: the persistent decode engine (csrc/decode_engine.hip: the 24 blocks of a token step as ONE launch, <= 4 rows,
+"""GPU: the persistent decode engine (csrc/decode_engine.hip: the 24 blocks of a token step as ONE launch, <= 6 rows,
 bf16) against the launch path it replaces (gemv_bf16_kernel + decode_attn2_kernel, five launches a layer): the engine
-repeats the launch path's arithmetic operation for operation, so ids AND logits have to be bit-identical - at 1 to 4
+repeats the launch path's arithmetic operation for operation, so ids AND logits have to be bit-identical - at 1 to 4 (5 - 6 rows: the launch path is MFMA there, tolerance + row-independence tests)
 rows, under graph replay and eager launches, through the register window of the cache attention and past it.
 Reference hot loop: indextts/gpt/model.py:115-192."""
 import numpy as np
@@ -68,7 +68,7 @@ def test_engine_ragged_rows_and_long_sequence(eng16, cond, rows):
     assert np.array_equal(lg.view(np.uint32), ref_lg.view(np.uint32))
 
 
-@pytest.mark.parametrize("items,nb,sample", [(1, 3, True), (1, 3, False), (2, 2, True), (1, 4, True), (1, 2, False)])
+@pytest.mark.parametrize("items,nb,sample", [(1, 3, True), (1, 3, False), (2, 2, True), (1, 4, True), (1, 2, False)])  # (2 x 3 = 6 rows: tolerance test below)
 def test_engine_beam_rows_equal_launch_path(eng16, cond, items, nb, sample):
     """The reference's default generate() mode (num_beams 3, model.py:698-703) one sentence at a time = 3 rows: the
     engine's cache attention gathers every key through the beam's ancestry row exactly as decode_attn2_kernel<.., ANC>
@@ -88,6 +88,76 @@ def test_engine_beam_rows_equal_launch_path(eng16, cond, items, nb, sample):
             eng16.debug()
     assert modes == [0, 1], modes
     assert res[0].shape == (items, n) and np.array_equal(res[0], res[1])
+
+
+@pytest.mark.parametrize("sample", [True, False])
+def test_engine_six_beam_rows_equal_the_three_row_runs(eng16, cond, sample):
+    """2 sentences x 3 beams = 6 rows on the engine (two-half mlp.c_proj slots, ancestry gather with nb = 3 of 6 rows): rows
+    are independent and the engine's arithmetic per row does not depend on the row count, so every sentence's ids equal
+    the ids of that sentence decoded alone (3 rows on the engine = bit-identical to the launch path, above)."""
+    text = np.stack([synth.text_ids(105, 91 + r, CFG.gpt.number_text_tokens) for r in range(2)]).astype(np.int32)
+    n, nb = 64, 3
+    u = np.random.default_rng(17).random((n, 2, 2 * nb), dtype=np.float32)
+    kw = dict(do_sample=sample, num_beams=nb, top_k=30, top_p=0.8, temperature=1.0, suppress_stop=True)
+    eng16.debug(engine=True)
+    try:
+        both = eng16.generate(cond, text, n, uniforms=u, **kw)
+        assert eng16.decode_mode() == 1
+        for i in range(2):
+            one = eng16.generate(cond, text[i:i + 1], n, uniforms=np.ascontiguousarray(u[:, i:i + 1]), **kw)
+            assert np.array_equal(one[0], both[i]), i
+    finally:
+        eng16.debug()
+
+
+@pytest.fixture(scope="module")
+def eng16s():  # the well-conditioned synthetic checkpoint of tests/test_gpu_bf16_accuracy.py: bf16 noise is not amplified
+    return ieng.build_engine(CFG, "bf16", parts=("gpt",), state_dicts={"gpt": synth.gpt_state_dict(CFG, 1234, profile="smooth")})
+
+
+@pytest.mark.parametrize("rows", [5, 6])
+def test_engine_5_6_rows_track_the_mfma_launch_path(eng16s, rows):
+    """5 - 6 rows (2 sentences x 3 beams: the reference's default mode on a two-sentence text): the engine keeps the GEMV
+    arithmetic (v_dot2c chains), the launch path at these row counts runs on the matrix cores - different summation orders,
+    so the comparison is a tolerance: teacher-forced on the launch path's own ids, every step's logits within 1e-2 relative
+    RMS (measured ~3e-3: two bf16 evaluations of the same step), the arg-max equal wherever the margin is not a near-tie."""
+    eng16 = eng16s
+    cond = eng16.conditioning(torch.from_numpy(synth.prompt_mel(511, seed=7)))
+    stop = CFG.gpt.stop_text_token
+    padded = np.full((rows, 105), stop, np.int32)  # ragged rows (left padding -> kv_start)
+    for r in range(rows):
+        padded[r, :105 - 7 * r] = synth.text_ids(105 - 7 * r, 71 + r, CFG.gpt.number_text_tokens)
+    n = 40
+    ref_codes, _ = run(eng16, cond, padded, n, no_engine=True)
+    traces, modes = [], []
+    try:
+        eng16.set_forced(ref_codes[:, :n])
+        for no_engine in (True, False):
+            eng16.debug(no_engine=no_engine, engine=not no_engine)
+            eng16.prefill(cond, padded, n, 10.0, True)
+            lgs = []
+            for k in range(n):
+                lgs.append(eng16.fetch(logits=True)[1].copy())
+                if k + 1 < n:
+                    eng16.decode(1)
+            modes.append(eng16.decode_mode())
+            eng16._exit()
+            traces.append(np.stack(lgs))
+    finally:
+        eng16.set_forced(None)
+        eng16.debug()
+    assert modes == [0, 1], modes
+    a, b = traces
+    worst = 0.0
+    for k in range(n):
+        for r in range(rows):
+            d = float(np.sqrt(((a[k, r] - b[k, r]) ** 2).mean()) / np.sqrt((a[k, r] ** 2).mean()))
+            worst = max(worst, d)
+            top = np.sort(a[k, r])[-2:]
+            if top[1] - top[0] > 0.25:
+                assert int(a[k, r].argmax()) == int(b[k, r].argmax()), (k, r)
+    print(f"engine vs MFMA launch path, {rows} rows: worst per-step logits rel-RMS {worst:.2e}")
+    assert worst < 1e-2, worst
 
 
 def test_engine_status_reports_no_timeout(eng16, cond):

@@ -258,6 +258,7 @@ def test_full_beam_search_bf16_six_rows_track_three_rows(eng16, mel, accuracy):
 
     def trace(txt):
         eng16.set_beam_sample(nb, do_sample=False)
+        eng16.debug(no_engine=True)  # the two launch-path kernel families (6 rows default to the persistent engine from r03 on)
         try:
             eng16.prefill(cond, txt, n, 10.0, True)
             out = [eng16.fetch(logits=True)[1].copy()]
@@ -267,6 +268,7 @@ def test_full_beam_search_bf16_six_rows_track_three_rows(eng16, mel, accuracy):
             eng16._exit()
         finally:
             eng16.set_beam_sample(1)
+            eng16.debug()
         return out
 
     both = trace(text)
