@@ -223,6 +223,7 @@ struct Engine {
   int gpt_prefill(const float* cond, const int32_t* text_ids, int B, int L, int max_gen, float penalty, int suppress,
                   hipStream_t s);
   int gpt_decode(int nsteps, hipStream_t s);
+  int gpt_decode_steps(int nsteps, hipStream_t s);
   int gpt_set_sampling(int do_sample, int top_k, float top_p, float temperature, const float* uniforms_host, long n);
   std::vector<float> sample_uniforms;  // host copy, uploaded by the next prefill
   int gpt_set_forced(const int32_t* ids_host, int B, int n);

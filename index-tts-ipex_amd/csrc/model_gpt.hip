@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <mutex>
 
 #include <cstdlib>
 
@@ -1067,11 +1068,42 @@ int Engine::gpt_set_forced(const int32_t* ids_host, int B, int n) {
   return OK;
 }
 
+// The persistent decode engine keeps one workgroup on EVERY CU for a whole token step and its workgroups wait for each other:
+// two such launches in flight together (two Engine objects decoding on two streams of one device) could each hold part of
+// the CUs and wait for workgroups that cannot become resident - until the 20 ms bound of the waits fires.  So engine launches
+// of one device are chained across streams: a decode call first makes its stream wait for the event behind the last engine
+// launch of the device (a no-op on the same stream), then records its own.  Other kernels may share the device freely: they
+// finish on their own and the engine's workgroups simply start later.
+namespace {
+struct EngineGate {
+  std::mutex mu;
+  hipEvent_t ev = nullptr;
+};
+EngineGate& engine_gate(int dev) {
+  static EngineGate gates[64];
+  return gates[dev & 63];
+}
+}  // namespace
+
 int Engine::gpt_decode(int nsteps, hipStream_t s) {
   if (!ds.active) {
     set_error("gpt_decode: call itts_gpt_prefill first");
     return E_STATE;
   }
+  static const bool no_gate = getenv("ITTS_ENGINE_NO_GATE") != nullptr;  // debugging aid: show what the chaining prevents
+  if (!engine_usable() || dry || no_gate) return gpt_decode_steps(nsteps, s);
+  int dev = 0;
+  ITTS_HIP_CHECK(hipGetDevice(&dev));
+  EngineGate& g = engine_gate(dev);
+  std::lock_guard<std::mutex> lk(g.mu);
+  if (!g.ev) ITTS_HIP_CHECK(hipEventCreateWithFlags(&g.ev, hipEventDisableTiming));
+  else ITTS_HIP_CHECK(hipStreamWaitEvent(s, g.ev, 0));
+  const int rc = gpt_decode_steps(nsteps, s);
+  ITTS_HIP_CHECK(hipEventRecord(g.ev, s));
+  return rc;
+}
+
+int Engine::gpt_decode_steps(int nsteps, hipStream_t s) {
   ITTS_REQUIRE(nsteps >= 0, "gpt_decode: nsteps < 0");
   if (use_graph && s != nullptr) {
     DecodeState& d = ds;

@@ -190,6 +190,35 @@ def test_engine_timeout_is_reported_and_the_launch_path_takes_over(cond, monkeyp
     eng.debug()
 
 
+def test_two_engine_objects_interleaved_on_one_device(eng16, cond):
+    """Two Engine objects (two HIP streams) decoding at the same time on one GPU, both on the persistent engine: its launches
+    keep one workgroup on every CU and wait for each other, so two in flight together could starve each other until the
+    20 ms bound fires - the library chains the engine launches of a device across streams.  Interleaved decode calls
+    without any synchronisation in between give each engine the ids it produces alone."""
+    other = ieng.build_engine(CFG, "bf16", parts=("gpt",))
+    texts = [synth.text_ids(105, 81 + i, CFG.gpt.number_text_tokens).reshape(1, -1).astype(np.int32) for i in range(2)]
+    n = 96
+    alone = []
+    for e, t in ((eng16, texts[0]), (other, texts[1])):
+        e.debug(engine=True)
+        alone.append(e.generate(cond, t, n, suppress_stop=True))
+    try:
+        for e, t in ((eng16, texts[0]), (other, texts[1])):
+            e.prefill(cond, t, n, 10.0, True)
+        for k in range(0, n - 1, 5):
+            for e in (eng16, other):
+                e.decode(min(5, n - 1 - k))
+        got = []
+        for e in (eng16, other):
+            assert e.decode_mode() == 1
+            got.append(e.fetch().astype(np.int64))
+            e._exit()
+    finally:
+        eng16.debug()
+        other.debug()
+    assert np.array_equal(got[0], alone[0]) and np.array_equal(got[1], alone[1])
+
+
 def test_launch_path_eager_full_length_equals_graph(eng16, cond):
     """The 122-launches-per-step path at the bench's full length WITHOUT graph capture (58 k eager launches: the run the
     r02 rocprofv3 --pmc pass died in) against its graph replay: same ids, same logits - the eager path's scratch / state
