@@ -594,7 +594,8 @@ int Engine::sample_from_logits(hipStream_t s, bool sampled) {
   if (sampled) return OK;  // the persistent engine's in-launch greedy sampler committed this step's tokens
   if (ds.host_sample) return OK;  // the caller reads the logits, picks the tokens and commits them (gpt_commit)
   const float* lg_in = ds.logits;
-  const bool typical = ds.typical_mass > 0.f && (ds.do_sample || (ds.nb > 1 && ds.beam_sample));
+  // (a logits PROCESSOR in the reference, model.py:690-697: greedy search and beam search run it too, not only the sampling modes)
+  const bool typical = ds.typical_mass > 0.f;
   if (typical) {  // TypicalLogitsWarper sits in HF's logits_processor list, right after the repetition penalty
     TypicalArgs ta;
     ta.logits = ds.logits;
@@ -771,7 +772,7 @@ int Engine::decode_step_launch(hipStream_t s) {
     // ... and the greedy sampler behind it (ITTS_ENGINE_SAMPLER=0: own launch): plain greedy search only - sampling, beams,
     // typical filtering and host-side sampling keep their kernels
     static const bool e_samp = !(getenv("ITTS_ENGINE_SAMPLER") && atoi(getenv("ITTS_ENGINE_SAMPLER")) == 0);
-    const bool fold_samp = fold_head && e_samp && !ds.do_sample && ds.nb == 1 && !ds.host_sample;
+    const bool fold_samp = fold_head && e_samp && !ds.do_sample && ds.nb == 1 && !ds.host_sample && !(ds.typical_mass > 0.f);
     if (fold_samp) {
       ea.fold_sampler = 1;
       ea.samp = greedy_sampler_args(ds.logits, false);

@@ -287,8 +287,8 @@ class Engine:
             # HF: TopK warper off (top_k = 0 / None) or wider than the device sampler's 128 candidates - exact on the host
             return self._generate_host_sampled(cond, text_ids, max_gen, repetition_penalty, suppress_stop, int(top_k or 0), top_p,
                                                temperature, seed, uniforms, typical_mass)
-        typical = bool(do_sample and typical_mass)
-        if typical:  # typical_sampling=True (model.py:690-697): TypicalLogitsWarper in front of the warpers
+        typical = bool(typical_mass)
+        if typical:  # typical_sampling=True (model.py:690-697): TypicalLogitsWarper behind the repetition penalty, in every mode
             L.check(self.lib.itts_gpt_set_typical(self.h, float(typical_mass)), "gpt_set_typical")
         if beams:
             if uniforms is None and do_sample:

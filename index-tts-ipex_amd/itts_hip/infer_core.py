@@ -80,7 +80,8 @@ def sampling_kwargs(do_sample, num_beams, top_k, top_p, temperature, typical_sam
       do_sample, num_beams == 1      multinomial sampling
       not do_sample, num_beams > 1   beam_search (deterministic)
       not do_sample, num_beams == 1  greedy
-      typical_sampling               the reference's TypicalLogitsWarper(typical_mass) in front of the warpers (sampling modes)
+      typical_sampling               the reference's TypicalLogitsWarper(typical_mass) behind the repetition penalty - a logits
+                                     PROCESSOR in the reference (model.py:690-697), so greedy and beam search run it too
     Limits of the device samplers (the web UI offers num_beams 1..10 and top_k 0..100): num_beams <= 10; at most 128 kept
     candidates per row.  top_k = 0 / None (HF: TopK warper off) or > 128 with ONE beam is exact all the same: the token choice
     then runs on the host over the whole vocabulary (host_sample_step below, one logits read-back per token); with several
@@ -97,11 +98,12 @@ def sampling_kwargs(do_sample, num_beams, top_k, top_p, temperature, typical_sam
         warnings.warn(f"itts_hip: num_beams={nb} > 10 is not supported; using 10", RuntimeWarning)
         nb = 10
     lp = float(length_penalty or 0.0)
-    if typical_sampling and not do_sample:
-        # HF appends TypicalLogitsWarper to `logits_processor` (model.py:690-697), so it would also filter greedy / beam search
-        warnings.warn("itts_hip: typical_sampling is ignored when do_sample=False (greedy / beam search run without it)", RuntimeWarning)
+    tm = float(typical_mass) if typical_sampling else 0.0
     if not do_sample:
-        return dict(num_beams=nb, length_penalty=lp) if nb > 1 else {}
+        kw = dict(num_beams=nb, length_penalty=lp) if nb > 1 else {}
+        if tm:
+            kw["typical_mass"] = tm
+        return kw
     k = int(top_k) if top_k else 0
     if k < 1 or k > 128:
         if nb > 1:
@@ -111,7 +113,7 @@ def sampling_kwargs(do_sample, num_beams, top_k, top_p, temperature, typical_sam
             k = 0 if k < 1 else k  # one beam: exact on the host (Engine.generate takes the host-sampling path)
     p = 1.0 if top_p is None else float(top_p)
     return dict(do_sample=True, top_k=k, top_p=min(max(p, 1e-6), 1.0), temperature=float(temperature or 1.0), num_beams=nb,
-                typical_mass=float(typical_mass) if typical_sampling else 0.0, length_penalty=lp,
+                typical_mass=tm, length_penalty=lp,
                 seed=int(torch.randint(0, 2 ** 31 - 1, (1,)).item()))
 
 

@@ -293,7 +293,7 @@ def sample_pick(scores, top_k: int, top_p: float, temperature: float, u: float) 
 
 def greedy_generate(cond, text_inputs, w: W, cfg_gpt, max_generate_length: int, repetition_penalty: float = 10.0,
                     suppress_eos: bool = False, trace: Optional[dict] = None, sampling: Optional[dict] = None,
-                    input_tokens: Optional[torch.Tensor] = None):
+                    input_tokens: Optional[torch.Tensor] = None, typical_mass: float = 0.0):
     """UnifiedVoice.inference_speech (model.py:655-708) with HF 4.36.2 `generate` greedy_search semantics
     (do_sample False, num_beams 1; eos=pad=stop_mel_token; MaxLengthCriteria): hand-rolled because the
     installed transformers 5.x `generate` skips the prefill (SURVEY 8c 'Critical caveat').
@@ -307,7 +307,12 @@ def greedy_generate(cond, text_inputs, w: W, cfg_gpt, max_generate_length: int, 
 
     input_tokens [b or 1, n] (model.py:672-686): given mel tokens are appended to the fake ids, so the FIRST forward embeds
     [start_mel, t1..tn] with positions 0..n (model.py:141-144) and the first generated token is fed at position n + 2
-    (model.py:151-155); the returned codes start after the given tokens (trunc_index, model.py:687,704)."""
+    (model.py:151-155); the returned codes start after the given tokens (trunc_index, model.py:687,704).
+
+    typical_mass > 0 (typical_sampling=True, model.py:690-697) with sampling None: greedy search over the typical-filtered
+    scores - the warper sits in HF's logits_processor list, which greedy search runs as well."""
+    import numpy as np
+
     stop = cfg_gpt["stop_mel_token"]
     fake, prefix, mask = prepare_gpt_inputs(cond, text_inputs, w, cfg_gpt)
     b, s, _ = prefix.shape
@@ -342,6 +347,10 @@ def greedy_generate(cond, text_inputs, w: W, cfg_gpt, max_generate_length: int, 
             nxt = torch.tensor([sample_pick(scores[r].numpy(), sampling["top_k"], sampling["top_p"], sampling["temperature"],
                                             float(sampling["uniforms"][k_step, r])) for r in range(b)], dtype=torch.long)
         else:
+            if typical_mass:  # greedy search runs the logits_processor list too: RepetitionPenalty, TypicalLogitsWarper(min keep 1)
+                from . import hf_beam
+
+                scores = torch.from_numpy(np.stack([hf_beam.typical_filter(scores[r].numpy(), typical_mass, 1) for r in range(b)]))
             nxt = torch.argmax(scores, dim=-1)
         nxt = nxt * unfinished + stop * (1 - unfinished)
         ids = torch.cat([ids, nxt[:, None]], dim=1)
@@ -411,7 +420,10 @@ def beam_sample_generate(cond, text_inputs, w: W, cfg_gpt, max_generate_length: 
         lp = repetition_penalty_(lp.clone(), ids, repetition_penalty) if repetition_penalty != 1.0 else lp
         lpn = lp.numpy()
         if not do_sample:
-            # HF beam_search: processors only (no warpers), torch.topk over the flat [beams * V] scores
+            # HF beam_search: processors only (no warpers; the reference's TypicalLogitsWarper IS a processor, model.py:690-697),
+            # torch.topk over the flat [beams * V] scores
+            if typical_mass:
+                lp = torch.from_numpy(np.stack([hf_beam.typical_filter(lpn[r], typical_mass, 2) for r in range(lpn.shape[0])]))
             flat = (lp + torch.from_numpy(beam_scores)[:, None]).view(b, nb * V)
             top = torch.topk(flat, 2 * nb, dim=1, largest=True, sorted=True)
             ns, ni, nt = top.values.numpy(), (top.indices // V).numpy(), (top.indices % V).numpy()

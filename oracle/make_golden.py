@@ -88,7 +88,7 @@ def build_ref_dvae(cfg, seed):
 
 
 def ref_greedy(gpt, cond_mel, text, max_gen, rep=10.0, n_trace=None, suppress_eos=False, trace_steps=None, input_tokens=None,
-               lens=None):
+               lens=None, typical_mass=0.0):
     """Hand-rolled HF-4.36.2-style greedy_search over the reference's own GPT2InferenceModel.forward
     (the installed transformers-5.x `generate` skips the prefill, so it is not used)."""
     from transformers import RepetitionPenaltyLogitsProcessor
@@ -108,6 +108,11 @@ def ref_greedy(gpt, cond_mel, text, max_gen, rep=10.0, n_trace=None, suppress_eo
         ids = torch.cat([ids, it], dim=1)
         mask = torch.nn.functional.pad(mask, (0, n_in), value=1)
     proc = RepetitionPenaltyLogitsProcessor(rep)
+    typical = None
+    if typical_mass:  # typical_sampling=True: the reference's own subclass, appended to the logits_processor list (model.py:690-697)
+        from indextts.utils.typical_sampling import TypicalLogitsWarper
+
+        typical = TypicalLogitsWarper(mass=typical_mass, min_tokens_to_keep=1)
     past = None
     b = ids.shape[0]
     unfinished = torch.ones(b, dtype=torch.long)
@@ -128,6 +133,8 @@ def ref_greedy(gpt, cond_mel, text, max_gen, rep=10.0, n_trace=None, suppress_eo
         scores = proc(ids, logits.clone())
         if suppress_eos:  # fixed-length decode: the engine's suppress_stop masks the stop score after the penalty
             scores[:, stop] = -float("inf")
+        if typical is not None:
+            scores = typical(ids, scores)
         top2 = torch.topk(scores, 2, dim=-1).values
         margins.append((top2[:, 0] - top2[:, 1]).clone())
         step += 1
@@ -552,6 +559,26 @@ def input_token_fixtures():
 
 
 @torch.no_grad()
+def typical_fixtures():
+    """typical_sampling=True WITHOUT sampling (model.py:690-697 appends the TypicalLogitsWarper to `logits_processor`, which
+    greedy search and beam search run too): the reference's forward + its own warper class, greedy and 3-beam search."""
+    cfg = icfg.micro()
+    g = cfg.gpt
+    gpt = build_ref_gpt(cfg, 1234)
+    mel = torch.from_numpy(synth.prompt_mel(61, seed=7))
+    text = torch.stack([torch.from_numpy(synth.text_ids(11, 11 + i, g.number_text_tokens)).int() for i in range(2)])
+    plain, *_ = ref_greedy(gpt, mel, text, max_gen=24)
+    codes, *_ = ref_greedy(gpt, mel, text, max_gen=24, typical_mass=0.3)
+    assert not torch.equal(plain[:, : codes.shape[1]], codes[:, : plain.shape[1]]), "the filter never removed the arg-max: pick another mass"
+    save("micro_greedy_typical", text=text, codes=codes, typical_mass=0.3, max_gen=24)
+    u = np.zeros((20, 2, 6), dtype=np.float32)
+    cb = ref_beam_sample(gpt, mel, text, 20, u, nb=3, do_sample=False, typical_mass=0.3)
+    cb0 = ref_beam_sample(gpt, mel, text, 20, u, nb=3, do_sample=False)
+    assert cb.shape != cb0.shape or not np.array_equal(cb, cb0), "beam search unchanged by the filter: pick another mass"
+    save("micro_beam_search3_typical", text=text, codes=cb, num_beams=3, typical_mass=0.3, max_gen=20)
+
+
+@torch.no_grad()
 def cond_batch_fixtures():
     """A batch of prompts of different lengths (model.py:490-502 with cond_mel_lengths, :599-602 per-row conditioning): two
     prompts padded to 61 frames, lengths 61 and 45, the padding filled with noise (it must not matter); conditioning latents
@@ -635,6 +662,7 @@ if __name__ == "__main__":
     ap.add_argument("--input-tokens", action="store_true")
     ap.add_argument("--smooth", action="store_true")
     ap.add_argument("--cond-batch", action="store_true")
+    ap.add_argument("--typical", action="store_true")
     a = ap.parse_args()
     ref_import.install()
     torch.manual_seed(0)
@@ -646,6 +674,8 @@ if __name__ == "__main__":
         smooth_fixtures()
     if a.cond_batch:
         cond_batch_fixtures()
+    if a.typical:
+        typical_fixtures()
     if a.full:
         full_fixtures()
     if a.front:

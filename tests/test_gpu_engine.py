@@ -348,6 +348,24 @@ def test_beam_sample_bf16_runs_and_is_deterministic(eng16, gold):
     assert np.array_equal(a, b) and a.shape[0] == g["text"].shape[0] and a.shape[1] <= int(g["max_gen"])
 
 
+def test_typical_filter_in_greedy_and_beam_search_matches_reference_fp32(eng32, gold):
+    """typical_sampling=True with do_sample=False (a logits PROCESSOR in the reference, model.py:690-697): the device runs
+    the typical pre-pass in front of the greedy arg-max / the beam-search candidates - ids against the reference fixtures."""
+    c = gold("micro_conditioning")
+    cond = torch.from_numpy(c["cond"])
+    g = gold("micro_greedy_typical")
+    got = eng32.generate(cond, g["text"], int(g["max_gen"]), typical_mass=float(g["typical_mass"]))
+    m = min(got.shape[1], g["codes"].shape[1])
+    assert np.array_equal(got[:, :m], g["codes"][:, :m]), (got, g["codes"])
+    gb = gold("micro_beam_search3_typical")
+    gotb = eng32.generate(cond, gb["text"], int(gb["max_gen"]), do_sample=False, num_beams=3, typical_mass=float(gb["typical_mass"]))
+    m = min(gotb.shape[1], gb["codes"].shape[1])
+    assert np.array_equal(gotb[:, :m], gb["codes"][:, :m]), (gotb, gb["codes"])
+    # and the next plain greedy generation is unfiltered again
+    g1 = gold("micro_decode_b1")
+    assert np.array_equal(eng32.generate(cond, g1["text"], 24), g1["codes"])
+
+
 def test_typical_sampling_single_beam_matches_oracle_fp32(eng32, gold):
     """typical_sampling=True with num_beams=1 (GenerationMixin.sample: RepetitionPenalty -> Typical(min keep 1) ->
     Temperature -> TopK -> TopP), micro and through a long vocabulary sort at IndexTTS-1.5 size in test_gpu_fullsize."""

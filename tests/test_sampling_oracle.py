@@ -114,6 +114,27 @@ def test_beam_hypotheses_bookkeeping():
     assert len(h) == 2
 
 
+def test_typical_filter_without_sampling_matches_reference_fixtures(gold):
+    """typical_sampling=True with do_sample=False: the reference appends its TypicalLogitsWarper to `logits_processor`
+    (model.py:690-697), so greedy search and beam search run it too (and may lose their arg-max to it).  Oracle against the
+    fixtures made from the reference's forward + its own warper class (make_golden.typical_fixtures)."""
+    cfg = icfg.micro()
+    w = ogpt.to_torch(synth.gpt_state_dict(cfg, 1234))
+    mel = torch.from_numpy(synth.prompt_mel(61, seed=7))
+    g = gold("micro_greedy_typical")
+    with torch.no_grad():
+        cond = ogpt.get_conditioning(mel, w, cfg.gpt)
+        out = ogpt.greedy_generate(cond, torch.from_numpy(g["text"]).long(), w, cfg.gpt, int(g["max_gen"]), typical_mass=float(g["typical_mass"]))
+        plain = ogpt.greedy_generate(cond, torch.from_numpy(g["text"]).long(), w, cfg.gpt, int(g["max_gen"]))
+    assert np.array_equal(out.numpy(), g["codes"])
+    assert not np.array_equal(plain.numpy()[:, : out.shape[1]], out.numpy()[:, : plain.shape[1]])  # the filter does something
+    gb = gold("micro_beam_search3_typical")
+    with torch.no_grad():
+        outb = ogpt.beam_sample_generate(cond, torch.from_numpy(gb["text"]).long(), w, cfg.gpt, int(gb["max_gen"]), num_beams=3,
+                                         do_sample=False, typical_mass=float(gb["typical_mass"]))
+    assert np.array_equal(outb.numpy(), gb["codes"]), (outb.numpy(), gb["codes"])
+
+
 def test_beam_scorer_keeps_n_best_in_descending_order():
     """BeamSearchScorer.finalize with num_beam_hyps_to_keep = n (generate()'s num_return_sequences under beams): rows
     n * b .. n * b + n - 1 are batch item b's hypotheses by descending score, the later insertion first on equal scores
