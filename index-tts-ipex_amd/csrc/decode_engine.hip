@@ -657,6 +657,16 @@ __global__ __launch_bounds__(1024) void decode_engine_kernel(EngArgs a) {
     }
 
     phase_done(ll);
+    // c_fc -> A on the workgroups that run no attention: requested early_fc x 64 clocks after this workgroup's compute waves are
+    // through c_attn (slot A is free then), i.e. while the attention workgroups compute, instead of behind B3 beside the h'
+    // gather (a gather pass queued behind its own CU's refill burst takes 2 - 3 x as long).  The delay matters: right behind
+    // c_attn the 51 KB land beside the q / k / v hop and the cache rows (0.456 ms per step against 0.448 for "behind B3"); 1.9 us
+    // later - the attention workgroups are computing, nothing else is on the fabric - 0.436.  0: behind B3 everywhere.
+    if (a.early_fc > 0 && lw && !acu) {
+      wait_own(own_lds, NCW * phase, rt);
+      for (int z = 0; z < a.early_fc; ++z) __builtin_amdgcn_s_sleep(1);
+      dma_rows<FO, D>(w.wf, w.bf, cu * FO, S0, ll);
+    }
     ENG_STAMP(8)
 
     // ================= P2: cache attention of (row gm, head gh) =================
@@ -884,7 +894,7 @@ __global__ __launch_bounds__(1024) void decode_engine_kernel(EngArgs a) {
     }  // (three slots: c_proj is older in the loader's queue than c_attn, it landed before this block's first barrier)
     ENG_STAMP(4)
     __syncthreads();
-    if (lw) {  // c_fc -> A: every wave is past c_attn
+    if (lw && !(a.early_fc > 0 && !acu)) {  // c_fc -> A: every wave is past c_attn
       if (a.thin_fc)
         dma_rows<FO, D, 12>(w.wf, w.bf, cu * FO, S0, ll);
       else

@@ -756,6 +756,8 @@ int Engine::decode_step_launch(hipStream_t s) {
     static const int e_ps = getenv("ITTS_ENGINE_PASS_SLEEP") ? atoi(getenv("ITTS_ENGINE_PASS_SLEEP")) : 1;
     static const int e_thin = getenv("ITTS_ENGINE_THIN_FC") ? atoi(getenv("ITTS_ENGINE_THIN_FC")) : 0;
     ea.thin_fc = e_thin;
+    static const int e_early = getenv("ITTS_ENGINE_EARLY_FC") ? atoi(getenv("ITTS_ENGINE_EARLY_FC")) : -1;
+    ea.early_fc = e_early >= 0 ? e_early : (B >= 2 ? 74 : 0);  // tools/ab_early.sh (profiles/r03_engine_early_fc.txt): no gain at one row
     ea.first_delay = e_fd;
     static const int e_cd = getenv("ITTS_ENGINE_CTX_DELAY") ? atoi(getenv("ITTS_ENGINE_CTX_DELAY")) : 0;
     ea.ctx_delay = e_cd;
