@@ -48,6 +48,11 @@ k0, k1 = (st[:, 1, 15] - t0) / 100.0, (st[:, 2, 15] - t0) / 100.0
 print(f"-- launch: workgroups start {k0.min():.2f} .. {k0.max():.2f} us, first block's E1 gathered at 0 .. {us[:, 0, 0].max():.2f}; last h2 published "
       f"{us[:, -1, 11].max():.2f}, workgroups end {k1.min():.2f} .. {k1.max():.2f} us (head + sampler: {k1.max() - us[:, -1, 11].max():.2f} us; "
       f"whole launch {k1.max() - k0.min():.2f} us)")
+# attention workgroups against the rest: mean over blocks 2..NL-2 of (stage time - block's first E1)
+base = us[:, 2:NL - 1, 0].min(axis=0, keepdims=True)
+rel = us[:, 2:NL - 1, :] - base[:, :, None]
+print("-- attention workgroups vs the others (mean us since the block's first E1): " +
+      ", ".join(f"{names[i]} {rel[acu][:, :, i].mean():.2f} / {rel[~acu][:, :, i].mean():.2f}" for i in (4, 9, 5, 10, 6, 11)))
 clk = st[:, 0, 15]
 print(f"shader clock over the launch: {np.median(clk) / 10.0:.0f} MHz (min {clk.min() / 10.0:.0f}, max {clk.max() / 10.0:.0f})")
 d = us[:, 2:NL - 1, :]
