@@ -177,7 +177,9 @@ int itts_gpt_set_forced(itts_engine* e, const int32_t* ids_host, int B, int n);
 /* The same, with the positions of the reference's `input_tokens` path (gpt/model.py:141-155,672-686): the given tokens are
  * part of the reference's FIRST forward, embedded with mel positions 0 .. n ([start_mel, t1 .. tn]), and the first generated
  * token is fed at position n + 2 - so given token k (0-based) is fed at position k + 1 here, not k + 2 as a generated
- * (or teacher-forced) token would be.  n = 0 clears. */
+ * (or teacher-forced) token would be.  n = 0 clears.  Works with beams too (itts_gpt_set_beams; B = batch items, every id
+ * >= 0): the given tokens go into every beam row with the beam scores, the cache ancestry and the hypotheses untouched, and
+ * HF's generated_len (length penalty, is_done) counts after them, as they belong to the decoder prompt there. */
 int itts_gpt_set_input_tokens(itts_engine* e, const int32_t* ids_host, int B, int n);
 
 /* How the last captured / launched decode step ran: 1 = the persistent decode engine (one launch for the GPT blocks of a

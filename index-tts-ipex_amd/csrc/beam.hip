@@ -261,6 +261,7 @@ __global__ __launch_bounds__(1024) void beam_select_kernel(BeamArgs a) {
   const int nb = a.nb, Beff = a.B * nb, mg = a.max_gen;
   const int k = a.len[bi * nb];
   if (k >= mg) return;
+  const bool given = a.forced && k < a.input_n;  // an `input_tokens` step: every beam takes the given token
   const int par = k & 1;
   const int* ids_old = a.ids + (size_t)par * Beff * mg;
   int* ids_new = a.ids + (size_t)(par ^ 1) * Beff * mg;
@@ -277,7 +278,7 @@ __global__ __launch_bounds__(1024) void beam_select_kernel(BeamArgs a) {
     worst_pre = a.hyp_worst[bi];
     counter_pre = a.hyp_counter[bi];
   }
-  if (!was_done) {  // block-uniform
+  if (!was_done && !given) {  // block-uniform
     if (tid == 0) {
       int o = 0;
       for (int r = 0; r < nb; ++r) {
@@ -379,7 +380,14 @@ __global__ __launch_bounds__(1024) void beam_select_kernel(BeamArgs a) {
   // ---- one thread: sort the picks, BeamSearchScorer.process ----
   if (tid == 0) {
     n_add = 0;
-    if (was_done) {
+    if (given) {
+      for (int q = 0; q < nb; ++q) {
+        nxt_src[q] = bi * nb + q;
+        nxt_tok[q] = a.forced[(size_t)(bi * nb + q) * mg + k];
+        nxt_score[q] = a.beam_scores[bi * nb + q];  // untouched: beam_sample zeros / beam_search [0, -1e9, ..]
+      }
+      s_done = was_done;
+    } else if (was_done) {
       for (int q = 0; q < nb; ++q) {
         nxt_src[q] = bi * nb + q;  // (HF points done batches at row 0; nothing of a done batch is read again)
         nxt_tok[q] = a.stop;
@@ -413,7 +421,7 @@ __global__ __launch_bounds__(1024) void beam_select_kernel(BeamArgs a) {
       float worst = worst_pre;
       int counter = counter_pre;
       int filled = 0;
-      const float lpdiv = a.length_penalty == 0.f ? 1.f : powf((float)(k + 1), a.length_penalty);
+      const float lpdiv = a.length_penalty == 0.f ? 1.f : powf((float)(k + 1 - a.input_n), a.length_penalty);  // generated_len
       for (int rank = 0; rank < nd && filled < nb; ++rank) {
         if (ptok[rank] == a.stop) {
           if (rank >= nb) continue;
@@ -474,7 +482,7 @@ __global__ __launch_bounds__(1024) void beam_select_kernel(BeamArgs a) {
   //      costs one memory round trip (a loop per beam and array paid nine) ----
   const int pos_next = pref0 + k + 1;  // where the next step appends (own physical row)
   const int n_ids = nb * k, n_anc = nb * a.Smax, n_h = a.h_next ? nb * a.D : 0;
-  const int pp = min(k + 2, a.pos_rows - 1);
+  const int pp = min(k < a.input_n ? k + 1 : k + 2, a.pos_rows - 1);  // a given token k was in the first forward, at position k + 1
   for (int rd = 0;; ++rd) {
     const int b_ids = rd * 2048, b_anc = rd * 4096, b_h = rd * 4096;
     if (b_ids >= n_ids && b_anc >= n_anc && b_h >= n_h) break;

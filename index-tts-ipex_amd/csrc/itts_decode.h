@@ -113,6 +113,11 @@ struct BeamArgs {
   float* cand_sc = nullptr;  // [B * nb][BEAM_MAX_CAND]
   int* cand_tok = nullptr;   // [B * nb][BEAM_MAX_CAND]
   int* cand_n = nullptr;     // [B * nb]
+  // HF `input_tokens` under beams (model.py:672-686): the first input_n steps of every beam row take forced[row][k] (all >= 0)
+  // with the beam scores, the ancestry and the hypotheses untouched; they belong to the decoder prompt, so generated_len
+  // (length penalty, is_done) counts from input_n and token k < input_n is fed at mel position k + 1
+  const int* forced = nullptr;  // [B * nb][max_gen]
+  int input_n = 0;
 };
 constexpr int BEAM_MAX_CAND = 128;
 int beam_sample_step(const BeamArgs& a, hipStream_t s);

@@ -371,7 +371,7 @@ int Engine::beam_finalize(int32_t* codes, hipStream_t s) {
       float worst = 1e9f;
       for (const Hyp& h : hy) worst = std::min(worst, h.score);
       int counter = 1 << 20;
-      const float lpdiv = d.length_penalty == 0.f ? 1.f : std::pow((float)k, d.length_penalty);  // generated_len = k here
+      const float lpdiv = d.length_penalty == 0.f ? 1.f : std::pow((float)(k - d.input_n), d.length_penalty);  // generated_len = k - given tokens
       for (int q = 0; q < nb; ++q) {
         const int row = b * nb + q;
         const float score = bscore[row] / lpdiv;
@@ -440,7 +440,9 @@ int Engine::gpt_prefill(const float* cond_dev, const int32_t* text_ids_in, int B
   ds.beam_sample = beam_do_sample;
   ds.length_penalty = beam_length_penalty;
   if (nbeam > 1) {
-    ITTS_REQUIRE(forced_n == 0, "gpt_prefill: forced tokens are not supported together with beams");
+    ITTS_REQUIRE(forced_n == 0 || forced_input, "gpt_prefill: teacher forcing (gpt_set_forced) is not supported together with beams; `input_tokens` is");
+    for (size_t i = 0; i < forced_host.size() && forced_n > 0; ++i)
+      ITTS_REQUIRE(forced_host[i] >= 0, "gpt_prefill: `input_tokens` under beams must not hold free (-1) entries");
     ITTS_REQUIRE(beam_returns <= nbeam, "`num_return_sequences` has to be smaller or equal to `num_beams`.");
     ITTS_TRY(ensure_beam_state(B, max_gen, Smax, s));
     const long n_init = std::max<long>(2L * B * Smax, 64);
@@ -473,11 +475,11 @@ int Engine::gpt_prefill(const float* cond_dev, const int32_t* text_ids_in, int B
     ITTS_HIP_CHECK(hipMemsetAsync(ds.forced, 0xFF, (size_t)B * max_gen * 4, s));  // -1: nothing forced yet
   }
   if (ds.use_forced) {
-    ITTS_REQUIRE(forced_B == B || forced_B == 1, "gpt_prefill: forced tokens were set for a different batch size");
+    ITTS_REQUIRE(forced_B == B_items || forced_B == 1, "gpt_prefill: forced tokens were set for a different batch size");
     ITTS_REQUIRE(forced_n <= max_gen, "gpt_prefill: more forced tokens than max_gen");
     std::vector<int32_t> tab((size_t)B * max_gen, -1);
     for (int b = 0; b < B; ++b)
-      for (int k = 0; k < forced_n; ++k) tab[(size_t)b * max_gen + k] = forced_host[(size_t)(forced_B == 1 ? 0 : b) * forced_n + k];
+      for (int k = 0; k < forced_n; ++k) tab[(size_t)b * max_gen + k] = forced_host[(size_t)(forced_B == 1 ? 0 : b / nbeam) * forced_n + k];
     ITTS_HIP_CHECK(hipMemcpyAsync(ds.forced, tab.data(), tab.size() * 4, hipMemcpyHostToDevice, s));
     ITTS_HIP_CHECK(hipStreamSynchronize(s));
   }
@@ -664,6 +666,8 @@ int Engine::sample_from_logits(hipStream_t s, bool sampled) {
     ba.D = D;
     ba.pos_rows = c.max_mel_tokens + 3;
     ba.emb_bf16 = adt == BF16;
+    ba.forced = ds.use_forced ? ds.forced : nullptr;
+    ba.input_n = ds.use_forced ? ds.input_n : 0;
     return beam_sample_step(ba, s);
   }
   SamplerArgs sa = greedy_sampler_args(lg_in, typical);

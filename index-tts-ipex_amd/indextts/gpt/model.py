@@ -106,8 +106,6 @@ class UnifiedVoice:
         n_forced = 0
         with self._eng.lock:
             if input_tokens is not None:
-                if sample_kw.get("num_beams", 1) > 1:
-                    raise NotImplementedError("input_tokens together with num_beams > 1")
                 it = input_tokens.detach().cpu().numpy() if isinstance(input_tokens, torch.Tensor) else np.asarray(input_tokens)
                 it = np.atleast_2d(it).astype(np.int32)
                 n_forced = it.shape[1]

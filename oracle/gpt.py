@@ -383,13 +383,17 @@ def latent_forward(cond, text_tokens, codes, w: W, cfg_gpt):
 def beam_sample_generate(cond, text_inputs, w: W, cfg_gpt, max_generate_length: int, num_beams: int = 3, top_k: int = 30,
                          top_p: float = 0.8, temperature: float = 1.0, repetition_penalty: float = 10.0,
                          length_penalty: float = 0.0, uniforms=None, trace: Optional[dict] = None, typical_mass: float = 0.0,
-                         do_sample: bool = True, num_return_sequences: int = 1):
+                         do_sample: bool = True, num_return_sequences: int = 1, input_tokens=None):
     """UnifiedVoice.inference_speech under the reference's DEFAULT kwargs (infer.py:116-124: do_sample=True, num_beams=3,
     top_k=30, top_p=0.8, length_penalty=0.0, repetition_penalty=10.0): HF 4.36.2 GenerationMixin.beam_sample +
     BeamSearchScorer, restated in oracle/hf_beam.py, over this module's GPT-2 stack with the KV cache re-ordered by
     beam_idx every step (GPT2InferenceModel._reorder_cache, model.py:194-207).  uniforms [max_gen, b, 2*num_beams] are
     the draws.  Returns codes [b * num_return_sequences, <= max_generate_length] (prefix stripped, model.py:704-705;
-    num_return_sequences = BeamSearchScorer's num_beam_hyps_to_keep, model.py:655,698-703: the n best per text row)."""
+    num_return_sequences = BeamSearchScorer's num_beam_hyps_to_keep, model.py:655,698-703: the n best per text row).
+
+    input_tokens [b or 1, n] (model.py:672-686): appended to the fake ids before the expansion, so they are part of the decoder
+    prompt of every beam (first forward at positions 0 .. n, generated_len counts after them); the draws of generated step j
+    are uniforms[n + j] (the device indexes its uniforms by the absolute step)."""
     import numpy as np
 
     from . import hf_beam
@@ -399,14 +403,22 @@ def beam_sample_generate(cond, text_inputs, w: W, cfg_gpt, max_generate_length: 
     nb = num_beams
     fake, prefix, mask = prepare_gpt_inputs(cond, text_inputs, w, cfg_gpt)
     b, s, _ = prefix.shape
+    n_in = 0
+    if input_tokens is not None:
+        it = torch.as_tensor(input_tokens).long()
+        it = it[None] if it.ndim == 1 else it
+        it = it.repeat(b // it.shape[0], 1)
+        n_in = it.shape[1]
+        fake = torch.cat([fake, it], dim=1)
+        mask = torch.cat([mask, torch.ones(b, n_in, dtype=mask.dtype)], dim=1)
     # _expand_inputs_for_generation: repeat_interleave(num_beams) on ids / mask; store_mel_emb's prefix repeats likewise
     ids = fake.repeat_interleave(nb, 0).clone()
     mask = mask.repeat_interleave(nb, 0)
     prefix = prefix.repeat_interleave(nb, 0)
     mel_emb, mel_pos = w["mel_embedding.weight"], w["mel_pos_embedding.emb.weight"]
-    emb = torch.cat([prefix, mel_emb[ids[:, s:]] + mel_pos[:1]], dim=1)
+    emb = torch.cat([prefix, mel_emb[ids[:, s:]] + mel_pos[: 1 + n_in]], dim=1)
     h, past = gpt2_stack(emb, w, cfg_gpt, key_mask=mask)
-    prompt_len = s + 1
+    prompt_len = s + 1 + n_in
     scorer = hf_beam.BeamSearchScorer(b, nb, length_penalty=length_penalty, max_length=prompt_len + max_generate_length,
                                       num_beam_hyps_to_keep=num_return_sequences)
     beam_scores = np.zeros(b * nb, dtype=np.float32)
@@ -444,7 +456,7 @@ def beam_sample_generate(cond, text_inputs, w: W, cfg_gpt, max_generate_length: 
         ns, nt, ni = [], [], []
         for bi in range(b):
             cands = [hf_beam.warp_row(lpn[bi * nb + r], top_k, top_p, temperature, 2) for r in range(nb)]
-            sc, tk, bm = hf_beam.beam_sample_step(cands, beam_scores[bi * nb:(bi + 1) * nb], V, uniforms[step, bi])
+            sc, tk, bm = hf_beam.beam_sample_step(cands, beam_scores[bi * nb:(bi + 1) * nb], V, uniforms[n_in + step, bi])
             ns.append(sc)
             nt.append(tk)
             ni.append(bm)

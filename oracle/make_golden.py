@@ -150,7 +150,7 @@ def ref_greedy(gpt, cond_mel, text, max_gen, rep=10.0, n_trace=None, suppress_eo
 
 
 def ref_beam_sample(gpt, cond_mel, text, max_gen, uniforms, nb=3, top_k=30, top_p=0.8, temperature=1.0, rep=10.0,
-                    length_penalty=0.0, typical_mass=0.0, do_sample=True):
+                    length_penalty=0.0, typical_mass=0.0, do_sample=True, input_tokens=None):
     """Hand-rolled HF-4.36.2 `beam_sample` over the reference's own GPT2InferenceModel.forward / _reorder_cache with the
     INSTALLED transformers logits processors / warpers (min_tokens_to_keep = 2 under beams) and the BeamSearchScorer
     restatement of oracle/hf_beam.py; torch.multinomial is replaced by the shared-uniform sequential draw."""
@@ -167,6 +167,13 @@ def ref_beam_sample(gpt, cond_mel, text, max_gen, uniforms, nb=3, top_k=30, top_
     s = emb.shape[1]
     b = ids.shape[0]
     V = gpt.number_mel_codes
+    n_in = 0
+    if input_tokens is not None:  # inference_speech, model.py:672-686: part of the decoder prompt of every beam
+        it = input_tokens[None] if input_tokens.ndim == 1 else input_tokens
+        it = it.repeat(b // it.shape[0], 1)
+        n_in = it.shape[1]
+        ids = torch.cat([ids, it], dim=1)
+        mask = torch.nn.functional.pad(mask, (0, n_in), value=1)
     ids = ids.repeat_interleave(nb, 0)
     mask = mask.repeat_interleave(nb, 0)
     proc = RepetitionPenaltyLogitsProcessor(rep)
@@ -182,7 +189,7 @@ def ref_beam_sample(gpt, cond_mel, text, max_gen, uniforms, nb=3, top_k=30, top_
         warpers.append(TopKLogitsWarper(top_k=top_k, min_tokens_to_keep=2))
     if top_p is not None and top_p < 1.0:
         warpers.append(TopPLogitsWarper(top_p=top_p, min_tokens_to_keep=2))
-    prompt_len = s + 1
+    prompt_len = s + 1 + n_in
     scorer = hf_beam.BeamSearchScorer(b, nb, length_penalty=length_penalty, max_length=prompt_len + max_gen)
     beam_scores = np.zeros(b * nb, dtype=np.float32)
     if not do_sample:  # beam_search initialisation
@@ -211,7 +218,7 @@ def ref_beam_sample(gpt, cond_mel, text, max_gen, uniforms, nb=3, top_k=30, top_
                 row = scn[bi * nb + r]
                 keep = np.nonzero(np.isfinite(row))[0]
                 cands.append((keep, row[keep]))
-            a, t, m = hf_beam.beam_sample_step(cands, beam_scores[bi * nb:(bi + 1) * nb], V, uniforms[step, bi])
+            a, t, m = hf_beam.beam_sample_step(cands, beam_scores[bi * nb:(bi + 1) * nb], V, uniforms[n_in + step, bi])
             ns.append(a)
             nt.append(t)
             ni.append(m)
@@ -556,6 +563,14 @@ def input_token_fixtures():
     t2 = torch.stack([text[0], torch.from_numpy(synth.text_ids(11, 12, g.number_text_tokens)).int()])
     codes2, logits2, *_ = ref_greedy(gpt, mel, t2, max_gen=16, input_tokens=given, n_trace=3)
     save("micro_input_tokens_b2", text=t2, input_tokens=given, codes=codes2, logits=logits2)
+    # the same continuation under beams (3-beam sample with a length penalty, 3-beam search): given tokens in every beam's prompt
+    n = 14
+    u = np.random.default_rng(77).random((5 + n, 2, 6), dtype=np.float32)
+    cs = ref_beam_sample(gpt, mel, t2, n, u, nb=3, top_k=30, top_p=0.8, temperature=1.0, length_penalty=0.7, input_tokens=given)
+    save("micro_input_tokens_beam_sample", text=t2, input_tokens=given, codes=cs, uniforms=u, num_beams=3, top_k=30, top_p=0.8,
+         temperature=1.0, length_penalty=0.7, max_gen=n)
+    cb = ref_beam_sample(gpt, mel, t2, n, u, nb=3, do_sample=False, length_penalty=1.0, input_tokens=given)
+    save("micro_input_tokens_beam_search", text=t2, input_tokens=given, codes=cb, num_beams=3, length_penalty=1.0, max_gen=n)
 
 
 @torch.no_grad()

@@ -129,6 +129,18 @@ def test_input_tokens_continuation_matches_reference(tts, gold, name):
     assert np.array_equal(out.cpu().numpy(), g["codes"])
 
 
+def test_input_tokens_with_beam_search_through_dropin(tts, gold):
+    """`inference_speech(input_tokens=..., num_beams=3, do_sample=False)`: the continuation under beam search, returned codes
+    start after the given tokens - against the reference fixture."""
+    g = gold("micro_input_tokens_beam_search")
+    mel = torch.from_numpy(gold("micro_conditioning")["mel"]).cuda()
+    out = tts.gpt.inference_speech(mel, torch.from_numpy(g["text"]), input_tokens=torch.from_numpy(g["input_tokens"]), do_sample=False,
+                                   num_beams=3, repetition_penalty=10.0, length_penalty=float(g["length_penalty"]),
+                                   max_generate_length=int(g["max_gen"])).cpu().numpy()
+    m = min(out.shape[1], g["codes"].shape[1])
+    assert np.array_equal(out[:, :m], g["codes"][:, :m]), (out, g["codes"])
+
+
 def test_padding_test_through_dropin(tts, gold):
     """tests/padding_test.py flow through `tts.gpt.inference_speech` with its kwargs."""
     g1, g5 = gold("micro_decode_b1"), gold("micro_decode_b5")

@@ -339,6 +339,31 @@ def test_beam_n_best_matches_oracle_fp32(eng32, gold, nb, nret, sample):
                        num_return_sequences=nb + 1)
 
 
+@pytest.mark.parametrize("mode", ["sample", "search"])
+def test_input_tokens_under_beams_match_reference_fp32(eng32, gold, mode):
+    """`input_tokens` continuation with 3 beams (model.py:672-686, 698-703): given tokens forced into every beam row at
+    positions 1 .. n with the beam scores, ancestry and hypotheses untouched, generated_len counted after them - ids against
+    the fixtures made from the reference's forward (beam-sample with length_penalty 0.7, beam search with 1.0)."""
+    c = gold("micro_conditioning")
+    cond = torch.from_numpy(c["cond"])
+    g = gold(f"micro_input_tokens_beam_{mode}")
+    given = g["input_tokens"].astype(np.int32)
+    n_in, n = given.shape[1], int(g["max_gen"])
+    eng32.set_input_tokens(given)
+    try:
+        got = eng32.generate(cond, g["text"], n_in + n, do_sample=mode == "sample", num_beams=3, top_k=30, top_p=0.8, temperature=1.0,
+                             uniforms=g["uniforms"] if mode == "sample" else None, length_penalty=float(g["length_penalty"]))
+    finally:
+        eng32.set_input_tokens(None)
+    assert np.array_equal(got[:, :n_in], np.repeat(given, got.shape[0] // given.shape[0], 0))
+    m = min(got.shape[1] - n_in, g["codes"].shape[1])
+    stop = CFG.gpt.stop_mel_token
+    assert np.array_equal(got[:, n_in:n_in + m], g["codes"][:, :m]) and (got[:, n_in + m:] == stop).all() and (g["codes"][:, m:] == stop).all(), (got, g["codes"])
+    # the next beam generation starts from the plain prompt again
+    g0 = gold("micro_beam_search3")
+    assert np.array_equal(eng32.generate(cond, g0["text"], int(g0["max_gen"]), do_sample=False, num_beams=3)[:, :g0["codes"].shape[1]], g0["codes"])
+
+
 def test_beam_sample_bf16_runs_and_is_deterministic(eng16, gold):
     c, g = gold("micro_conditioning"), gold("micro_beam_a")
     cond = torch.from_numpy(c["cond"])

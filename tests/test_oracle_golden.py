@@ -89,6 +89,21 @@ def test_input_tokens_continuation(gold, wg, name):
     assert np.abs(plain["logits"][:, 0].numpy() - g["logits"][:, 0]).max() > 1e-2
 
 
+@pytest.mark.parametrize("mode", ["sample", "search"])
+def test_input_tokens_continuation_under_beams(gold, wg, mode):
+    """`input_tokens` with num_beams = 3 (model.py:672-686 + 698-703): the given tokens are part of every beam's decoder
+    prompt (generated_len - length penalty, is_done - counts after them); fixtures = the reference's own forward /
+    _reorder_cache with the scorer restatement, beam-sample with a length penalty and beam search."""
+    g = gold(f"micro_input_tokens_beam_{mode}")
+    mel = torch.from_numpy(gold("micro_conditioning")["mel"])
+    cond = ogpt.get_conditioning(mel, wg, CFG.gpt)
+    out = ogpt.beam_sample_generate(cond, torch.from_numpy(g["text"]).long(), wg, CFG.gpt, int(g["max_gen"]), num_beams=3,
+                                    top_k=30, top_p=0.8, temperature=1.0, length_penalty=float(g["length_penalty"]),
+                                    uniforms=g["uniforms"] if mode == "sample" else None, do_sample=mode == "sample",
+                                    input_tokens=torch.from_numpy(g["input_tokens"]))
+    assert np.array_equal(out.numpy(), g["codes"]), (out.numpy(), g["codes"])
+
+
 def test_padded_prompt_conditioning(gold, wg):
     """get_conditioning with cond_mel_lengths (model.py:490-502): the reference's masked conformer / perceiver on a prompt
     padded from 45 to 61 frames (padding = noise) gives the latents of the prompt cut to 45 frames with the convolution
