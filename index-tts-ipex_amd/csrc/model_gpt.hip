@@ -761,7 +761,7 @@ int Engine::decode_step_launch(hipStream_t s) {
     static const int e_thin = getenv("ITTS_ENGINE_THIN_FC") ? atoi(getenv("ITTS_ENGINE_THIN_FC")) : 0;
     ea.thin_fc = e_thin;
     static const int e_early = getenv("ITTS_ENGINE_EARLY_FC") ? atoi(getenv("ITTS_ENGINE_EARLY_FC")) : -1;
-    ea.early_fc = e_early >= 0 ? e_early : (B >= 2 ? 74 : 0);  // tools/ab_early.sh (profiles/r03_engine_early_fc.txt): no gain at one row
+    ea.early_fc = e_early >= 0 ? e_early : 74;  // tools/ab_early.sh, tools/eng_pacing_rows.sh (profiles/r03_engine_early_fc.txt)
     ea.first_delay = e_fd;
     static const int e_cd = getenv("ITTS_ENGINE_CTX_DELAY") ? atoi(getenv("ITTS_ENGINE_CTX_DELAY")) : 0;
     ea.ctx_delay = e_cd;
