@@ -410,6 +410,18 @@ def main():
                                         "decode_ms_per_token_step": mp["roofline"]["avg_launch_ms"]}
             except Exception as e:  # noqa: BLE001
                 also["product_loop"] = {"error": repr(e)[:200]}
+            try:  # the same utterance in the reference's DEFAULT generate() mode (infer.py:116-124: beam-sample, 3 beams): 6 decode rows
+                import copy
+
+                ab = copy.copy(a)
+                ab.beams = 3
+                mb = measure(eng, cfg, ab, a.batch, 2, 1, rank, world)
+                also["reference_default_mode_3_beams"] = {"value": mb["value"], "unit": "audio-s/s", "ms_per_step": mb["ms_per_step"],
+                                                          "vs_headline": round(mb["value"] / max(m["value"], 1e-9), 4), "config": mb["config"],
+                                                          "decode_ms_per_token_step": mb["roofline"]["avg_launch_ms"],
+                                                          "kernel": mb["roofline"]["kernel"]}
+            except Exception as e:  # noqa: BLE001
+                also["reference_default_mode_3_beams"] = {"error": repr(e)[:200]}
         out["also"] = also
     if rank == 0:
         if not a.no_cpu_baseline:

@@ -39,4 +39,6 @@ def test_bench_gpus2_self_launch_over_gloo():
     c4 = j2["also"]["config4_batch32_per_gpu"]
     assert c4["config"]["utterances_per_gpu"] == 32 and c4["n_gpus"] == 2 and c4["value"] > 0
     assert j1["also"]["config3_batch32"]["config"]["utterances_per_gpu"] == 32 and "product_loop" in j1["also"]
+    d3 = j1["also"]["reference_default_mode_3_beams"]  # the reference's default generate() mode rides along too
+    assert d3["value"] > 0 and d3["config"]["decode_batch"] == 3 * j1["config"]["decode_batch"]
     assert j2["dist"]["world_size"] == 2 and j2["dist"]["backend"] == "gloo" and j2["dist"]["collectives_in_timed_region"] == 0
