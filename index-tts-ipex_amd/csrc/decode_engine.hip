@@ -1,4 +1,6 @@
-// Persistent decode engine (decode batches <= 4, bf16 weights): the 24 GPT-2 blocks of ONE token step as ONE launch.
+// Persistent decode engine (decode batches <= 6 rows - beam rows included -, bf16 weights): ONE token step as ONE launch - the 24
+// GPT-2 blocks, then ln_f -> final_norm -> mel_head and, for greedy search, the sampler (repetition penalty, arg-max, bookkeeping,
+// next input embedding).
 //
 // Reference hot loop: GPT2InferenceModel.forward, indextts/gpt/model.py:115-192 (HF 4.36.2 GPT2Block: LN -> c_attn ->
 // attention over the cache -> c_proj + residual -> LN -> c_fc -> gelu_new -> c_proj + residual).  The launch path
@@ -23,7 +25,9 @@
 //
 // Arithmetic is the launch path's, operation for operation (same lane <-> k mapping and accumulation order of the GEMV
 // dot products, same LayerNorm reduction tree, same attention window / split / merge): logits and ids are bit-identical
-// to gemv_bf16_kernel + decode_attn2_kernel (tests/test_gpu_engine_persistent.py).
+// to gemv_bf16_kernel + decode_attn2_kernel at 1 - 4 rows (tests/test_gpu_engine_persistent.py); 5 - 6 rows keep that
+// arithmetic row for row (the launch path runs on the matrix cores there: tolerance + row-independence tests).
+// LDS maps by row count: three weight slots (<= 2 rows), two slots with aliased edge buffers (3 - 4), a half slot B (5 - 6).
 //
 // Every spin is bounded (wall clock, s_memrealtime) and also ends on a chip-wide abort word; a workgroup that gave up
 // runs on without waiting, so the grid always drains.  The host reads the abort word at status / fetch.
