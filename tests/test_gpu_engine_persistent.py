@@ -160,6 +160,16 @@ def test_engine_5_6_rows_track_the_mfma_launch_path(eng16s, rows):
     assert worst < 1e-2, worst
 
 
+@pytest.mark.parametrize("rows", [2, 6])
+def test_engine_repeats_are_identical(eng16, cond, rows):
+    """The hand-offs are polled, their timing differs from run to run - the results must not: three full-length generations
+    (479 engine launches each, graph replay) return the same ids and the same final logits, bit for bit."""
+    text = np.stack([synth.text_ids(105, 131 + r, CFG.gpt.number_text_tokens) for r in range(rows)]).astype(np.int32)
+    runs = [run(eng16, cond, text, 480, no_engine=False, chunk=64) for _ in range(3)]
+    for codes, lg in runs[1:]:
+        assert np.array_equal(codes, runs[0][0]) and np.array_equal(lg.view(np.uint32), runs[0][1].view(np.uint32))
+
+
 def test_engine_status_reports_no_timeout(eng16, cond):
     text = synth.text_ids(105, 31, CFG.gpt.number_text_tokens).reshape(1, -1).astype(np.int32)
     eng16.debug(engine=True)
