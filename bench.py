@@ -382,12 +382,21 @@ def main():
         "dtype": ("fp8-e4m3 gpt weights (decode), bf16 activations/KV" if a.gpt_fp8 else a.dtype), "data": "synthetic",
         "rtf": m["rtf"], "phases_ms_per_step": m["phases_ms_per_step"], "config": m["config"], "roofline": m["roofline"],
     }
+    out["decode_mode"] = "persistent_engine" if eng.decode_mode() == 1 else "launch_path"
     if world > 1:
         import torch.distributed as dist
 
+        # every rank must have decoded on the path the headline describes: under nccl (one rank per GPU) that is the persistent
+        # engine - a silent per-rank downgrade (hand-off timeout, fewer CUs on a partitioned device) must show in SCALE_rNN.json
+        mode = torch.tensor([eng.decode_mode()], dtype=torch.int32, device=device if dist.get_backend() == "nccl" else "cpu")
+        lo = mode.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
         out["dist"] = {"backend": dist.get_backend(), "world_size": dist.get_world_size(),
                        "weights_replicate_s": round(getattr(eng, "replicate_s", 0.0), 3),
-                       "collectives_in_timed_region": 0}
+                       "collectives_in_timed_region": 0,
+                       "ranks_on_persistent_engine": "all" if int(lo[0]) == 1 else "NOT all"}
+        if dist.get_backend() == "nccl" and a.dtype == "bf16" and not a.micro and os.environ.get("ITTS_ENGINE", "1") != "0":
+            assert int(lo[0]) == 1, "a rank fell back from the persistent decode engine to the launch path"
     # the default run also measures, next to the headline line (the same per-GPU workload at every N, so the driver's
     # scaling curve compares like with like): 32 utterances per GPU = 64 decode rows - BASELINE config 3 at one GPU, BASELINE
     # config 4 (N x 32 utterances sharded data-parallel) at N GPUs - and, at one GPU, the product loop of Engine.generate
@@ -422,6 +431,20 @@ def main():
                                                           "kernel": mb["roofline"]["kernel"]}
             except Exception as e:  # noqa: BLE001
                 also["reference_default_mode_3_beams"] = {"error": repr(e)[:200]}
+            try:  # BASELINE config 5: one 2000-char utterance = 20 sentences as one decode batch, fp8-e4m3 GPT weights (bf16 activations / KV)
+                import copy
+
+                a5 = copy.copy(a)
+                a5.sentences, a5.gpt_fp8 = 20, True
+                eng5 = build_engine_dp(cfg, a.dtype, device, True)
+                m5 = measure(eng5, cfg, a5, 1, 2, 1, rank, world)
+                also["config5_longform_fp8"] = {"value": m5["value"], "unit": "audio-s/s", "steps": 2, "warmup": 1, "ms_per_step": m5["ms_per_step"],
+                                                "dtype": "fp8-e4m3 gpt weights (decode), bf16 activations/KV",
+                                                "phases_ms_per_step": m5["phases_ms_per_step"], "config": m5["config"], "roofline": m5["roofline"]}
+                del eng5
+                torch.cuda.empty_cache()
+            except Exception as e:  # noqa: BLE001
+                also["config5_longform_fp8"] = {"error": repr(e)[:200]}
         out["also"] = also
     if rank == 0:
         if not a.no_cpu_baseline:

@@ -2,7 +2,7 @@
  *
  * Conventions: plain pointers and sizes, no torch types; every pointer is a DEVICE pointer
  * unless the parameter name ends in `_host`; the caller allocates outputs; calls are asynchronous on the
- * given HIP stream unless stated; the return value is 0 or a negative error code and
+ * given HIP stream unless stated; the return value is 0 or a negative error code (ITTS_E_*) and
  * `itts_last_error()` returns the message (thread-local).  One engine per host thread (the reference's
  * web UI shares one engine between threads without a lock, webui.py:441-452: callers must serialise).
  *
@@ -22,6 +22,19 @@ typedef struct itts_engine itts_engine;
 #define ITTS_F32 0
 #define ITTS_BF16 1
 #define ITTS_F16 5 /* IEEE half: accepted by itts_snake_aa_fwd only (the reference op dispatches float/half/bf16) */
+
+/* status codes */
+#define ITTS_OK 0
+#define ITTS_E_INVALID (-1)
+#define ITTS_E_HIP (-2)
+#define ITTS_E_NOMEM (-3)
+#define ITTS_E_STATE (-4)
+#define ITTS_E_MISSING (-5)
+/* itts_gpt_status / itts_gpt_fetch: a hand-off wait inside the persistent decode engine gave up (20 ms wall clock; the engine
+ * needs the 256 CUs of its GPU to itself - ONE process per GPU).  The codes of this generation are not valid;
+ * the engine object has switched itself to the five-launches-per-block path, so the caller simply generates again (the Python
+ * shim does, once, with a logged warning). */
+#define ITTS_E_HANDOFF (-6)
 
 const char* itts_last_error(void);
 int itts_abi_version(void);
@@ -182,8 +195,9 @@ int itts_gpt_set_forced(itts_engine* e, const int32_t* ids_host, int B, int n);
  * HF's generated_len (length penalty, is_done) counts after them, as they belong to the decoder prompt there. */
 int itts_gpt_set_input_tokens(itts_engine* e, const int32_t* ids_host, int B, int n);
 
-/* How the last captured / launched decode step ran: 1 = the persistent decode engine (one launch for the GPT blocks of a
- * token step; <= 2 rows, bf16, IndexTTS-1.5 dims, no beams / fp8 copies), 0 = five launches per block. */
+/* How the last captured / launched decode step ran: 1 = the persistent decode engine (ONE launch per token step: the GPT
+ * blocks, the head and - greedy search - the sampler; 1 - 6 decode rows, beam rows included (cache ancestry); IndexTTS-1.5
+ * dims, a whole MI355X), 0 = five launches per block. */
 int itts_gpt_decode_mode(itts_engine* e);
 
 /* Host-side token choice, for generate() modes outside the device samplers' limits (HF warpers over the whole vocabulary:
@@ -198,6 +212,19 @@ int itts_gpt_set_host_sampling(itts_engine* e, int on);
  * block shared by every row (what infer.py passes). */
 int itts_gpt_set_cond_per_row(itts_engine* e, int on);
 int itts_gpt_commit(itts_engine* e, const int32_t* tokens_host, itts_stream stream);
+
+/* The same under beams (itts_gpt_set_host_sampling(e, 1) BEFORE itts_gpt_set_beams, which then accepts any top_k and no
+ * uniforms): HF beam_sample with `top_k = 0 / None` or > 128 (infer.py:116-124 forwards the kwargs verbatim; the device beam
+ * sampler keeps at most 128 candidates per beam).  Per step the caller reads the logits [B * num_beams, V] (itts_gpt_fetch) and
+ * itts_gpt_beam_state - ids_host int32 [B * num_beams][max_gen]: every beam's id history (the first *step_host entries are
+ * valid), scores_host [B * num_beams]: the running beam scores, done_host [B]: BeamSearchScorer._done - applies log_softmax ->
+ * logits processors -> warpers -> + beam scores and draws 2 * num_beams candidates per batch item, then hands them IN DRAW
+ * ORDER ([B][2 * num_beams]: score with the beam score included, token, beam index within the item) to
+ * itts_gpt_commit_beams, which runs BeamSearchScorer.process (hypotheses, done) and the beam re-ordering (id histories, cache
+ * ancestry = _reorder_cache, gpt/model.py:194-207) on the device as the device-sampled mode does.  itts_gpt_fetch finalizes. */
+int itts_gpt_beam_state(itts_engine* e, int32_t* ids_host, float* scores_host, int32_t* done_host, int* step_host, itts_stream stream);
+int itts_gpt_commit_beams(itts_engine* e, const float* pick_score_host, const int32_t* pick_tok_host, const int32_t* pick_beam_host,
+                          itts_stream stream);
 
 /* G1/G3/G4 step 0: prepare_gpt_inputs (model.py:591-654) + prefill + first greedy token.
  * cond fp32 [latents, D]; text ids host int32 [B, L] (may hold start/stop padding ids, stripped per row).

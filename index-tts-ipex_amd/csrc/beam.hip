@@ -278,7 +278,14 @@ __global__ __launch_bounds__(1024) void beam_select_kernel(BeamArgs a) {
     worst_pre = a.hyp_worst[bi];
     counter_pre = a.hyp_counter[bi];
   }
-  if (!was_done && !given) {  // block-uniform
+  if (!was_done && !given && a.host_sc) {  // the caller warped and drew (gpt_commit_beams): picks in draw order
+    if (tid < nd) {
+      p_sc[tid] = a.host_sc[(size_t)bi * nd + tid];
+      p_tok[tid] = a.host_tok[(size_t)bi * nd + tid];
+      p_beam[tid] = a.host_beam[(size_t)bi * nd + tid];
+    }
+    __syncthreads();
+  } else if (!was_done && !given) {  // block-uniform
     if (tid == 0) {
       int o = 0;
       for (int r = 0; r < nb; ++r) {
@@ -707,6 +714,15 @@ int beam_sample_step(const BeamArgs& a, hipStream_t s) {
   ITTS_REQUIRE(a.logits && (a.uniforms || !a.do_sample) && a.ids && a.anc && a.len && a.hyp_tok && a.done, "beam_sample: null state");
   ITTS_REQUIRE(a.cand_sc && a.cand_tok && a.cand_n, "beam_sample: candidate scratch missing");
   hipLaunchKernelGGL(beam_cand_kernel, dim3(a.nb, a.B), dim3(1024), (size_t)a.V * 4, s, a);
+  hipLaunchKernelGGL(beam_select_kernel, dim3(a.B), dim3(1024), 0, s, a);
+  ITTS_HIP_CHECK(hipGetLastError());
+  return OK;
+}
+
+int beam_commit_step(const BeamArgs& a, hipStream_t s) {
+  ITTS_REQUIRE(a.nb >= 2 && a.nb <= MAXB, "beam_commit: 2 <= num_beams <= 10");
+  ITTS_REQUIRE(a.host_sc && a.host_tok && a.host_beam, "beam_commit: picks missing");
+  ITTS_REQUIRE(a.ids && a.anc && a.len && a.hyp_tok && a.done, "beam_commit: null state");
   hipLaunchKernelGGL(beam_select_kernel, dim3(a.B), dim3(1024), 0, s, a);
   ITTS_HIP_CHECK(hipGetLastError());
   return OK;

@@ -237,6 +237,15 @@ int itts_gpt_commit(itts_engine* e, const int32_t* tokens_host, itts_stream s) {
   ENG(e);
   return e->e.gpt_commit(tokens_host, (hipStream_t)s);
 }
+int itts_gpt_beam_state(itts_engine* e, int32_t* ids_host, float* scores_host, int32_t* done_host, int* step_host, itts_stream s) {
+  ENG(e);
+  return e->e.gpt_beam_state(ids_host, scores_host, done_host, step_host, (hipStream_t)s);
+}
+int itts_gpt_commit_beams(itts_engine* e, const float* pick_score_host, const int32_t* pick_tok_host, const int32_t* pick_beam_host,
+                          itts_stream s) {
+  ENG(e);
+  return e->e.gpt_commit_beams(pick_score_host, pick_tok_host, pick_beam_host, (hipStream_t)s);
+}
 int itts_gpt_set_forced(itts_engine* e, const int32_t* ids_host, int B, int n) {
   ENG(e);
   return e->e.gpt_set_forced(ids_host, B, n);

@@ -130,8 +130,33 @@ __device__ __forceinline__ u64 ld_gran1(const u64* p) {
   asm volatile("global_load_dwordx2 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(x) : "v"(p) : "memory");
   return x;
 }
-__device__ __forceinline__ void ld_wait() {
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+// The wait of a pass NAMES every destination register of the pass as read-write (cdna_hip_programming.md 5.7 item 1, form (ii)):
+// hipcc takes an asm load's destination as written at the end of the load statement, so without this operand list it would be
+// free to copy, spill or re-allocate x[j] between the load and the wait - correctness would rest on today's register
+// allocation.  With the operands every later use of x[j] depends on THIS statement, and nothing between a load and it may
+// touch the registers (the loads' own "=v" outputs feed only this statement).
+template <int CH>
+__device__ __forceinline__ void ld_wait(u32x4 (&x)[CH]) {
+  static_assert(CH >= 1 && CH <= 10, "operand list of the wait");
+#define ITTS_W(i) "+v"(x[i < CH ? i : 0])
+  if constexpr (CH == 1) asm volatile("s_waitcnt vmcnt(0)" : ITTS_W(0) : : "memory");
+  else if constexpr (CH == 2) asm volatile("s_waitcnt vmcnt(0)" : ITTS_W(0), ITTS_W(1) : : "memory");
+  else if constexpr (CH == 3) asm volatile("s_waitcnt vmcnt(0)" : ITTS_W(0), ITTS_W(1), ITTS_W(2) : : "memory");
+  else if constexpr (CH == 4) asm volatile("s_waitcnt vmcnt(0)" : ITTS_W(0), ITTS_W(1), ITTS_W(2), ITTS_W(3) : : "memory");
+  else if constexpr (CH == 5) asm volatile("s_waitcnt vmcnt(0)" : ITTS_W(0), ITTS_W(1), ITTS_W(2), ITTS_W(3), ITTS_W(4) : : "memory");
+  else if constexpr (CH == 6) asm volatile("s_waitcnt vmcnt(0)" : ITTS_W(0), ITTS_W(1), ITTS_W(2), ITTS_W(3), ITTS_W(4), ITTS_W(5) : : "memory");
+  else if constexpr (CH == 7)
+    asm volatile("s_waitcnt vmcnt(0)" : ITTS_W(0), ITTS_W(1), ITTS_W(2), ITTS_W(3), ITTS_W(4), ITTS_W(5), ITTS_W(6) : : "memory");
+  else if constexpr (CH == 8)
+    asm volatile("s_waitcnt vmcnt(0)" : ITTS_W(0), ITTS_W(1), ITTS_W(2), ITTS_W(3), ITTS_W(4), ITTS_W(5), ITTS_W(6), ITTS_W(7) : : "memory");
+  else if constexpr (CH == 9)
+    asm volatile("s_waitcnt vmcnt(0)" : ITTS_W(0), ITTS_W(1), ITTS_W(2), ITTS_W(3), ITTS_W(4), ITTS_W(5), ITTS_W(6), ITTS_W(7), ITTS_W(8) : : "memory");
+  else
+    asm volatile("s_waitcnt vmcnt(0)"
+                 : ITTS_W(0), ITTS_W(1), ITTS_W(2), ITTS_W(3), ITTS_W(4), ITTS_W(5), ITTS_W(6), ITTS_W(7), ITTS_W(8), ITTS_W(9)
+                 :
+                 : "memory");
+#undef ITTS_W
   __builtin_amdgcn_sched_barrier(0);
 }
 
@@ -179,12 +204,13 @@ __device__ __forceinline__ void sweep2(const u64* __restrict__ g, int npairs, in
     while (need) {
       u32x4 x[CH];
 #pragma unroll
-      for (int j = 0; j < CH; ++j)
+      for (int j = 0; j < CH; ++j) {
+        x[j] = u32x4{0u, 0u, 0u, 0u};  // (defined on the paths that skip the load: the wait statement reads every x[j])
         if ((need >> j) & 1u) x[j] = ld_gran2(g + 2 * (gt + 256 * (j0 + j)));  // only what has not arrived yet
-      ld_wait();
+      }
+      ld_wait<CH>(x);
 #pragma unroll
       for (int j = 0; j < CH; ++j) {
-        asm volatile("" : "+v"(x[j]));
         if (((need >> j) & 1u) && x[j][1] == rt.tag && x[j][3] == rt.tag) {
           sink(2 * (gt + 256 * (j0 + j)), x[j][0]);
           sink(2 * (gt + 256 * (j0 + j)) + 1, x[j][2]);
@@ -1198,7 +1224,16 @@ __global__ __launch_bounds__(1024) void decode_engine_kernel(EngArgs a) {
               best = sv[w];
               bi = si[w];
             }
-          sampler_commit(a.samp, b, bi, si, k_pre, unf_pre);
+          // A gather lane that gave up keeps the sentinel id: with the abort word set every lane of this workgroup may have
+          // (all 256 candidates dead).  Nothing is committed then - no id, no seen-bit, no embedding row from an id outside
+          // the vocabulary - the abort word is (re)raised and the host fails this generation (model_gpt.hip engine_check).
+          if (bi < 0 || bi >= a.V) {
+            __hip_atomic_store(a.ctr + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            si[0] = a.samp.stop;
+            si[1] = -1;  // sampler_next_embedding: nothing to write
+          } else {
+            sampler_commit(a.samp, b, bi, si, k_pre, unf_pre);
+          }
         }
         __syncthreads();
         sampler_next_embedding(a.samp, b, si, t);

@@ -231,6 +231,9 @@ struct Engine {
   int gpt_set_host_sampling(int on);
   int cond_per_row = 0;  // itts_gpt_set_cond_per_row: the cond passed to prefill holds one [latents, D] block per batch item
   int gpt_commit(const int32_t* tokens_host, hipStream_t s);
+  int gpt_beam_state(int32_t* ids_host, float* scores_host, int32_t* done_host, int* step_host, hipStream_t s);
+  int gpt_commit_beams(const float* pick_score_host, const int32_t* pick_tok_host, const int32_t* pick_beam_host, hipStream_t s);
+  BeamArgs beam_args(const float* lg_in, bool typical) const;
   int forced_input = 0;  // the forced tokens are HF `input_tokens`: token k sits at mel position k + 1 (model.py:141-144)
   int gpt_set_typical(float mass);
   int gpt_set_beam_sample(int num_beams, int top_k, float top_p, float temperature, const float* uniforms_host, long n);

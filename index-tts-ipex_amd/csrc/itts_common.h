@@ -16,7 +16,9 @@ enum PadMode : int { PAD_ZERO = 0, PAD_REFLECT = 1 };
 inline size_t dtype_size(int dt) { return dt == F32 ? 4 : (dt == BF16 || dt == F16) ? 2 : dt == I32 ? 4 : dt == FP8 ? 1 : 8; }
 
 // status codes of the C ABI (0 ok, negative = error; message via itts_last_error())
-enum Status : int { OK = 0, E_INVALID = -1, E_HIP = -2, E_NOMEM = -3, E_STATE = -4, E_MISSING = -5 };
+// E_HANDOFF: an in-launch hand-off of the persistent decode engine (or of the fused q/k/v launch) timed out - the codes of this
+// generation are not valid, the engine object has switched to the launch path, the caller may simply generate again
+enum Status : int { OK = 0, E_INVALID = -1, E_HIP = -2, E_NOMEM = -3, E_STATE = -4, E_MISSING = -5, E_HANDOFF = -6 };
 
 void set_error(const std::string& msg);
 const char* last_error();

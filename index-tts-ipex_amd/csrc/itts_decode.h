@@ -118,9 +118,16 @@ struct BeamArgs {
   // (length penalty, is_done) counts from input_n and token k < input_n is fed at mel position k + 1
   const int* forced = nullptr;  // [B * nb][max_gen]
   int input_n = 0;
+  // host-side warpers + draws (top_k outside [1, 128] under beams): the 2 * nb picks of every batch item IN DRAW ORDER
+  // [B][2 * nb] - score (running beam score included), token, beam; beam_select_kernel then only sorts them and runs the
+  // BeamSearchScorer bookkeeping + the history / ancestry swap
+  const float* host_sc = nullptr;
+  const int* host_tok = nullptr;
+  const int* host_beam = nullptr;
 };
 constexpr int BEAM_MAX_CAND = 128;
 int beam_sample_step(const BeamArgs& a, hipStream_t s);
+int beam_commit_step(const BeamArgs& a, hipStream_t s);  // host picks -> scorer bookkeeping (beam_select_kernel only)
 
 // TypicalLogitsWarper pre-pass (beam.hip): processed scores of every row -> out [rows, V] with the filtered ones at -inf
 struct TypicalArgs {

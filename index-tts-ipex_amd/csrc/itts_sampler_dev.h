@@ -21,7 +21,8 @@ __device__ __forceinline__ void sampler_commit(const SamplerArgs& a, int b, int 
       const int f = a.forced[(size_t)b * a.max_gen + k];
       choice = f >= 0 ? f : choice;
     }
-    const int tok = unf ? choice : a.stop;
+    int tok = unf ? choice : a.stop;
+    tok = tok < 0 ? 0 : (tok >= a.V ? a.V - 1 : tok);  // never index seen[] / emb[] outside the vocabulary
     a.ids[(size_t)b * a.max_gen + k] = tok;
     a.cur_tok[b] = tok;
     a.seen[(size_t)b * a.V + tok] = 1;

@@ -3,6 +3,8 @@
 // GPT2InferenceModel.forward (indextts/gpt/model.py:115-192,521-708); HF transformers 4.36.2 GPT2Model /
 // greedy_search semantics (not vendored; restated in oracle/gpt.py and pinned by tests/golden).
 #include <algorithm>
+#include <atomic>
+#include <cstdio>
 #include <cmath>
 #include <cstring>
 #include <mutex>
@@ -165,11 +167,16 @@ int Engine::ensure_decode_tiles(hipStream_t s) {
 bool Engine::engine_usable() const {
   const char* ev = getenv("ITTS_ENGINE");  // read per call: tests flip it inside one process
   const bool env_off = ev ? atoi(ev) == 0 : !ENG_DEFAULT_ON;
-  static const int ncu = [] {
-    int dev = 0, n = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0;
-    return n;
-  }();
+  // CU count of the device this call runs on (a process may drive engines on several ordinals, and a partitioned MI355X
+  // exposes fewer CUs on some of them): cached per ordinal, the same key EngineGate uses
+  static std::atomic<int> ncu_of[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return false;
+  int ncu = ncu_of[dev & 63].load(std::memory_order_relaxed);
+  if (ncu == 0) {
+    if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0) ncu = -1;
+    ncu_of[dev & 63].store(ncu, std::memory_order_relaxed);
+  }
   const itts_config& c = cfg;
   if ((env_off && !ds.eng_force) || ds.eng_off || ds.eng_failed || ncu != ENG_NCU) return false;
   if (ds.fuse && !ds.fuse_failed) return false;  // A/B switch of the fused projection + attention launch: a launch-path variant
@@ -317,8 +324,8 @@ int Engine::gpt_set_beams(int num_beams, int do_sample, int top_k, float top_p, 
     return OK;
   }
   ITTS_REQUIRE(num_beams <= 10, "gpt_set_beams: num_beams must be in [2, 10]");
-  if (do_sample) {
-    ITTS_REQUIRE(top_k >= 1 && top_k <= 128, "gpt_set_beams: top_k must be in [1, 128]");
+  if (do_sample && !ds.host_sample) {  // (host sampling: the caller warps and draws itself, any top_k - gpt_commit_beams)
+    ITTS_REQUIRE(top_k >= 1 && top_k <= 128, "gpt_set_beams: top_k must be in [1, 128] (wider: itts_gpt_set_host_sampling first)");
     ITTS_REQUIRE(top_p > 0.f && top_p <= 1.f && temperature > 0.f, "gpt_set_beams: need 0 < top_p <= 1 and temperature > 0");
     ITTS_REQUIRE(uniforms_host && n > 0, "gpt_set_beams: uniforms missing");
     sample_uniforms.assign(uniforms_host, uniforms_host + n);
@@ -451,7 +458,7 @@ int Engine::gpt_prefill(const float* cond_dev, const int32_t* text_ids_in, int B
     ITTS_HIP_CHECK(hipGetLastError());
   }
   if (engine_usable()) ITTS_TRY(ensure_engine_state(s));  // allocations must not happen inside the graph capture of the step
-  if (ds.do_sample || (nbeam > 1 && beam_do_sample)) {
+  if (ds.do_sample || (nbeam > 1 && beam_do_sample && !ds.host_sample)) {
     const size_t need_u = nbeam > 1 ? (size_t)max_gen * B_items * 2 * nbeam : (size_t)max_gen * B;
     ITTS_REQUIRE(sample_uniforms.size() >= need_u,
                  "gpt_prefill: sampling enabled but fewer uniforms than max_gen * B (* 2 * num_beams) were supplied");
@@ -471,8 +478,8 @@ int Engine::gpt_prefill(const float* cond_dev, const int32_t* text_ids_in, int B
   ds.use_forced = forced_n > 0;
   ds.input_n = forced_input ? forced_n : 0;
   if (ds.host_sample) {
-    ITTS_REQUIRE(forced_n == 0 && nbeam == 1 && !ds.do_sample, "gpt_prefill: host sampling excludes forced tokens, beams and the device sampler");
-    ITTS_HIP_CHECK(hipMemsetAsync(ds.forced, 0xFF, (size_t)B * max_gen * 4, s));  // -1: nothing forced yet
+    ITTS_REQUIRE(forced_n == 0 && !ds.do_sample, "gpt_prefill: host sampling excludes forced tokens and the device sampler");
+    if (nbeam == 1) ITTS_HIP_CHECK(hipMemsetAsync(ds.forced, 0xFF, (size_t)B * max_gen * 4, s));  // -1: nothing forced yet
   }
   if (ds.use_forced) {
     ITTS_REQUIRE(forced_B == B_items || forced_B == 1, "gpt_prefill: forced tokens were set for a different batch size");
@@ -588,10 +595,62 @@ int Engine::head_and_sample(hipStream_t s, bool have_logits, bool sampled) {
   return sample_from_logits(s);
 }
 
+// arguments of the beam kernels (beam_sample_step / beam_commit_step) from the decode state
+BeamArgs Engine::beam_args(const float* lg_in, bool typical) const {
+  const itts_config& c = cfg;
+  const int D = c.model_dim, V = c.number_mel_codes, B = ds.B;
+  BeamArgs ba;
+  ba.logits = lg_in;
+  ba.preprocessed = typical;
+  ba.do_sample = ds.beam_sample;
+  ba.length_penalty = ds.length_penalty;
+  ba.cand_sc = ds.cand_sc;
+  ba.cand_tok = ds.cand_tok;
+  ba.cand_n = ds.cand_n;
+  ba.V = V;
+  ba.max_gen = ds.max_gen;
+  ba.stop = c.stop_mel_token;
+  ba.suppress_stop = ds.suppress_stop;
+  ba.nb = ds.nb;
+  ba.B = B / ds.nb;
+  ba.top_k = ds.top_k;
+  ba.top_p = ds.top_p;
+  ba.temperature = ds.temperature;
+  ba.penalty = ds.penalty;
+  ba.start_tok = c.start_mel_token;
+  ba.fake_id = 1;  // prepare_gpt_inputs: fake ids are all 1 with last = start_mel_token (model.py:644-653)
+  ba.Smax = ds.Smax;
+  ba.uniforms = ds.uniforms;
+  ba.len = ds.len;
+  ba.cur_tok = ds.cur_tok;
+  ba.unfinished = ds.unfinished;
+  ba.ids = ds.beam_ids;
+  ba.anc = ds.anc;
+  ba.prefix_dev = ds.prefix_dev;
+  ba.beam_scores = ds.beam_scores;
+  ba.hyp_tok = ds.hyp_tok;
+  ba.hyp_score = ds.hyp_score;
+  ba.hyp_len = ds.hyp_len;
+  ba.hyp_order = ds.hyp_order;
+  ba.hyp_n = ds.hyp_n;
+  ba.hyp_worst = ds.hyp_worst;
+  ba.hyp_counter = ds.hyp_counter;
+  ba.done = ds.beam_done;
+  ba.h_next = ds.h;
+  ba.emb = gpt.mel_emb;
+  ba.pos = gpt.mel_pos;
+  ba.D = D;
+  ba.pos_rows = c.max_mel_tokens + 3;
+  ba.emb_bf16 = adt == BF16;
+  ba.forced = ds.use_forced ? ds.forced : nullptr;
+  ba.input_n = ds.use_forced ? ds.input_n : 0;
+  return ba;
+}
+
 // repetition penalty / argmax or the sampling / beam modes / bookkeeping on ds.logits [B][V]
 int Engine::sample_from_logits(hipStream_t s, bool sampled) {
   const itts_config& c = cfg;
-  const int D = c.model_dim, V = c.number_mel_codes, B = ds.B;
+  const int V = c.number_mel_codes, B = ds.B;
   ITTS_TRY(tap("logits0", ds.logits, F32, (int64_t)B * V, s));
   if (sampled) return OK;  // the persistent engine's in-launch greedy sampler committed this step's tokens
   if (ds.host_sample) return OK;  // the caller reads the logits, picks the tokens and commits them (gpt_commit)
@@ -623,51 +682,7 @@ int Engine::sample_from_logits(hipStream_t s, bool sampled) {
     lg_in = ds.scores2;
   }
   if (ds.nb > 1) {  // beam-sample: one workgroup per batch item over its nb rows
-    BeamArgs ba;
-    ba.logits = lg_in;
-    ba.preprocessed = typical;
-    ba.do_sample = ds.beam_sample;
-    ba.length_penalty = ds.length_penalty;
-    ba.cand_sc = ds.cand_sc;
-    ba.cand_tok = ds.cand_tok;
-    ba.cand_n = ds.cand_n;
-    ba.V = V;
-    ba.max_gen = ds.max_gen;
-    ba.stop = c.stop_mel_token;
-    ba.suppress_stop = ds.suppress_stop;
-    ba.nb = ds.nb;
-    ba.B = B / ds.nb;
-    ba.top_k = ds.top_k;
-    ba.top_p = ds.top_p;
-    ba.temperature = ds.temperature;
-    ba.penalty = ds.penalty;
-    ba.start_tok = c.start_mel_token;
-    ba.fake_id = 1;  // prepare_gpt_inputs: fake ids are all 1 with last = start_mel_token (model.py:644-653)
-    ba.Smax = ds.Smax;
-    ba.uniforms = ds.uniforms;
-    ba.len = ds.len;
-    ba.cur_tok = ds.cur_tok;
-    ba.unfinished = ds.unfinished;
-    ba.ids = ds.beam_ids;
-    ba.anc = ds.anc;
-    ba.prefix_dev = ds.prefix_dev;
-    ba.beam_scores = ds.beam_scores;
-    ba.hyp_tok = ds.hyp_tok;
-    ba.hyp_score = ds.hyp_score;
-    ba.hyp_len = ds.hyp_len;
-    ba.hyp_order = ds.hyp_order;
-    ba.hyp_n = ds.hyp_n;
-    ba.hyp_worst = ds.hyp_worst;
-    ba.hyp_counter = ds.hyp_counter;
-    ba.done = ds.beam_done;
-    ba.h_next = ds.h;
-    ba.emb = gpt.mel_emb;
-    ba.pos = gpt.mel_pos;
-    ba.D = D;
-    ba.pos_rows = c.max_mel_tokens + 3;
-    ba.emb_bf16 = adt == BF16;
-    ba.forced = ds.use_forced ? ds.forced : nullptr;
-    ba.input_n = ds.use_forced ? ds.input_n : 0;
+    const BeamArgs ba = beam_args(lg_in, typical);
     return beam_sample_step(ba, s);
   }
   SamplerArgs sa = greedy_sampler_args(lg_in, typical);
@@ -1059,6 +1074,54 @@ int Engine::gpt_commit(const int32_t* tokens_host, hipStream_t s) {
   return st;
 }
 
+// Host-side beam_sample (the generate() kwargs the device beam sampler does not cover: top_k = 0 / None or > 128 with several
+// beams, infer.py:116-124 + webui.py:393-402).  The step stops behind the head GEMV (host sampling mode); the caller reads the
+// logits and gpt_beam_state (every beam's id history, running scores, the done flags), does log_softmax -> processors ->
+// warpers -> + beam scores -> the 2 * num_beams draws itself and hands the picks IN DRAW ORDER to gpt_commit_beams, which runs
+// BeamSearchScorer.process and the history / cache-ancestry swap on the device exactly as the device-sampled mode does
+// (beam_select_kernel with the draw skipped), so hypotheses, finalize and the engine's beam rows are shared.
+int Engine::gpt_beam_state(int32_t* ids_host, float* scores_host, int32_t* done_host, int* step_host, hipStream_t s) {
+  if (!ds.active || ds.nb <= 1) {
+    set_error("gpt_beam_state: needs an active beam generation");
+    return E_STATE;
+  }
+  int k = 0;
+  ITTS_HIP_CHECK(hipMemcpyAsync(&k, ds.len, 4, hipMemcpyDeviceToHost, s));
+  ITTS_HIP_CHECK(hipStreamSynchronize(s));
+  const size_t rows = (size_t)ds.B, mg = (size_t)ds.max_gen;
+  if (ids_host) ITTS_HIP_CHECK(hipMemcpyAsync(ids_host, ds.beam_ids + (size_t)(k & 1) * rows * mg, rows * mg * 4, hipMemcpyDeviceToHost, s));
+  if (scores_host) ITTS_HIP_CHECK(hipMemcpyAsync(scores_host, ds.beam_scores, rows * 4, hipMemcpyDeviceToHost, s));
+  if (done_host) ITTS_HIP_CHECK(hipMemcpyAsync(done_host, ds.beam_done, (size_t)(ds.B / ds.nb) * 4, hipMemcpyDeviceToHost, s));
+  ITTS_HIP_CHECK(hipStreamSynchronize(s));
+  if (step_host) *step_host = k;
+  return OK;
+}
+
+int Engine::gpt_commit_beams(const float* pick_score_host, const int32_t* pick_tok_host, const int32_t* pick_beam_host, hipStream_t s) {
+  if (!ds.active || !ds.host_sample || ds.nb <= 1) {
+    set_error("gpt_commit_beams: needs an active beam generation in host-sampling mode");
+    return E_STATE;
+  }
+  ITTS_REQUIRE(pick_score_host && pick_tok_host && pick_beam_host, "gpt_commit_beams: picks missing");
+  const int items = ds.B / ds.nb, nd = 2 * ds.nb;
+  for (int i = 0; i < items * nd; ++i) {
+    ITTS_REQUIRE(pick_tok_host[i] >= 0 && pick_tok_host[i] < cfg.number_mel_codes, "gpt_commit_beams: token id out of range");
+    ITTS_REQUIRE(pick_beam_host[i] >= 0 && pick_beam_host[i] < ds.nb, "gpt_commit_beams: beam index out of range");
+  }
+  // the candidate scratch of the device sampler is idle in this mode: [0, items * nd) of cand_sc / cand_tok, beams behind the tokens
+  static_assert(BEAM_MAX_CAND >= 4, "pick scratch fits the candidate scratch");
+  ITTS_HIP_CHECK(hipMemcpyAsync(ds.cand_sc, pick_score_host, (size_t)items * nd * 4, hipMemcpyHostToDevice, s));
+  ITTS_HIP_CHECK(hipMemcpyAsync(ds.cand_tok, pick_tok_host, (size_t)items * nd * 4, hipMemcpyHostToDevice, s));
+  ITTS_HIP_CHECK(hipMemcpyAsync(ds.cand_tok + (size_t)items * nd, pick_beam_host, (size_t)items * nd * 4, hipMemcpyHostToDevice, s));
+  BeamArgs ba = beam_args(ds.logits, false);
+  ba.host_sc = ds.cand_sc;
+  ba.host_tok = ds.cand_tok;
+  ba.host_beam = ds.cand_tok + (size_t)items * nd;
+  const int st = beam_commit_step(ba, s);
+  ITTS_HIP_CHECK(hipStreamSynchronize(s));  // the picks are the caller's buffers
+  return st;
+}
+
 int Engine::gpt_set_forced(const int32_t* ids_host, int B, int n) {
   forced_input = 0;
   if (n <= 0 || !ids_host) {
@@ -1189,7 +1252,7 @@ int Engine::engine_check(hipStream_t s) {
       ds.fuse_failed = 1;  // later generations take the two-launch path
       ITTS_HIP_CHECK(hipMemsetAsync(ds.fuse_err, 0, 4, s));
       set_error("in-launch q/k/v hand-off timed out (fused projection + attention disabled for this engine; the codes of this generation are not valid)");
-      return E_HIP;
+      return E_HANDOFF;
     }
   }
   if (!ds.eng_ctr) return OK;
@@ -1202,7 +1265,9 @@ int Engine::engine_check(hipStream_t s) {
   ITTS_HIP_CHECK(hipMemcpyAsync(ds.eng_ctr, ctr0, 8, hipMemcpyHostToDevice, s));
   ITTS_HIP_CHECK(hipStreamSynchronize(s));
   set_error("decode engine: an in-launch hand-off timed out (persistent engine disabled for this engine; the codes of this generation are not valid)");
-  return E_HIP;
+  fprintf(stderr, "[itts_hip] persistent decode engine: a hand-off wait gave up (another process or kernel held CUs of this GPU?); "
+                  "this engine object uses the five-launches-per-block decode path from now on\n");
+  return E_HANDOFF;
 }
 
 int Engine::gpt_status(int* steps, int* n_unf, hipStream_t s) {

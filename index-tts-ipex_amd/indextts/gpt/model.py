@@ -68,9 +68,11 @@ class UnifiedVoice:
                          **hf_generate_kwargs):
         """Mel codes [b, <= max_generate_length] (model.py:655-708).  HF `generate` kwargs are accepted: greedy search
         (do_sample=False), multinomial sampling (do_sample=True), beam-sample (do_sample=True, num_beams 2..10) and beam
-        search (do_sample=False, num_beams > 1) with top_k <= 128, top_p, temperature, repetition_penalty, length_penalty
-        and typical_sampling run on the device.  `input_tokens` [b or 1, n] (model.py:672-686): given mel tokens the
-        generation continues after; like the reference, the returned codes start after them."""
+        search (do_sample=False, num_beams > 1) with top_p, temperature, repetition_penalty, length_penalty and typical_sampling
+        in HF 4.36.2 semantics: top_k in [1, 128] entirely on the device, `top_k = 0 / None` (warper off) or > 128 with the warpers
+        and draws on the host over the whole vocabulary (one or several beams).  `input_tokens` [b or 1, n] (model.py:672-686):
+        given mel tokens the generation continues after; like the reference, the returned codes start after them - with
+        num_return_sequences > 1 as well (the reference's row expansion, see below)."""
         nrs = int(num_return_sequences)
         if nrs < 1:
             raise ValueError("num_return_sequences has to be >= 1")
@@ -85,8 +87,6 @@ class UnifiedVoice:
             # independently (GenerationMixin._expand_inputs_for_generation); greedy search with nrs > 1 is an error in HF too
             if not hf_generate_kwargs.get("do_sample", False):
                 raise ValueError("num_return_sequences has to be 1 when doing greedy search")
-            if input_tokens is not None:
-                raise NotImplementedError("num_return_sequences > 1 together with input_tokens")
         sample_kw = infer_core.sampling_kwargs(hf_generate_kwargs.get("do_sample", False), hf_generate_kwargs.get("num_beams", 1),
                                                hf_generate_kwargs.get("top_k", 50), hf_generate_kwargs.get("top_p", 1.0),
                                                hf_generate_kwargs.get("temperature", 1.0), typical_sampling, typical_mass,
@@ -95,19 +95,42 @@ class UnifiedVoice:
         ids = text_inputs.detach().cpu().numpy() if isinstance(text_inputs, torch.Tensor) else np.asarray(text_inputs)
         if ids.ndim == 1:
             ids = ids[None]
-        if nrs > 1 and nbeams <= 1:
-            ids = np.repeat(ids, nrs, axis=0)
-            if cond.shape[0] > 1:
-                cond = cond.repeat_interleave(nrs, 0)
+        it = None
+        if input_tokens is not None:
+            it = input_tokens.detach().cpu().numpy() if isinstance(input_tokens, torch.Tensor) else np.asarray(input_tokens)
+            it = np.atleast_2d(it).astype(np.int32)
         if cond.shape[0] not in (1, ids.shape[0]):
             raise ValueError(f"{cond.shape[0]} conditioning prompts for {ids.shape[0]} text rows")
+        if it is not None and nrs > 1:
+            # model.py:672-686: BEFORE generate() the reference repeats the text rows to num_return_sequences rows
+            # (`input_ids.repeat(nrs // b, 1)`) and the given tokens likewise; generate() then expands every one of those rows
+            # again (x nrs sampled copies, or x num_beams with nrs hypotheses returned per row): nrs * nrs sequences come back.
+            # Row j of the nrs pre-expansion rows continues tokens j % bt; its prefix embedding is text row j // (nrs // b)
+            # (store_mel_emb + repeat_interleave, model.py:131-139) while its attention mask is row j % b of the tiled masks -
+            # the same row only if b == 1 or every text row has the same number of valid tokens, which is required here.
+            b, bt = ids.shape[0], it.shape[0]
+            assert nrs % bt == 0, "The num_return_sequences must be divisible by the batch number of input_tokens"
+            assert nrs % b == 0, "The num_return_sequences must be divisible by the batch number of text_inputs"
+            valid = [int(((r != self.start_text_token) & (r != self.stop_text_token)).sum()) for r in ids]
+            if b > 1 and len(set(valid)) > 1:
+                raise ValueError("num_return_sequences > 1 with input_tokens and a padded text batch: the reference pairs the prefix of "
+                                 "one row with the attention mask of another (model.py:131-139 vs :680-683); pass rows of equal length")
+            row_of = [j // (nrs // b) for j in range(nrs)]
+            ids = ids[row_of]
+            it = it[[j % bt for j in range(nrs)]]
+            if cond.shape[0] > 1:
+                cond = cond[row_of]
+        if nrs > 1 and nbeams <= 1:
+            ids = np.repeat(ids, nrs, axis=0)
+            if it is not None and it.shape[0] > 1:
+                it = np.repeat(it, nrs, axis=0)
+            if cond.shape[0] > 1:
+                cond = cond.repeat_interleave(nrs, 0)
         max_gen = self.max_mel_tokens - 1 if max_generate_length is None else int(max_generate_length)
         rep = float(hf_generate_kwargs.get("repetition_penalty", 1.0) or 1.0)
         n_forced = 0
         with self._eng.lock:
-            if input_tokens is not None:
-                it = input_tokens.detach().cpu().numpy() if isinstance(input_tokens, torch.Tensor) else np.asarray(input_tokens)
-                it = np.atleast_2d(it).astype(np.int32)
+            if it is not None:
                 n_forced = it.shape[1]
                 self._eng.set_input_tokens(it)
             try:

@@ -14,8 +14,9 @@ Same constructor and methods (`extract_features`, `infer`, `infer_fast`, `set_gr
     do_sample=True, num_beams=3; up to 10 beams, per-beam cache ancestry instead of HF's per-step cache copy), beam search
     (do_sample=False, num_beams > 1), multinomial sampling (num_beams=1) and greedy - with top_k <= 128 / top_p /
     temperature / repetition_penalty / length_penalty and `typical_sampling` (TypicalLogitsWarper) in HF 4.36.2 semantics;
-    `top_k = 0 / None` (HF: TopK warper off) or > 128 with one beam is exact too - the token choice then runs on the host over
-    the whole vocabulary, one logits read-back per token (with several beams it is clamped to 128 with a warning).
+    `top_k = 0 / None` (HF: TopK warper off) or > 128 is exact too, with one beam or several - the warpers and draws then run on
+    the host over the whole vocabulary, one logits read-back per token (under beams BeamSearchScorer.process, the beam
+    re-ordering and finalize stay on the device).
     Draws come from a numpy Generator seeded from torch's global RNG, so `torch.manual_seed` makes a run reproducible
     (torch.multinomial's own stream cannot be reproduced on a device);
   * the text normaliser is built and loaded as in infer.py:69-71; its third-party written-form normalisers (`tn` /

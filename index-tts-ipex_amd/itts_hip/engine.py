@@ -213,7 +213,7 @@ class Engine:
 
     def set_beam_sample(self, num_beams: int, top_k: int = 30, top_p: float = 0.8, temperature: float = 1.0,
                         uniforms: Optional[np.ndarray] = None, do_sample: bool = True, length_penalty: float = 0.0,
-                        num_return_sequences: int = 1):
+                        num_return_sequences: int = 1, host: bool = False):
         """HF beam_sample (do_sample: the reference's default generate() mode, infer.py:116-124; uniforms
         [max_gen, B, 2 * num_beams] float32 in [0, 1)) or beam_search (not do_sample: deterministic) for the following
         generations.  num_beams <= 1 switches beams off.  num_return_sequences: the n best hypotheses per row (fetch
@@ -225,10 +225,11 @@ class Engine:
             return
         L.check(self.lib.itts_gpt_set_beam_returns(self.h, int(num_return_sequences)), "gpt_set_beam_returns")
         self._nret = int(num_return_sequences)
-        u = np.ascontiguousarray(uniforms, dtype=np.float32) if do_sample else None
+        dev_draws = do_sample and not host  # host: the caller warps and draws (any top_k), the library needs no uniforms
+        u = np.ascontiguousarray(uniforms, dtype=np.float32) if dev_draws else None
         L.check(self.lib.itts_gpt_set_beams(self.h, int(num_beams), int(bool(do_sample)), int(top_k), float(top_p), float(temperature),
-                                            float(length_penalty), u.ctypes.data_as(C.c_void_p) if do_sample else None,
-                                            u.size if do_sample else 0), "gpt_set_beams")
+                                            float(length_penalty), u.ctypes.data_as(C.c_void_p) if dev_draws else None,
+                                            u.size if dev_draws else 0), "gpt_set_beams")
         self._nb = int(num_beams)
 
     def set_forced(self, ids: Optional[np.ndarray]):
@@ -279,12 +280,30 @@ class Engine:
         or at max length.  num_beams > 1: HF beam_sample (do_sample; uniforms [max_gen, B, 2 * num_beams]) or beam_search
         (not do_sample) over num_beams beams per row; returns the best finalized hypothesis per row, or with
         num_return_sequences = n the n best of every row ([B * n, len], best first)."""
+        kw = dict(repetition_penalty=repetition_penalty, suppress_stop=suppress_stop, check_every=check_every, do_sample=do_sample,
+                  top_k=top_k, top_p=top_p, temperature=temperature, seed=seed, uniforms=uniforms, num_beams=num_beams,
+                  typical_mass=typical_mass, length_penalty=length_penalty, num_return_sequences=num_return_sequences)
+        try:
+            return self._generate_once(cond, text_ids, max_gen, **kw)
+        except L.HandoffTimeout as e:
+            # The persistent decode engine needs every CU of its GPU; a wait inside it gave up (another process or a long
+            # foreign kernel held CUs).  The library has switched this engine object to the launch path: redo the utterance
+            # there, once, in this process - same prefill, same uniforms / seed, so the same ids as an undisturbed run.
+            _warn_downgrade(e)
+            return self._generate_once(cond, text_ids, max_gen, **kw)
+
+    def _generate_once(self, cond, text_ids, max_gen, repetition_penalty, suppress_stop, check_every, do_sample, top_k, top_p,
+                       temperature, seed, uniforms, num_beams, typical_mass, length_penalty, num_return_sequences) -> np.ndarray:
         beams = num_beams > 1
         if num_return_sequences != 1 and not beams:
             raise ValueError("num_return_sequences > 1 without beams: repeat the rows (indextts/gpt/model.py does, as HF does)")
         nrow = np.asarray(text_ids).shape[0]
-        if do_sample and not beams and (not top_k or int(top_k) < 1 or int(top_k) > 128):
-            # HF: TopK warper off (top_k = 0 / None) or wider than the device sampler's 128 candidates - exact on the host
+        if do_sample and (not top_k or int(top_k) < 1 or int(top_k) > 128):
+            # HF: TopK warper off (top_k = 0 / None) or wider than the device samplers' 128 candidates - exact on the host
+            if beams:
+                return self._generate_host_beams(cond, text_ids, max_gen, repetition_penalty, suppress_stop, int(top_k or 0), top_p,
+                                                 temperature, seed, uniforms, typical_mass, num_beams, length_penalty,
+                                                 num_return_sequences)
             return self._generate_host_sampled(cond, text_ids, max_gen, repetition_penalty, suppress_stop, int(top_k or 0), top_p,
                                                temperature, seed, uniforms, typical_mass)
         typical = bool(typical_mass)
@@ -365,6 +384,56 @@ class Engine:
         finally:
             L.check(self.lib.itts_gpt_set_host_sampling(self.h, 0), "gpt_set_host_sampling")
         return out[:, :n]
+
+    def _generate_host_beams(self, cond, text_ids, max_gen, repetition_penalty, suppress_stop, top_k, top_p, temperature, seed,
+                             uniforms, typical_mass, num_beams, length_penalty, num_return_sequences) -> np.ndarray:
+        """HF beam_sample with the warpers and the draws on the host (infer_core.host_beam_step: any top_k, whole vocabulary),
+        BeamSearchScorer.process / beam re-ordering / finalize on the device (itts_gpt_commit_beams).  One logits + beam-state
+        read-back per token."""
+        from . import infer_core
+
+        ids_in = np.asarray(text_ids)
+        items, nb, nd = ids_in.shape[0], int(num_beams), 2 * int(num_beams)
+        if uniforms is None:
+            uniforms = np.random.default_rng(seed).random((max_gen, items, nd), dtype=np.float32)
+        u = np.ascontiguousarray(uniforms, dtype=np.float32).reshape(-1, items, nd)
+        stop, start = self.ccfg.stop_mel_token, self.ccfg.start_mel_token
+        hist = np.empty((items * nb, max_gen), dtype=np.int32)
+        scores = np.empty(items * nb, dtype=np.float32)
+        done = np.empty(items, dtype=np.int32)
+        step = C.c_int()
+        L.check(self.lib.itts_gpt_set_host_sampling(self.h, 1), "gpt_set_host_sampling")
+        try:
+            self.set_beam_sample(nb, top_k, top_p, temperature, None, do_sample=True, length_penalty=length_penalty,
+                                 num_return_sequences=num_return_sequences, host=True)
+            self.prefill(cond, text_ids, max_gen, repetition_penalty, suppress_stop)
+            while True:
+                L.check(self.lib.itts_gpt_beam_state(self.h, hist.ctypes.data_as(C.c_void_p), scores.ctypes.data_as(C.c_void_p),
+                                                     done.ctypes.data_as(C.c_void_p), C.byref(step), self._s()), "gpt_beam_state")
+                k = step.value
+                if k >= max_gen or done.all():
+                    break
+                lg = np.empty((items * nb, self.ccfg.number_mel_codes), dtype=np.float32)
+                L.check(self.lib.itts_gpt_fetch(self.h, None, lg.ctypes.data_as(C.c_void_p), self._s()), "gpt_fetch")
+                psc, ptok, pbeam = infer_core.host_beam_step(lg, hist, k, scores, done, nb, float(repetition_penalty), float(temperature),
+                                                             top_k, top_p, float(typical_mass or 0.0), u[k], stop, bool(suppress_stop),
+                                                             start)
+                L.check(self.lib.itts_gpt_commit_beams(self.h, psc.ctypes.data_as(C.c_void_p), ptok.ctypes.data_as(C.c_void_p),
+                                                       pbeam.ctypes.data_as(C.c_void_p), self._s()), "gpt_commit_beams")
+                if k + 1 >= max_gen:
+                    break
+                self.decode(1)
+            step2, _ = self.status()
+            codes = self.fetch()[:, :step2].astype(np.int64)
+            self._exit()
+        finally:
+            self.set_beam_sample(1)
+            L.check(self.lib.itts_gpt_set_host_sampling(self.h, 0), "gpt_set_host_sampling")
+        n = 0
+        for row in codes:
+            hit = np.nonzero(row == stop)[0]
+            n = max(n, int(hit[0]) + 1 if len(hit) else step2)
+        return codes[:, :n]
 
     def latent(self, cond: torch.Tensor, text_ids: np.ndarray, codes: np.ndarray) -> torch.Tensor:
         """-> latent [1, T, D] engine dtype."""
@@ -451,6 +520,16 @@ class Engine:
         L.check(self.lib.itts_dvae_decode(self.h, c.ctypes.data_as(C.c_void_p), B, T, out.data_ptr(), self._s()), "dvae_decode")
         self._exit()
         return out.transpose(1, 2)
+
+
+def _warn_downgrade(err):
+    import logging
+    import warnings
+
+    msg = ("itts_hip: the persistent decode engine timed out on a hand-off (one process per GPU is required, INTEGRATION.md); "
+           f"this engine now decodes on the five-launches-per-block path and the utterance is generated again: {err}")
+    logging.getLogger("itts_hip").warning(msg)
+    warnings.warn(msg, RuntimeWarning, stacklevel=3)
 
 
 def _dvae_code_len(T: int, layers: int) -> int:

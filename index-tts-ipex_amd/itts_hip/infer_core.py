@@ -83,10 +83,10 @@ def sampling_kwargs(do_sample, num_beams, top_k, top_p, temperature, typical_sam
       typical_sampling               the reference's TypicalLogitsWarper(typical_mass) behind the repetition penalty - a logits
                                      PROCESSOR in the reference (model.py:690-697), so greedy and beam search run it too
     Limits of the device samplers (the web UI offers num_beams 1..10 and top_k 0..100): num_beams <= 10; at most 128 kept
-    candidates per row.  top_k = 0 / None (HF: TopK warper off) or > 128 with ONE beam is exact all the same: the token choice
-    then runs on the host over the whole vocabulary (host_sample_step below, one logits read-back per token); with several
-    beams it is clamped to 128 with a warning.  The seed is drawn from torch's global RNG so that torch.manual_seed governs
-    the run as it does for the reference's torch.multinomial."""
+    candidates per row.  top_k = 0 / None (HF: TopK warper off) or > 128 is exact all the same: the token choice then runs
+    on the host over the whole vocabulary (host_sample_step / host_beam_step below, one logits read-back per token) - with
+    one beam or several.  The seed is drawn from torch's global RNG so that torch.manual_seed governs the run as it does for
+    the reference's torch.multinomial."""
     import warnings
 
     import torch
@@ -105,12 +105,8 @@ def sampling_kwargs(do_sample, num_beams, top_k, top_p, temperature, typical_sam
             kw["typical_mass"] = tm
         return kw
     k = int(top_k) if top_k else 0
-    if k < 1 or k > 128:
-        if nb > 1:
-            warnings.warn(f"itts_hip: top_k={top_k} is outside [1, 128] (with num_beams > 1); using 128", RuntimeWarning)
-            k = 128
-        else:
-            k = 0 if k < 1 else k  # one beam: exact on the host (Engine.generate takes the host-sampling path)
+    if k < 1:
+        k = 0  # HF: TopK warper off - exact on the host (Engine.generate takes the host-sampling path, with or without beams)
     p = 1.0 if top_p is None else float(top_p)
     return dict(do_sample=True, top_k=k, top_p=min(max(p, 1e-6), 1.0), temperature=float(temperature or 1.0), num_beams=nb,
                 typical_mass=tm, length_penalty=lp,
@@ -119,12 +115,18 @@ def sampling_kwargs(do_sample, num_beams, top_k, top_p, temperature, typical_sam
 
 # ---- host-side token choice (HF GenerationMixin.sample over the whole vocabulary) ----
 def host_distribution(scores: np.ndarray, seen_ids, penalty: float, temperature: float, top_k: int, top_p: float,
-                      typical_mass: float, stop: int, suppress_stop: bool):
+                      typical_mass: float, stop: int, suppress_stop: bool, min_keep: int = 1, log_softmax_first: bool = False,
+                      return_scores: bool = False):
     """One row of HF 4.36.2 `sample()`'s score pipeline, in the order generate() builds it for infer.py:116-124 /
     model.py:688-703: RepetitionPenaltyLogitsProcessor over every id seen so far (fake prefix id, start token, generated
     codes) -> [TypicalLogitsWarper] -> TemperatureLogitsWarper -> TopKLogitsWarper (off when top_k < 1) -> TopPLogitsWarper.
-    Returns (kept token ids in descending-score order - ties: lower id first -, un-normalised weights exp(s - s_max)).  fp32."""
+    Returns (kept token ids in descending-score order - ties: lower id first -, un-normalised weights exp(s - s_max)).  fp32.
+    Beams (beam_sample): log_softmax_first (the processors see log-probabilities), min_keep = 2 (min_tokens_to_keep of every
+    warper and of the typical filter, model.py:693-694); return_scores: the warped scores instead of the weights."""
     s = np.asarray(scores, dtype=np.float32).copy()
+    if log_softmax_first:
+        m = s.max()
+        s = (s - np.float32(m + np.float32(np.log(np.exp((s - m).astype(np.float32)).sum(dtype=np.float32))))).astype(np.float32)
     ids = np.fromiter(seen_ids, dtype=np.int64)
     if penalty != 1.0 and ids.size:
         v = s[ids]
@@ -132,23 +134,73 @@ def host_distribution(scores: np.ndarray, seen_ids, penalty: float, temperature:
     if suppress_stop:
         s[stop] = -np.inf
     if typical_mass and 0.0 < typical_mass < 1.0:
-        s = _typical_filter(s, float(typical_mass))
+        s = _typical_filter(s, float(typical_mass), min_keep)
     if temperature != 1.0:
         s = (s / np.float32(temperature)).astype(np.float32)
     keep = np.nonzero(np.isfinite(s))[0]
-    if top_k and top_k >= 1 and top_k < keep.size:
-        kth = np.partition(s[keep], keep.size - top_k)[keep.size - top_k]
+    kk = max(int(top_k), min_keep) if top_k and top_k >= 1 else 0  # TopKLogitsWarper: top_k = max(top_k, min_tokens_to_keep)
+    if kk and kk < keep.size:
+        kth = np.partition(s[keep], keep.size - kk)[keep.size - kk]
         keep = keep[s[keep] >= kth]  # ties with the k-th largest stay (HF compares against the k-th value)
     order = np.lexsort((keep, -s[keep].astype(np.float64)))
     idx = keep[order]
     e = np.exp((s[idx] - s[idx[0]]).astype(np.float32)).astype(np.float32)
     n = idx.size
     if top_p is not None and top_p < 1.0 and n > 1:
-        # ascending cumulative probability <= 1 - top_p is removed; the best token always stays (min_tokens_to_keep = 1)
+        # ascending cumulative probability <= 1 - top_p is removed; the best min_tokens_to_keep always stay
         z = np.float32(e.sum(dtype=np.float32))
         tail = np.cumsum((e[::-1] / z).astype(np.float32), dtype=np.float32)  # tail[i] = mass of the i + 1 smallest
         n -= int((tail[: n - 1] <= np.float32(1.0) - np.float32(top_p)).sum())
-    return idx[:n], e[:n]
+        n = min(max(n, min_keep), idx.size)
+    return (idx[:n], s[idx[:n]]) if return_scores else (idx[:n], e[:n])
+
+
+def host_beam_step(logits: np.ndarray, ids_hist: np.ndarray, k: int, beam_scores: np.ndarray, done: np.ndarray, nb: int,
+                   penalty: float, temperature: float, top_k: int, top_p: float, typical_mass: float, u: np.ndarray, stop: int,
+                   suppress_stop: bool, start_tok: int, fake_id: int = 1):
+    """One step of HF 4.36.2 `beam_sample` up to (not including) BeamSearchScorer.process, for every batch item, on the host:
+    per beam log_softmax -> RepetitionPenalty over the beam's own ids (the fake prompt id, the start token, its k generated
+    codes) -> [Typical] -> Temperature -> TopK -> TopP (min_tokens_to_keep = 2) -> + running beam score; the kept candidates
+    of an item's beams in flat (beam-major, token-ascending) order = next_token_scores.view(batch, beams * vocab); 2 * nb
+    draws without replacement as sequential inverse-CDF look-ups of the caller's uniforms u [items, 2 * nb] (the convention
+    of the device sampler, beam.hip beam_select_kernel: fp32 running sums in flat order).
+    logits [items * nb, V], ids_hist [items * nb, >= k], beam_scores [items * nb], done [items].
+    -> (scores, tokens, beams) each [items, 2 * nb], in DRAW order (itts_gpt_commit_beams sorts them and runs the scorer)."""
+    lg = np.asarray(logits, dtype=np.float32)
+    items = lg.shape[0] // nb
+    nd = 2 * nb
+    psc = np.zeros((items, nd), dtype=np.float32)
+    ptok = np.full((items, nd), stop, dtype=np.int32)
+    pbeam = np.zeros((items, nd), dtype=np.int32)
+    for bi in range(items):
+        if done[bi]:
+            continue
+        fs, ft, fb = [], [], []
+        for r in range(nb):
+            row = bi * nb + r
+            seen = {int(fake_id), int(start_tok)} | {int(t) for t in ids_hist[row, :k]}
+            idx, sc = host_distribution(lg[row], seen, penalty, temperature, top_k, top_p, typical_mass, stop, suppress_stop,
+                                        min_keep=2, log_softmax_first=True, return_scores=True)
+            o = np.argsort(idx, kind="stable")
+            fs.append((sc[o] + np.float32(beam_scores[row])).astype(np.float32))
+            ft.append(idx[o])
+            fb.append(np.full(idx.size, r, dtype=np.int32))
+        fs, ft, fb = np.concatenate(fs), np.concatenate(ft), np.concatenate(fb)
+        e = np.exp((fs - fs.max()).astype(np.float32)).astype(np.float32)
+        alive = np.ones(e.size, dtype=bool)
+        for j in range(nd):
+            c = np.cumsum(np.where(alive, e, np.float32(0.0)), dtype=np.float32)  # sequential fp32 sums; a dead entry adds 0.0 (exact)
+            target = np.float32(np.float32(u[bi, j]) * c[-1])
+            hit = np.nonzero(alive & (c >= target))[0]
+            live = np.nonzero(alive)[0]
+            if live.size == 0:
+                break  # fewer live candidates than picks (cannot happen with min_tokens_to_keep = 2): the stop-token defaults stay
+            pick = int(hit[0]) if hit.size else int(live[-1])
+            alive[pick] = False
+            psc[bi, j], ptok[bi, j], pbeam[bi, j] = fs[pick], ft[pick], fb[pick]
+        if live.size == 0:
+            psc[bi, j:] = -np.inf
+    return psc, ptok, pbeam
 
 
 def host_sample_step(logits: np.ndarray, seen: Sequence[set], penalty: float, temperature: float, top_k: int, top_p: float,
@@ -165,8 +217,9 @@ def host_sample_step(logits: np.ndarray, seen: Sequence[set], penalty: float, te
     return out
 
 
-def _typical_filter(s: np.ndarray, mass: float) -> np.ndarray:
-    """The reference's TypicalLogitsWarper (indextts/utils/typical_sampling.py:9-30, min_tokens_to_keep = 1) on one fp32 row."""
+def _typical_filter(s: np.ndarray, mass: float, min_keep: int = 1) -> np.ndarray:
+    """The reference's TypicalLogitsWarper (indextts/utils/typical_sampling.py:9-30) on one fp32 row; min_keep =
+    min_tokens_to_keep (2 under beams, model.py:693-694)."""
     m = s.max()
     z = np.exp((s - m).astype(np.float32)).astype(np.float32)
     normalized = ((s - m) - np.float32(np.log(z.sum(dtype=np.float32)))).astype(np.float32)
@@ -180,5 +233,8 @@ def _typical_filter(s: np.ndarray, mass: float) -> np.ndarray:
     cum = np.cumsum(eo / eo.sum(dtype=np.float32), dtype=np.float32)
     last = min(int((cum < np.float32(mass)).sum()), s.size - 1)
     out = s.copy()
-    out[order[shifted[order] > shifted[order][last]]] = -np.inf
+    remove = shifted[order] > shifted[order][last]
+    if min_keep > 1:
+        remove[:min_keep] = False
+    out[order[remove]] = -np.inf
     return out

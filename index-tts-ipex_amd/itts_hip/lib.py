@@ -83,6 +83,8 @@ _PROTOS = {
     "itts_gpt_set_host_sampling": (i32, [vp, i32]),
     "itts_gpt_set_cond_per_row": (i32, [vp, i32]),
     "itts_gpt_commit": (i32, [vp, vp, vp]),
+    "itts_gpt_beam_state": (i32, [vp, vp, vp, vp, C.POINTER(i32), vp]),
+    "itts_gpt_commit_beams": (i32, [vp, vp, vp, vp, vp]),
     "itts_gpt_set_typical": (i32, [vp, f32]),
     "itts_gpt_set_beams": (i32, [vp, i32, i32, i32, f32, f32, f32, vp, i64]),
     "itts_gpt_set_beam_sample": (i32, [vp, i32, i32, f32, f32, vp, i64]),
@@ -127,7 +129,17 @@ def load():
     return lib
 
 
+E_HANDOFF = -6  # include/itts_hip.h ITTS_E_HANDOFF
+
+
+class HandoffTimeout(RuntimeError):
+    """A hand-off wait inside the persistent decode engine gave up: this generation's codes are not valid, the engine
+    object has switched to the launch path; generating again is safe (Engine.generate does it once)."""
+
+
 def check(status: int, what: str = ""):
     if status != 0:
         msg = load().itts_last_error().decode("utf-8", "replace")
+        if status == E_HANDOFF:
+            raise HandoffTimeout(f"libitts_hip {what} failed ({status}): {msg}")
         raise RuntimeError(f"libitts_hip {what} failed ({status}): {msg}")

@@ -73,11 +73,13 @@ def conformer_pe(max_len: int, d: int) -> np.ndarray:
     return pe.unsqueeze(0).numpy()
 
 
-def gpt_state_dict(cfg, seed: int = 1234, profile: str = "sharp") -> Dict[str, np.ndarray]:
+def gpt_state_dict(cfg, seed: int = 1234, profile: str = "sharp", stop_bias: float = 0.0) -> Dict[str, np.ndarray]:
     """profile "sharp" (default, every parity fixture): Q / K projections x 2.5, so attention is close to an arg-max and a
     one-token change flips greedy ids (SURVEY 8c sensitivity warning) - which also amplifies bf16 weight rounding to 0.1 - 0.3
     relative on logits / latents.  profile "smooth": Q / K gain 1 (score std ~ 1, soft attention), mel_head gain 1: the
-    conditioning of a trained checkpoint - the bf16 ACCURACY tests use it, so their bounds can be tight enough to fail."""
+    conditioning of a trained checkpoint - the bf16 ACCURACY tests use it, so their bounds can be tight enough to fail.
+    stop_bias: added to mel_head.bias[stop_mel_token] - the random checkpoint otherwise (almost) never emits the stop token, and
+    the eos bookkeeping of the decode loops (rows finishing at different steps, pad fill, beams finishing) would go untested."""
     assert profile in ("sharp", "smooth"), profile
     qk_gain = 2.5 if profile == "sharp" else 1.0
     head_gain = 3.0 if profile == "sharp" else 1.0
@@ -150,7 +152,12 @@ def gpt_state_dict(cfg, seed: int = 1234, profile: str = "sharp") -> Dict[str, n
     b.ln("final_norm", D)
     b.lin("text_head", g["number_text_tokens"] + 1, D)
     b.lin("mel_head", g["number_mel_codes"], D, gain=head_gain)
-    return b.build()
+    sd = b.build()
+    if stop_bias:
+        hb = np.array(sd["mel_head.bias"], dtype=np.float32, copy=True)
+        hb[g["stop_mel_token"]] += np.float32(stop_bias)
+        sd["mel_head.bias"] = hb
+    return sd
 
 
 def bigvgan_state_dict(cfg, seed: int = 1234) -> Dict[str, np.ndarray]:

@@ -39,11 +39,11 @@ def tt(sd):
     return {k: torch.from_numpy(np.array(v)) for k, v in sd.items()}
 
 
-def build_ref_gpt(cfg, seed, profile="sharp"):
+def build_ref_gpt(cfg, seed, profile="sharp", stop_bias=0.0):
     from indextts.gpt.model import UnifiedVoice
 
     m = UnifiedVoice(**cfg.gpt)
-    sd = tt(synth.gpt_state_dict(cfg, seed, profile=profile))
+    sd = tt(synth.gpt_state_dict(cfg, seed, profile=profile, stop_bias=stop_bias))
     ref_sd = m.state_dict()
     assert set(sd) == set(ref_sd), (sorted(set(sd) ^ set(ref_sd))[:10])
     for k in sd:
@@ -118,6 +118,7 @@ def ref_greedy(gpt, cond_mel, text, max_gen, rep=10.0, n_trace=None, suppress_eo
     unfinished = torch.ones(b, dtype=torch.long)
     logits_trace = []
     margins = []
+    stop_gaps = []
     step = 0
     while True:
         inp = ids if past is None else ids[:, -1:]
@@ -137,6 +138,8 @@ def ref_greedy(gpt, cond_mel, text, max_gen, rep=10.0, n_trace=None, suppress_eo
             scores = typical(ids, scores)
         top2 = torch.topk(scores, 2, dim=-1).values
         margins.append((top2[:, 0] - top2[:, 1]).clone())
+        if suppress_eos:  # how far the stop logit is below the winner (calibrates synth's stop_bias for the eos fixtures)
+            stop_gaps.append((top2[:, 0] - logits[:, stop]).clone())
         step += 1
         nxt = torch.argmax(scores, dim=-1)
         nxt = nxt * unfinished + stop * (1 - unfinished)
@@ -146,11 +149,12 @@ def ref_greedy(gpt, cond_mel, text, max_gen, rep=10.0, n_trace=None, suppress_eo
         if unfinished.max() == 0 or ids.shape[-1] >= s + 1 + n_in + max_gen:
             break
     ref_greedy.last_margins = torch.stack(margins, 1)
+    ref_greedy.last_stop_gaps = torch.stack(stop_gaps, 1) if stop_gaps else None
     return ids[:, s + 1 + n_in:], torch.stack(logits_trace, 1), conds, emb, mask[:, : s + 1]
 
 
 def ref_beam_sample(gpt, cond_mel, text, max_gen, uniforms, nb=3, top_k=30, top_p=0.8, temperature=1.0, rep=10.0,
-                    length_penalty=0.0, typical_mass=0.0, do_sample=True, input_tokens=None):
+                    length_penalty=0.0, typical_mass=0.0, do_sample=True, input_tokens=None, prebuilt=None, nret=1):
     """Hand-rolled HF-4.36.2 `beam_sample` over the reference's own GPT2InferenceModel.forward / _reorder_cache with the
     INSTALLED transformers logits processors / warpers (min_tokens_to_keep = 2 under beams) and the BeamSearchScorer
     restatement of oracle/hf_beam.py; torch.multinomial is replaced by the shared-uniform sequential draw."""
@@ -160,14 +164,21 @@ def ref_beam_sample(gpt, cond_mel, text, max_gen, uniforms, nb=3, top_k=30, top_
     from oracle import hf_beam
 
     stop = gpt.stop_mel_token
-    lens = torch.tensor([cond_mel.shape[-1]])
-    conds = gpt.get_conditioning(cond_mel, lens)
-    ids, emb, mask = gpt.prepare_gpt_inputs(conds, text)
-    gpt.inference_model.store_mel_emb(emb)
-    s = emb.shape[1]
-    b = ids.shape[0]
     V = gpt.number_mel_codes
     n_in = 0
+    if prebuilt is not None:
+        # (ids, mask) exactly as the reference's inference_speech handed them to generate() (captured by a stub generate: the
+        # row expansion of model.py:672-686 is the reference's own code); store_mel_emb has been called by inference_speech
+        ids, mask = prebuilt
+        s = ids.shape[1] - 1
+        b = ids.shape[0]
+    else:
+        lens = torch.tensor([cond_mel.shape[-1]])
+        conds = gpt.get_conditioning(cond_mel, lens)
+        ids, emb, mask = gpt.prepare_gpt_inputs(conds, text)
+        gpt.inference_model.store_mel_emb(emb)
+        s = emb.shape[1]
+        b = ids.shape[0]
     if input_tokens is not None:  # inference_speech, model.py:672-686: part of the decoder prompt of every beam
         it = input_tokens[None] if input_tokens.ndim == 1 else input_tokens
         it = it.repeat(b // it.shape[0], 1)
@@ -190,7 +201,7 @@ def ref_beam_sample(gpt, cond_mel, text, max_gen, uniforms, nb=3, top_k=30, top_
     if top_p is not None and top_p < 1.0:
         warpers.append(TopPLogitsWarper(top_p=top_p, min_tokens_to_keep=2))
     prompt_len = s + 1 + n_in
-    scorer = hf_beam.BeamSearchScorer(b, nb, length_penalty=length_penalty, max_length=prompt_len + max_gen)
+    scorer = hf_beam.BeamSearchScorer(b, nb, length_penalty=length_penalty, max_length=prompt_len + max_gen, num_beam_hyps_to_keep=nret)
     beam_scores = np.zeros(b * nb, dtype=np.float32)
     if not do_sample:  # beam_search initialisation
         beam_scores.reshape(b, nb)[:, 1:] = -1e9
@@ -498,6 +509,141 @@ def smooth_fixtures():
     save("smooth_decode_b6", text=t6, codes=c6, margins=ref_greedy.last_margins, top_idx0=top6.indices, top_val0=top6.values)
 
 
+EOS_STOP_BIAS = None  # set by eos_fixtures(); the committed value lives in the fixture (stop_bias)
+
+
+@torch.no_grad()
+def eos_fixtures():
+    """The SHIPPED decode loop: eos enabled, rows finishing at different steps (HF pads a finished row with the stop token,
+    greedy_search's unfinished_sequences; beams finish into BeamHypotheses).  The synthetic checkpoint never emits the stop
+    token on its own, so mel_head.bias[stop] is raised (synth stop_bias) by an amount calibrated HERE on the reference: the gap
+    between the winning score and the stop logit over 64 stop-suppressed steps of three ragged rows; the bias is chosen so
+    that the three rows stop at three different steps, each with >= 0.05 of head-room against a rounding flip.
+      smooth_eos_b3:     3 ragged rows, greedy, eos enabled: ids [3, n] (pad = stop), per-row stop step, margins
+      smooth_eos_beam:   2 sentences x 3 beams, beam_sample (the reference's default kwargs) AND beam_search, eos enabled:
+                         finalized hypotheses [2, n]"""
+    cfg = icfg.indextts_1_5()
+    g = cfg.gpt
+    mel = torch.from_numpy(synth.prompt_mel(511, seed=7))
+    L = 105
+    pool_lens = [105, 80, 60, 95, 70, 100, 50, 88]
+    pool = torch.full((len(pool_lens), L), g.stop_text_token, dtype=torch.int32)  # pad_tokens_cat pads with the stop TEXT token (infer.py:316-318)
+    for r, n in enumerate(pool_lens):
+        pool[r, :n] = torch.from_numpy(synth.text_ids(n, 141 + r, g.number_text_tokens)).int()
+    print("[eos] calibrating stop_bias on the reference (smooth profile, stop suppressed, a pool of 8 ragged rows) ...")
+    gpt = build_ref_gpt(cfg, 1234, profile="smooth")
+    NS = 64
+    t0 = time.time()
+    cache = os.environ.get("ITTS_EOS_GAPS_CACHE", "")  # authoring convenience: the calibration pass takes a minute
+    if cache and os.path.exists(cache):
+        gaps = np.load(cache)
+    else:
+        ref_greedy(gpt, mel, pool, max_gen=NS, suppress_eos=True, n_trace=1)
+        gaps = ref_greedy.last_stop_gaps.numpy()  # [8, NS] winner - stop logit
+        if cache:
+            np.save(cache, gaps)
+    print(f"  {NS} steps in {time.time() - t0:.1f}s; gap min per row {gaps.min(1)}, median {np.median(gaps):.2f}")
+    # a bias d and three rows of the pool (the first two = the two sentences of the beam / drop-in tests, lengths 105 / 80 preferred)
+    # whose first step with gap < d differs by >= 6 steps, lies in [6, 58], with >= `room` of head-room at every step up to it
+    import itertools
+
+    found = []
+    room = 0.05
+    for cand in np.sort(gaps.reshape(-1)):
+        d = float(cand) + 2 * room
+        first = {}
+        for r in range(gaps.shape[0]):
+            hit = np.nonzero(gaps[r] < d)[0]
+            if len(hit) and 3 <= hit[0] <= 60 and not np.any(np.abs(gaps[r, : int(hit[0]) + 1] - d) < room):
+                first[r] = int(hit[0])
+        for tri in itertools.combinations(sorted(first), 3):
+            st = [first[r] for r in tri]
+            found.append((min(abs(x - y) for i, x in enumerate(st) for y in st[i + 1:]), -tri[0], d, list(tri), st))
+    found.sort(reverse=True)  # the widest spacing between the three stop steps; ties: the pool's first row (105 text tokens) included
+    best = found[0][2:] if found and found[0][0] >= 6 else None
+    assert best is not None, "no stop_bias separates the rows"
+    stop_bias, sel, first = float(np.float32(best[0])), best[1], best[2]
+    t3 = pool[sel].clone()
+    lens = [pool_lens[r] for r in sel]
+    print(f"  stop_bias {stop_bias:.4f}: pool rows {sel} (text lengths {lens}) stop at steps {first}")
+    del gpt
+    gpt = build_ref_gpt(cfg, 1234, profile="smooth", stop_bias=stop_bias)
+    codes, lg, *_ = ref_greedy(gpt, mel, t3, max_gen=NS, n_trace=1)
+    stops = [int(np.nonzero(codes[r].numpy() == g.stop_mel_token)[0][0]) for r in range(3)]
+    assert stops == first, (stops, first)
+    assert codes.shape[1] == max(stops) + 1  # HF stops with the step in which the last row finishes
+    save("smooth_eos_b3", text=t3, text_lens=np.asarray(lens), stop_bias=np.float32(stop_bias), codes=codes, stop_steps=np.asarray(stops),
+         margins=ref_greedy.last_margins)
+    # beams: the reference's default generate() kwargs (infer.py:116-124) on a two-sentence text = 6 rows, and beam search
+    t2 = t3[:2].clone()
+    for tag, sample in (("sample", True), ("search", False)):
+        MG = 72
+        u = np.random.default_rng(23).random((MG, 2, 6), dtype=np.float32)
+        t0 = time.time()
+        out = ref_beam_sample(gpt, mel, t2, MG, u, nb=3, top_k=30, top_p=0.8, temperature=1.0, rep=10.0, length_penalty=0.0,
+                              do_sample=sample)
+        print(f"  beam_{tag} 2 x 3: {out.shape} in {time.time() - t0:.1f}s; stop positions "
+              f"{[int(np.argmax(out[r] == g.stop_mel_token)) if (out[r] == g.stop_mel_token).any() else -1 for r in range(2)]}")
+        save(f"smooth_eos_beam_{tag}", text=t2, stop_bias=np.float32(stop_bias), uniforms=u, codes=out)
+
+
+@torch.no_grad()
+def nrs_input_token_fixtures():
+    """`inference_speech(input_tokens=[2 rows], num_return_sequences=2)` (model.py:672-686): the reference repeats the text row
+    and the given tokens to num_return_sequences rows BEFORE generate(), which expands them again (x num_beams under beams, with
+    num_return_sequences hypotheses returned per row).  The expansion is the reference's own code: inference_speech is called
+    for real with `inference_model.generate` replaced by a stub that records what it was handed; the recorded (ids, mask) then go
+    through the hand-rolled beam search (the installed transformers generate() is not usable)."""
+    cfg = icfg.micro()
+    g = cfg.gpt
+    gpt = build_ref_gpt(cfg, 1234)
+    mel = torch.from_numpy(synth.prompt_mel(61, seed=7))
+    text = torch.from_numpy(synth.text_ids(11, 11, g.number_text_tokens)).view(1, 11).int()
+    base, *_ = ref_greedy(gpt, mel, text, max_gen=24)
+    given = torch.stack([base[0, :4].clone(), base[0, 4:8].clone()])  # two different continuations of one text
+    given[1, 1] = (int(given[1, 1]) + 3) % (g.number_mel_codes - 2)
+    cap = {}
+
+    def stub(inputs, **kw):
+        cap["inputs"], cap["kw"] = inputs.clone(), kw
+        return inputs
+
+    real = gpt.inference_model.generate
+    gpt.inference_model.generate = stub
+    try:
+        gpt.inference_speech(mel, text, input_tokens=given, num_return_sequences=2, max_generate_length=12, do_sample=False,
+                             num_beams=3, length_penalty=1.0, repetition_penalty=10.0)
+    finally:
+        gpt.inference_model.generate = real
+    ids, mask = cap["inputs"], cap["kw"]["attention_mask"]
+    assert cap["kw"]["num_return_sequences"] == 2 and ids.shape[0] == 2 and cap["kw"]["max_length"] == ids.shape[1] + 12
+    n_in = given.shape[1]
+    rows_tokens = ids[:, -n_in:].clone()  # what each pre-expansion row continues from
+    codes = ref_beam_sample(gpt, mel, text, 12, None, nb=3, do_sample=False, length_penalty=1.0, prebuilt=(ids, mask), nret=2)
+    assert codes.shape[0] == 4
+    save("micro_input_tokens_nrs", text=text, input_tokens=given, rows_tokens=rows_tokens, codes=codes[:, :], num_beams=3,
+         num_return_sequences=2, length_penalty=1.0, max_gen=12)
+
+
+@torch.no_grad()
+def host_beam_fixtures():
+    """beam_sample with the TopK warper OFF (`top_k = 0`, which infer.py:116-124 forwards verbatim and webui.py:393-402 offers) and
+    with top_k = 200: more candidates per beam than the device sampler's 128 - IndexTTS-1.5 sizes (V = 8194), smooth checkpoint
+    (logit std ~1: top_p 0.8 keeps thousands of tokens), 1 sentence x 3 beams, 20 steps; installed transformers warpers."""
+    cfg = icfg.indextts_1_5()
+    g = cfg.gpt
+    gpt = build_ref_gpt(cfg, 1234, profile="smooth")
+    mel = torch.from_numpy(synth.prompt_mel(511, seed=7))
+    text = torch.from_numpy(synth.text_ids(105, 151, g.number_text_tokens)).view(1, 105).int()
+    MG = 20
+    for tag, tk in (("topk0", 0), ("topk200", 200)):
+        u = np.random.default_rng(31).random((MG, 1, 6), dtype=np.float32)
+        t0 = time.time()
+        out = ref_beam_sample(gpt, mel, text, MG, u, nb=3, top_k=tk, top_p=0.8, temperature=1.0, rep=10.0, length_penalty=0.0)
+        print(f"  beam_sample {tag}: {out.shape} in {time.time() - t0:.1f}s")
+        save(f"smooth_beam_{tag}", text=text, uniforms=u, codes=out, top_k=tk, top_p=0.8, num_beams=3, max_gen=MG)
+
+
 @torch.no_grad()
 def fast_fixtures():
     """`infer_fast` (infer.py:332-537) on the micro config, greedy: 5 sentences, bucket size 2 -> length-sorted buckets,
@@ -678,6 +824,9 @@ if __name__ == "__main__":
     ap.add_argument("--smooth", action="store_true")
     ap.add_argument("--cond-batch", action="store_true")
     ap.add_argument("--typical", action="store_true")
+    ap.add_argument("--eos", action="store_true")
+    ap.add_argument("--nrs", action="store_true")
+    ap.add_argument("--host-beams", action="store_true")
     a = ap.parse_args()
     ref_import.install()
     torch.manual_seed(0)
@@ -691,6 +840,12 @@ if __name__ == "__main__":
         cond_batch_fixtures()
     if a.typical:
         typical_fixtures()
+    if a.eos:
+        eos_fixtures()
+    if a.nrs:
+        nrs_input_token_fixtures()
+    if a.host_beams:
+        host_beam_fixtures()
     if a.full:
         full_fixtures()
     if a.front:

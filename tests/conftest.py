@@ -29,7 +29,7 @@ def gold():
 @pytest.fixture(scope="session")
 def accuracy():
     """Measured accuracy numbers of the GPU parity tests (bf16 engine vs the reference fixtures ...), collected in
-    one dict and written to gpurun_out/r03_accuracy.json when the session ends (copied to profiles/ and committed)."""
+    one dict and written to gpurun_out/r04_accuracy.json when the session ends (copied to profiles/ and committed)."""
     import json
 
     rec = {}
@@ -37,5 +37,5 @@ def accuracy():
     if rec:
         out = os.path.join(ROOT, "gpurun_out")
         os.makedirs(out, exist_ok=True)
-        with open(os.path.join(out, "r03_accuracy.json"), "w") as f:
+        with open(os.path.join(out, "r04_accuracy.json"), "w") as f:
             json.dump(rec, f, indent=1, sort_keys=True)

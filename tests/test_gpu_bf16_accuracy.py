@@ -13,7 +13,9 @@ reference modules (oracle/make_golden.py --smooth, IndexTTS-1.5 sizes):
   * six different sentences decoded FREE-RUNNING as one batch on the MFMA path against the reference ids: a row may leave
     the reference sequence only at a step whose reference top-1 / top-2 margin is small (tests/padding_test.py:35-96 is the
     reference's own batched greedy flow).
-Measured values go to gpurun_out/r03_accuracy.json (committed under profiles/)."""
+  * BASELINE config 5 (fp8-e4m3 GPT weights, power-of-two row scales; bf16 activations / KV): the same teacher-forced top-8
+    logits and the latent against the fp32 reference - what the quantisation costs, with a bound that can fail.
+Measured values go to gpurun_out/r04_accuracy.json (committed under profiles/)."""
 import numpy as np
 import pytest
 import torch
@@ -166,3 +168,45 @@ def test_bf16_free_running_six_rows(eng16s, mel, gold, accuracy, path):
     for r in range(6):
         assert at[r] is None or at[r] < 0.04, f"row {r}: ids part at step {agree[r]} where the reference margin is {at[r]:.3f}"
     assert sum(agree) >= 6 * 8 and sorted(agree)[-2] >= 16, agree  # most rows follow the reference for a while
+
+
+# ---- BASELINE config 5: fp8-e4m3 GPT weights (per-row power-of-two scales), bf16 activations / KV ----
+# e4m3 keeps 3 mantissa bits: a weight moves by up to 2^-4 relative (bf16: 2^-9).  Measured in r04 (profiles/r04_accuracy.json);
+# the bounds are 2 x the measurement.
+BOUND_FP8 = 0.2
+BOUND_FP8_LATENT = 0.2
+
+
+@pytest.fixture(scope="module")
+def eng8s(sd_smooth):
+    return ieng.build_engine(CFG, "bf16", parts=("gpt",), state_dicts={"gpt": sd_smooth}, gpt_fp8="fp8")
+
+
+@pytest.mark.parametrize("nrows", [2, 20])
+def test_fp8_forced_logits(eng8s, mel, gold, control, accuracy, nrows):
+    """Teacher-forced on the reference ids, 2 rows (fp8 GEMV reader) and 20 rows (config 5's batch: fp8 fragment tiles on the
+    matrix cores): top-8 logits of the fp8-weight engine against the fp32 reference, up to S = 619."""
+    g = gold("smooth_decode_b1")
+    cond = eng8s.conditioning(mel)
+    lgs = forced_trace(eng8s, cond, g, nrows)
+    assert eng8s.decode_mode() == 0  # the persistent engine streams bf16 weights only
+    for k, lg in lgs.items():
+        for r in range(1, nrows):
+            assert np.array_equal(lg[r], lg[0]), (k, r)
+    res = top8_err(lgs, g)
+    accuracy[f"smooth_fp8_weights_forced_rows{nrows}_top8_logits_rel_rms_by_S"] = res
+    agree = [int(lgs[int(k)][0].argmax()) == int(g["top_idx"][i][0]) for i, k in enumerate(g["trace_steps"])]
+    accuracy[f"smooth_fp8_weights_forced_rows{nrows}_argmax_equal_to_reference"] = f"{sum(agree)} of {len(agree)} traced steps"
+    assert max(res.values()) < BOUND_FP8, res
+    early = np.mean([v for S, v in res.items() if S < 300])
+    late = np.mean([v for S, v in res.items() if S >= 400])
+    assert late < 1.5 * early + 0.02, (early, late)  # no growth with the sequence length
+
+
+def test_fp8_latent(eng8s, mel, gold, accuracy):
+    g = gold("smooth_decode_b1")
+    cond = eng8s.conditioning(mel)
+    lat = eng8s.latent(cond, g["text"].astype(np.int32), g["codes"][0, :480]).float().cpu().numpy()[0]
+    e = max(rms_rel(lat[:, :16], g["latent_sample"]), rms_rel(lat[g["latent_row_idx"]], g["latent_rows"]))
+    accuracy["smooth_fp8_weights_latent_T480_rel_rms"] = e
+    assert e < BOUND_FP8_LATENT, e

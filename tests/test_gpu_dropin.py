@@ -141,6 +141,36 @@ def test_input_tokens_with_beam_search_through_dropin(tts, gold):
     assert np.array_equal(out[:, :m], g["codes"][:, :m]), (out, g["codes"])
 
 
+def test_input_tokens_with_num_return_sequences_matches_reference(tts, gold):
+    """`inference_speech(input_tokens=[2 rows], num_return_sequences=2, num_beams=3)` (model.py:672-686): the reference repeats
+    text and tokens to nrs rows before generate(), which returns nrs hypotheses for each of them - 4 sequences.  The fixture's
+    row expansion was recorded from the reference's own inference_speech (stubbed generate), the ids come from the hand-rolled
+    beam search over exactly those inputs."""
+    g = gold("micro_input_tokens_nrs")
+    mel = torch.from_numpy(gold("micro_conditioning")["mel"]).cuda()
+    out = tts.gpt.inference_speech(mel, torch.from_numpy(g["text"]), input_tokens=torch.from_numpy(g["input_tokens"]),
+                                   num_return_sequences=int(g["num_return_sequences"]), do_sample=False, num_beams=int(g["num_beams"]),
+                                   repetition_penalty=10.0, length_penalty=float(g["length_penalty"]),
+                                   max_generate_length=int(g["max_gen"])).cpu().numpy()
+    assert out.shape[0] == 4
+    m = min(out.shape[1], g["codes"].shape[1])
+    assert np.array_equal(out[:, :m], g["codes"][:, :m]), (out, g["codes"])
+    stop = CFG.gpt.stop_mel_token
+    assert (out[:, m:] == stop).all() and (g["codes"][:, m:] == stop).all()
+    # one beam, sampling: nrs pre-expansion rows (tokens row j % 2) x nrs sampled copies each = 4 rows - equal to the explicit
+    # call on the expanded rows (same seed -> same uniforms), i.e. the expansion is the reference's (rows_tokens, recorded from it)
+    kw = dict(do_sample=True, top_k=30, top_p=0.8, temperature=1.0, num_beams=1, repetition_penalty=10.0, max_generate_length=10)
+    torch.manual_seed(5)
+    a = tts.gpt.inference_speech(mel, torch.from_numpy(g["text"]), input_tokens=torch.from_numpy(g["input_tokens"]),
+                                 num_return_sequences=2, **kw).cpu().numpy()
+    rows_tok = np.repeat(g["rows_tokens"], 2, axis=0)
+    torch.manual_seed(5)
+    b = tts.gpt.inference_speech(mel, torch.from_numpy(np.repeat(g["text"], 4, axis=0)), input_tokens=torch.from_numpy(rows_tok), **kw).cpu().numpy()
+    assert a.shape[0] == 4 and np.array_equal(a, b)
+    with pytest.raises(AssertionError, match="divisible"):
+        tts.gpt.inference_speech(mel, torch.from_numpy(g["text"]), input_tokens=torch.from_numpy(g["input_tokens"]), num_return_sequences=3, **kw)
+
+
 def test_padding_test_through_dropin(tts, gold):
     """tests/padding_test.py flow through `tts.gpt.inference_speech` with its kwargs."""
     g1, g5 = gold("micro_decode_b1"), gold("micro_decode_b5")

@@ -182,22 +182,40 @@ def test_engine_status_reports_no_timeout(eng16, cond):
 
 def test_engine_timeout_is_reported_and_the_launch_path_takes_over(cond, monkeypatch):
     """Failure detection: every in-launch wait is bounded by a wall clock (20 ms).  With the bound forced to 10 ns every
-    hand-off gives up, the launch drains, the abort word is set: status() / fetch() raise, the engine object disables its
-    persistent engine and the next generation runs on the five-launches-per-block path with the right ids."""
+    hand-off gives up, the launch drains (the in-launch sampler commits NOTHING when its candidates are missing - no id outside
+    the vocabulary reaches the id buffer, the seen-bitmap or the embedding gather), the abort word is set: status() / fetch()
+    return ITTS_E_HANDOFF (lib.HandoffTimeout), the engine object disables its persistent engine, and Engine.generate redoes the
+    utterance once on the five-launches-per-block path with a logged RuntimeWarning - the caller gets the right ids."""
+    from itts_hip import lib as ilib
+
     eng = ieng.build_engine(CFG, "bf16", parts=("gpt",))
     text = synth.text_ids(105, 61, CFG.gpt.number_text_tokens).reshape(1, -1).astype(np.int32)
     eng.debug(no_engine=True)
     want = eng.generate(cond, text, 12, suppress_stop=True)
     monkeypatch.setenv("ITTS_ENGINE_TIMEOUT_TICKS", "1")
     eng.debug(engine=True, no_graph=True)
-    with pytest.raises(RuntimeError, match="hand-off timed out"):
-        eng.generate(cond, text, 12, suppress_stop=True)
+    # the C ABI level: the failed generation is reported, not returned
+    eng.prefill(cond, text, 12, 10.0, True)
+    eng.decode(11)
+    with pytest.raises(ilib.HandoffTimeout, match="hand-off timed out"):
+        eng.fetch()
+    eng._exit()
+    assert issubclass(ilib.HandoffTimeout, RuntimeError)
+    # the product level: a second engine object, same forced timeout - generate() downgrades, warns and returns the right ids
+    eng2 = ieng.build_engine(CFG, "bf16", parts=("gpt",))
+    eng2.debug(engine=True, no_graph=True)
+    with pytest.warns(RuntimeWarning, match="persistent decode engine timed out"):
+        got2 = eng2.generate(cond, text, 12, suppress_stop=True)
+    assert eng2.decode_mode() == 0 and np.array_equal(got2, want)
+    ids_ok = (got2 >= 0) & (got2 < CFG.gpt.number_mel_codes)
+    assert ids_ok.all()
     monkeypatch.delenv("ITTS_ENGINE_TIMEOUT_TICKS")
     eng.debug(engine=True)
     got = eng.generate(cond, text, 12, suppress_stop=True)
     assert eng.decode_mode() == 0  # disabled for this engine object after the failure
     assert np.array_equal(got, want)
     eng.debug()
+    eng2.debug()
 
 
 def test_two_engine_objects_interleaved_on_one_device(eng16, cond):

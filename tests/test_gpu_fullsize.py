@@ -102,7 +102,7 @@ def test_full_bigvgan(eng32, eng16, mel, gold):
     r16 = rms_rel(wav16, g["wav"])
     print(f"full-size vocoder waveform rel-RMS error: fp32 {r32:.2e}, bf16 {r16:.3f}")
     assert r32 < 1e-3  # stated fp32 waveform RMS tolerance (north_star)
-    assert r16 < 0.15
+    assert r16 < 4e-2  # r03 measured 1.6e-2; the control-based bound (2 x fp32-on-rounded-weights + 2e-3) is in test_gpu_longrun.py
 
 
 def test_full_roundtrip_properties_bf16(eng16, mel):

@@ -273,3 +273,61 @@ def test_host_typical_filter_matches_reference_subclass():
         got = infer_core._typical_filter(scores, mass)
         want = base(mass=mass, min_tokens_to_keep=1)(torch.zeros(1, 1, dtype=torch.long), torch.from_numpy(scores)[None].clone())[0].numpy()
         assert np.array_equal(np.isfinite(got), np.isfinite(want)), (V, mass)
+
+
+@pytest.mark.parametrize("V", [66, 8194])
+@pytest.mark.parametrize("cfg", [(0, 0.8, 1.0), (200, 0.9, 0.7), (0, 1.0, 1.0), (30, 0.8, 1.0)])
+def test_host_beam_step_matches_hf_processors_and_the_oracle_draw(V, cfg):
+    """The product's HOST beam_sample step (itts_hip.infer_core.host_beam_step: beams with `top_k = 0 / None` or > 128) against
+    what oracle/make_golden.ref_beam_sample runs per step: torch.log_softmax -> the INSTALLED RepetitionPenalty / Temperature /
+    TopK / TopP classes (min_tokens_to_keep = 2) -> oracle.hf_beam.beam_sample_step (flat order, sequential draws without
+    replacement, stable sort by score).  Two batch items x 3 beams, one item finished (its picks are ignored by the scorer)."""
+    from itts_hip import infer_core
+    from oracle import hf_beam
+
+    top_k, top_p, temp = cfg
+    nb, items, k = 3, 2, 6
+    rng = np.random.default_rng(V * 13 + top_k + int(top_p * 100))
+    logits = (rng.standard_normal((items * nb, V)) * 1.5).astype(np.float32)
+    hist = rng.integers(2, V - 1, (items * nb, 12)).astype(np.int32)
+    beam_scores = (-rng.random(items * nb) * 3).astype(np.float32)
+    u = rng.random((items, 2 * nb)).astype(np.float32)
+    stop, start = V - 1, V - 2
+    done = np.zeros(items, dtype=np.int32)
+    psc, ptok, pbeam = infer_core.host_beam_step(logits, hist, k, beam_scores, done, nb, 10.0, temp, top_k, top_p, 0.0, u, stop, False, start)
+    for bi in range(items):
+        cands = []
+        for r in range(nb):
+            row = bi * nb + r
+            ids = torch.tensor([[1, start] + [int(t) for t in hist[row, :k]]])
+            s = torch.log_softmax(torch.from_numpy(logits[row])[None], dim=-1)
+            s = tlp.RepetitionPenaltyLogitsProcessor(10.0)(ids, s.clone())
+            if temp != 1.0:
+                s = tlp.TemperatureLogitsWarper(temp)(ids, s)
+            if top_k:
+                s = tlp.TopKLogitsWarper(top_k=top_k, min_tokens_to_keep=2)(ids, s)
+            if top_p < 1.0:
+                s = tlp.TopPLogitsWarper(top_p=top_p, min_tokens_to_keep=2)(ids, s)
+            rowv = s[0].numpy()
+            keep = np.nonzero(np.isfinite(rowv))[0]
+            cands.append((keep, rowv[keep]))
+        ws, wt, wb = hf_beam.beam_sample_step(cands, beam_scores[bi * nb:(bi + 1) * nb], V, u[bi])
+        # the product hands the picks over in DRAW order; the scorer kernel sorts them (stable, descending) as the oracle does
+        order = sorted(range(2 * nb), key=lambda j: -float(psc[bi, j]))
+        assert np.array_equal(ptok[bi][order], wt) and np.array_equal(pbeam[bi][order], wb), (bi, cfg)
+        assert np.abs(psc[bi][order] - ws).max() < 2e-5
+    done[1] = 1
+    psc2, ptok2, _ = infer_core.host_beam_step(logits, hist, k, beam_scores, done, nb, 10.0, temp, top_k, top_p, 0.0, u, stop, False, start)
+    assert np.array_equal(ptok2[0], ptok[0]) and (ptok2[1] == stop).all()
+
+
+def test_host_typical_filter_min_keep_2_matches_reference_subclass():
+    from itts_hip import infer_core
+    from oracle import hf_beam
+
+    rng = np.random.default_rng(12)
+    for V, mass in ((66, 0.9), (8194, 0.2)):
+        scores = (rng.standard_normal(V) * 2).astype(np.float32)
+        got = infer_core._typical_filter(scores, mass, 2)
+        want = hf_beam.typical_filter(scores, mass, 2)  # pinned to the reference's class by test_typical_filter_matches_reference_class
+        assert np.array_equal(np.isfinite(got), np.isfinite(want)) and np.isfinite(got).sum() >= 2
