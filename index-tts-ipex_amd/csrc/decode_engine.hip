@@ -204,10 +204,10 @@ __device__ __forceinline__ void sweep2(const u64* __restrict__ g, int npairs, in
     while (need) {
       u32x4 x[CH];
 #pragma unroll
-      for (int j = 0; j < CH; ++j) {
-        x[j] = u32x4{0u, 0u, 0u, 0u};  // (defined on the paths that skip the load: the wait statement reads every x[j])
+      for (int j = 0; j < CH; ++j)
         if ((need >> j) & 1u) x[j] = ld_gran2(g + 2 * (gt + 256 * (j0 + j)));  // only what has not arrived yet
-      }
+      // (x[j] stays undefined where the load was skipped - it is not looked at below; giving it a value there would make the
+      // compiler MERGE two values behind the load statement, i.e. copy the destination register before the data has landed)
       ld_wait<CH>(x);
 #pragma unroll
       for (int j = 0; j < CH; ++j) {

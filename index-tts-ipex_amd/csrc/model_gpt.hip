@@ -1261,6 +1261,13 @@ int Engine::engine_check(hipStream_t s) {
   ITTS_HIP_CHECK(hipStreamSynchronize(s));
   if (!host[1]) return OK;
   ds.eng_failed = 1;
+  // The drained launches computed on hand-offs that never arrived: what they appended to the K/V cache is arbitrary bits, and the
+  // decode attention multiplies rows past the sequence end by p = 0 instead of selecting them away (ensure_decode_state) - a NaN
+  // or infinity left there would poison the next generation's first steps.  Back to the zero fill of a fresh allocation.
+  if (ds.kc && ds.vc && ds.cache_bytes) {
+    ITTS_HIP_CHECK(hipMemsetAsync(ds.kc, 0, ds.cache_bytes, s));
+    ITTS_HIP_CHECK(hipMemsetAsync(ds.vc, 0, ds.cache_bytes, s));
+  }
   const unsigned ctr0[2] = {host[0] ? host[0] : 1u, 0u};
   ITTS_HIP_CHECK(hipMemcpyAsync(ds.eng_ctr, ctr0, 8, hipMemcpyHostToDevice, s));
   ITTS_HIP_CHECK(hipStreamSynchronize(s));

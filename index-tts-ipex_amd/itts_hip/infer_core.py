@@ -123,35 +123,39 @@ def host_distribution(scores: np.ndarray, seen_ids, penalty: float, temperature:
     Returns (kept token ids in descending-score order - ties: lower id first -, un-normalised weights exp(s - s_max)).  fp32.
     Beams (beam_sample): log_softmax_first (the processors see log-probabilities), min_keep = 2 (min_tokens_to_keep of every
     warper and of the typical filter, model.py:693-694); return_scores: the warped scores instead of the weights."""
-    s = np.asarray(scores, dtype=np.float32).copy()
+    # The kept SET is computed with torch's CPU ops in the order and form of the HF 4.36.2 classes (sort -> softmax -> cumsum,
+    # topk's k-th value, log_softmax): with thousands of kept tokens the top-p boundary depends on the last bits of a
+    # cumulative sum, and the reference's arithmetic IS torch's - a numpy restatement parts from it once in a few hundred steps.
+    import torch
+
+    s = torch.from_numpy(np.asarray(scores, dtype=np.float32).copy())
+    V = s.shape[0]
     if log_softmax_first:
-        m = s.max()
-        s = (s - np.float32(m + np.float32(np.log(np.exp((s - m).astype(np.float32)).sum(dtype=np.float32))))).astype(np.float32)
-    ids = np.fromiter(seen_ids, dtype=np.int64)
-    if penalty != 1.0 and ids.size:
+        s = torch.log_softmax(s, dim=-1)
+    ids = torch.from_numpy(np.fromiter(seen_ids, dtype=np.int64))
+    if penalty != 1.0 and ids.numel():
         v = s[ids]
-        s[ids] = np.where(v < 0, v * np.float32(penalty), v / np.float32(penalty)).astype(np.float32)
+        s[ids] = torch.where(v < 0, v * float(penalty), v / float(penalty))  # RepetitionPenaltyLogitsProcessor
     if suppress_stop:
-        s[stop] = -np.inf
+        s[stop] = -float("inf")
     if typical_mass and 0.0 < typical_mass < 1.0:
-        s = _typical_filter(s, float(typical_mass), min_keep)
+        s = torch.from_numpy(_typical_filter(s.numpy(), float(typical_mass), min_keep))
     if temperature != 1.0:
-        s = (s / np.float32(temperature)).astype(np.float32)
+        s = s / float(temperature)  # TemperatureLogitsWarper
+    if top_k and top_k >= 1:  # TopKLogitsWarper: top_k = max(top_k, min_tokens_to_keep), ties with the k-th value stay
+        kk = min(max(int(top_k), min_keep), V)
+        s = s.masked_fill(s < torch.topk(s, kk)[0][-1], -float("inf"))
+    if top_p is not None and top_p < 1.0:  # TopPLogitsWarper
+        sorted_logits, sorted_idx = torch.sort(s, descending=False)
+        remove = sorted_logits.softmax(dim=-1).cumsum(dim=-1) <= (1 - float(top_p))
+        remove[-min_keep:] = False
+        s[sorted_idx[remove]] = -float("inf")
+    s = s.numpy()
     keep = np.nonzero(np.isfinite(s))[0]
-    kk = max(int(top_k), min_keep) if top_k and top_k >= 1 else 0  # TopKLogitsWarper: top_k = max(top_k, min_tokens_to_keep)
-    if kk and kk < keep.size:
-        kth = np.partition(s[keep], keep.size - kk)[keep.size - kk]
-        keep = keep[s[keep] >= kth]  # ties with the k-th largest stay (HF compares against the k-th value)
     order = np.lexsort((keep, -s[keep].astype(np.float64)))
     idx = keep[order]
     e = np.exp((s[idx] - s[idx[0]]).astype(np.float32)).astype(np.float32)
     n = idx.size
-    if top_p is not None and top_p < 1.0 and n > 1:
-        # ascending cumulative probability <= 1 - top_p is removed; the best min_tokens_to_keep always stay
-        z = np.float32(e.sum(dtype=np.float32))
-        tail = np.cumsum((e[::-1] / z).astype(np.float32), dtype=np.float32)  # tail[i] = mass of the i + 1 smallest
-        n -= int((tail[: n - 1] <= np.float32(1.0) - np.float32(top_p)).sum())
-        n = min(max(n, min_keep), idx.size)
     return (idx[:n], s[idx[:n]]) if return_scores else (idx[:n], e[:n])
 
 

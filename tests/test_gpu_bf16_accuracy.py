@@ -171,10 +171,11 @@ def test_bf16_free_running_six_rows(eng16s, mel, gold, accuracy, path):
 
 
 # ---- BASELINE config 5: fp8-e4m3 GPT weights (per-row power-of-two scales), bf16 activations / KV ----
-# e4m3 keeps 3 mantissa bits: a weight moves by up to 2^-4 relative (bf16: 2^-9).  Measured in r04 (profiles/r04_accuracy.json);
-# the bounds are 2 x the measurement.
-BOUND_FP8 = 0.2
-BOUND_FP8_LATENT = 0.2
+# e4m3 keeps 3 mantissa bits: a weight moves by up to 2^-4 relative (bf16: 2^-9).  Measured in r04 (profiles/r04_accuracy.json):
+# top-8 logits 1.2e-2 .. 2.2e-2 relative RMS at 2 and at 20 rows (bf16 weights: 2.0e-3 .. 3.4e-3), flat in S, the arg-max equal to
+# the reference's at 10 of the 12 traced steps; latent T = 480 5.8e-2 (bf16: 7.1e-3).  The bounds are 2 x the measurement.
+BOUND_FP8 = 0.045
+BOUND_FP8_LATENT = 0.12
 
 
 @pytest.fixture(scope="module")
