@@ -32,11 +32,22 @@
 // Every spin is bounded (wall clock, s_memrealtime) and also ends on a chip-wide abort word; a workgroup that gave up
 // runs on without waiting, so the grid always drains.  The host reads the abort word at status / fetch.
 #include <cstdlib>
+#include <type_traits>
 
 #include "itts_decode.h"
 #include "itts_engine_kernel.h"
 #include "itts_sampler_dev.h"
 #include "decode_pinned.h"
+
+#ifndef ITTS_KV_PREFETCH
+#define ITTS_KV_PREFETCH 1  // attention workgroups touch their cache rows (one dword per 64 bytes) at the head of the block: the rows
+                            // are in this XCD's L2 when the register window is requested behind c_attn
+#endif
+#ifndef ITTS_EARLY_KV
+#define ITTS_EARLY_KV 0  // window pairs of the cache attention requested INTO REGISTERS at the head of the block (0: all behind c_attn).
+                         // Measured r04: 3 / 6 pairs early cost 12 spilled VGPRs, whose scratch reloads queue behind the HBM misses
+                         // (vmcnt is in-order): 0.4365 -> 0.457 / 0.473 ms per step.  The L2 prefetch below gets the lead time without registers.
+#endif
 
 namespace itts {
 namespace {
@@ -635,6 +646,70 @@ __global__ __launch_bounds__(1024) void decode_engine_kernel(EngArgs a) {
     const int ll = tl & 63;
     u64* __restrict__ G = a.gran + (size_t)l * LSTRIDE;
 
+    // ---- cache rows of this block's attention (workgroup (row gm, head gh)): the register window of every key split ----
+    // Requested at the HEAD of the block (a.early_kv), not behind c_attn: the rows of earlier positions do not depend on anything
+    // this block computes, and an HBM miss takes 1 - 2 us under load - behind c_attn it ended 0.8 - 1.5 us after the q / k / v
+    // hand-off had arrived (r03 timeline: q / k / v published at 1.8 us, polled at 3.8).  Who asks when: the compute waves at
+    // once (they wait for no memory operation in this phase); a gather wave behind its E1 sweep and the loader behind its wait
+    // for c_attn (vmcnt is in-order: a wait of theirs in front of these requests would hold the sweep / the first barrier for
+    // an HBM miss).  Same rows, same registers, same arithmetic as before.
+    constexpr int NIT_ = 3, NSPLIT_ = 4, SLOTS_ = 32, LPK_ = 8, VEC_ = 8, UNC_ = 2;
+    KVec kr[2 * NIT_], vr[2 * NIT_];
+    const int a_sp = wave >> 2, a_atid = (wave & 3) * 64 + ll, a_slot = a_atid / LPK_, a_sub = a_atid % LPK_;
+    const size_t a_lo = ((size_t)l * a.B * H + (size_t)(acu ? gm : 0) * H + gh) * a.Smax * DH;
+    const uint8_t* a_arow = nullptr;
+    size_t a_lbase = 0;  // (ANC) first row of this beam's batch item in block l
+    if constexpr (ANC) {
+      a_arow = a.anc + ((size_t)my_par * a.B + (acu ? gm : 0)) * a.Smax;
+      a_lbase = ((size_t)l * a.B + (size_t)((acu ? gm : 0) / a.nb) * a.nb) * H;
+    }
+    auto krow = [&](int j) -> const bf16_t* {
+      if constexpr (ANC) return a.kc + ((a_lbase + (size_t)min((int)a_arow[j], a.nb - 1) * H + gh) * a.Smax + j) * DH;
+      return a.kc + a_lo + (size_t)j * DH;
+    };
+    auto vrow = [&](int j) -> const bf16_t* {
+      if constexpr (ANC) return a.vc + ((a_lbase + (size_t)min((int)a_arow[j], a.nb - 1) * H + gh) * a.Smax + j) * DH;
+      return a.vc + a_lo + (size_t)j * DH;
+    };
+    auto kv_issue = [&](auto lo_c, auto hi_c) {  // window pairs [lo, hi)
+      constexpr int LO = decltype(lo_c)::value, HI = decltype(hi_c)::value;
+      // split = wave / 4 is an SGPR: the "was this pair of the window requested" tests are scalar branches that skip the dead
+      // half of the window (S = 380: 3 of 6 pairs per split) instead of computing it under a select
+#pragma unroll
+      for (int u = LO; u < HI; ++u)
+        if (u < UNC_ || (u * NSPLIT_ + a_sp) * SLOTS_ < my_pos + 1) {
+          const int j = min((u * NSPLIT_ + a_sp) * SLOTS_ + a_slot, a.Smax - 1);
+          kr[u].load(krow(j) + a_sub * VEC_);
+          vr[u].load(vrow(j) + a_sub * VEC_);
+        }
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    constexpr int EKV = ITTS_EARLY_KV;  // window pairs requested at the head of the block (the rest behind c_attn)
+    using Ic0 = std::integral_constant<int, 0>;
+    using IcE = std::integral_constant<int, EKV>;
+    using IcN = std::integral_constant<int, 2 * NIT_>;
+    // L2 prefetch of the cache rows [kv_start, S) of this (row, head): one dword per 64 bytes of every K and V row, by the compute
+    // waves (they wait for no memory operation in this phase, so nothing queues behind these misses), into ONE register that is
+    // never read - it only has to stay out of the allocator's hands until the loads have landed (kept alive to the head of P2,
+    // behind the q / k / v poll, 2 - 3 us later).  Default cache policy: the lines are to stay in L2 for the nontemporal window
+    // loads behind c_attn, which then take an L2 hit (~0.1 us) instead of an HBM miss (1 - 2 us under load).
+    unsigned pf_sink = 0;
+    if (ITTS_KV_PREFETCH && acu && cwv) {
+      const int c0 = cw * 64 + ll;  // 0 .. 703
+      for (int j = my_ks + c0; j < my_pos; j += NCW * 64) {
+        const char* pk = reinterpret_cast<const char*>(krow(j));
+        const char* pv = reinterpret_cast<const char*>(vrow(j));
+        asm volatile("global_load_dword %0, %1, off\n\tglobal_load_dword %0, %1, off offset:64\n\t"
+                     "global_load_dword %0, %2, off\n\tglobal_load_dword %0, %2, off offset:64"
+                     : "+v"(pf_sink)  // read-write: ONE live range over all iterations (a fresh "=v" per iteration would let the
+                                      // allocator recycle the previous iteration's register while its load is still in flight)
+                     : "v"(pk), "v"(pv)
+                     : "memory");
+      }
+    }
+    const bool early_kv = acu && EKV > 0;
+    if (early_kv && cwv) kv_issue(Ic0{}, IcE{});
+
     // ================= P1: residual stream -> LN1 -> c_attn =================
     if (gw) {
       if (l == 0) {
@@ -644,12 +719,14 @@ __global__ __launch_bounds__(1024) void decode_engine_kernel(EngArgs a) {
         wait_own(own_lds, NCW * phase, rt);
         sweep2<(NB * D / 2 + 255) / 256, false>(G - LSTRIDE + OH2, NB * D / 2, tl, rt, [&](int i, uint32_t v) { xf[i] = __uint_as_float(v); }, rt.first_delay);
       }
+      if (early_kv) kv_issue(Ic0{}, IcE{});
     } else if (lw) {
       if (HALFB && l > 0 && qcu) {  // the rest of this block's c_attn -> A: every compute wave is through the last block's mlp.c_proj
         wait_own(own_lds, NCW * phase, rt);
         dma_rows_at<QO - QA1, D>(w.wa, an0 + QA1, S0 + 256, ll);
       }
       dma_wait_keep<0>();  // c_attn (and, before it, c_proj) of this block
+      if (early_kv) kv_issue(Ic0{}, IcE{});
     }
     ENG_STAMP(0)
     __syncthreads();
@@ -701,43 +778,13 @@ __global__ __launch_bounds__(1024) void decode_engine_kernel(EngArgs a) {
 
     // ================= P2: cache attention of (row gm, head gh) =================
     if (acu) {
-      // K/V rows: requested before the q / k / v hand-off is polled, so the cache stream hides behind that hop (all 16
-      // waves; the thread <-> (split, slot, sub) mapping of decode_attn2_kernel<.., 256, 4>)
-      // split = wave / 4 is an SGPR: the "was this pair of the window requested" tests below are scalar branches that skip
-      // the dead half of the window (S = 380: 3 of 6 pairs per split) instead of computing it under a select
-      const int sp = wave >> 2, atid = (wave & 3) * 64 + ll, slot = atid / LPK, sub = atid % LPK;
-      KVec kr[2 * NIT], vr[2 * NIT];
-      const size_t lo = ((size_t)l * a.B * H + (size_t)gm * H + gh) * a.Smax * DH;
-      bf16_t* kb = a.kc + lo;
-      bf16_t* vb = a.vc + lo;
-      const uint8_t* arow = nullptr;
-      size_t lbase = 0;  // (ANC) first row of this beam's batch item in block l
-      if constexpr (ANC) {
-        arow = a.anc + ((size_t)my_par * a.B + gm) * a.Smax;
-        lbase = ((size_t)l * a.B + (size_t)(gm / a.nb) * a.nb) * H;
-      }
-      auto krow = [&](int j) -> const bf16_t* {
-        if constexpr (ANC) return a.kc + ((lbase + (size_t)min((int)arow[j], a.nb - 1) * H + gh) * a.Smax + j) * DH;
-        return kb + (size_t)j * DH;
-      };
-      auto vrow = [&](int j) -> const bf16_t* {
-        if constexpr (ANC) return a.vc + ((lbase + (size_t)min((int)arow[j], a.nb - 1) * H + gh) * a.Smax + j) * DH;
-        return vb + (size_t)j * DH;
-      };
-#pragma unroll
-      for (int u = 0; u < UNC; ++u) {
-        const int j = min((u * NSPLIT + sp) * SLOTS + slot, a.Smax - 1);
-        kr[u].load(krow(j) + sub * VEC);
-        vr[u].load(vrow(j) + sub * VEC);
-      }
+      // K/V rows of the register window: requested at the head of the block (early_kv) or - the r03 placement - here, before the
+      // q / k / v hand-off is polled (all 16 waves; the thread <-> (split, slot, sub) mapping of decode_attn2_kernel<.., 256, 4>)
+      const int sp = a_sp, atid = a_atid, slot = a_slot, sub = a_sub;
+      bf16_t* kb = a.kc + a_lo;
+      bf16_t* vb = a.vc + a_lo;
+      kv_issue(IcE{}, IcN{});  // what was not requested at the head of the block
       const int pos = my_pos, S = pos + 1, ks = my_ks;
-#pragma unroll
-      for (int u = UNC; u < 2 * NIT; ++u)
-        if ((u * NSPLIT + sp) * SLOTS < S) {
-          const int j = min((u * NSPLIT + sp) * SLOTS + slot, a.Smax - 1);
-          kr[u].load(krow(j) + sub * VEC);
-          vr[u].load(vrow(j) + sub * VEC);
-        }
       __builtin_amdgcn_sched_barrier(0);
       if (gw && tl < 3 * DH) {  // q / k / v of this (row, head): 192 granules, one per thread
         const u64* __restrict__ p = G + OQKV + (size_t)gm * 3 * D + (tl / DH) * D + gh * DH + tl % DH;
@@ -754,6 +801,7 @@ __global__ __launch_bounds__(1024) void decode_engine_kernel(EngArgs a) {
         }
       }
       ENG_STAMP(2)
+      if (ITTS_KV_PREFETCH && cwv) asm volatile("s_waitcnt vmcnt(0)" : "+v"(pf_sink) : : "memory");  // (the window loads are needed now anyway)
       __syncthreads();
       float qr[VEC];
       const bool own = atid < LPK && sp == 0;  // slot 0 of split 0 appends this step's row
