@@ -64,6 +64,9 @@ typedef struct {
   int force_simple; /* 1 = vector-ALU kernel even when the MFMA kernel supports the shape */
 } itts_gemm_args;
 int itts_gemm(const itts_gemm_args* args, itts_stream stream);
+/* Which kernel family itts_gemm takes for these arguments (no launch): 0 vector ALU, 1 register-staged MFMA, 2 LDS-DMA staged
+ * 128-wide tiles, 3 the 256 x 256 eight-phase kernel, 4 the LDS-tiled narrow conv.  Tests and tools/bench_gemm.py use it. */
+int itts_gemm_which(const itts_gemm_args* args);
 
 int itts_layernorm(void* y, int dtype_y, const void* x, int dtype_x, const float* gamma, const float* beta, int rows,
                    int D, float eps, itts_stream stream);

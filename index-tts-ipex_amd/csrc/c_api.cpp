@@ -12,14 +12,28 @@ struct itts_engine {
 };
 
 namespace itts {
-int gemm(const GemmArgs& g, int ta, int tw, int tc, hipStream_t s) {
+// which kernel family the dispatcher takes for a shape: 0 vector ALU, 1 register-staged MFMA (gemm_mfma), 2 LDS-DMA staged 128-wide
+// tiles (gemm_glds), 3 256 x 256 eight-phase (gemm_p8), 4 LDS-tiled narrow conv (conv_lds)
+int gemm_which(const GemmArgs& g, int ta, int tw, int tc) {
   static const bool no_conv_lds = getenv("ITTS_NO_CONV_LDS") != nullptr;
-  if (!no_conv_lds && conv_lds_supported(g, ta, tw, tc)) return conv_lds(g, s);
+  if (!no_conv_lds && conv_lds_supported(g, ta, tw, tc)) return 4;
   static const bool no_glds = getenv("ITTS_NO_GEMM_GLDS") != nullptr;  // A/B switch: the register-staged kernel everywhere
   const bool old = no_glds || getenv("ITTS_GEMM_FORCE_OLD") != nullptr;  // (per call: the parity test runs both on one shape)
-  if (!old && gemm_glds_supported(g, ta, tw, tc)) return gemm_glds(g, ta, tw, tc, s);
-  if (gemm_mfma_supported(g, ta, tw, tc)) return gemm_mfma(g, ta, tw, tc, s);
-  return gemm_simple(g, ta, tw, tc, s);
+  // ITTS_GEMM_P8=0: without the 256 x 256 eight-phase kernel (A/B, read per call)
+  const char* p8e = getenv("ITTS_GEMM_P8");
+  if (!old && !(p8e && atoi(p8e) == 0) && gemm_p8_supported(g, ta, tw, tc)) return 3;
+  if (!old && gemm_glds_supported(g, ta, tw, tc)) return 2;
+  if (gemm_mfma_supported(g, ta, tw, tc)) return 1;
+  return 0;
+}
+int gemm(const GemmArgs& g, int ta, int tw, int tc, hipStream_t s) {
+  switch (gemm_which(g, ta, tw, tc)) {
+    case 4: return conv_lds(g, s);
+    case 3: return gemm_p8(g, ta, tw, tc, s);
+    case 2: return gemm_glds(g, ta, tw, tc, s);
+    case 1: return gemm_mfma(g, ta, tw, tc, s);
+    default: return gemm_simple(g, ta, tw, tc, s);
+  }
 }
 }  // namespace itts
 
@@ -37,13 +51,7 @@ int itts_snake_aa_fwd(void* dst, const void* src, const float* up12, const float
   return E_INVALID;
 }
 
-int itts_gemm(const itts_gemm_args* a, itts_stream stream) {
-  (void)hipGetLastError();  // drop stale errors left by other HIP users (torch)
-  if (!a) {
-    set_error("itts_gemm: null args");
-    return E_INVALID;
-  }
-  GemmArgs g;
+static void to_gemm_args(const itts_gemm_args* a, GemmArgs& g) {
   g.A = a->A; g.W = a->W; g.C = a->C;
   g.M = a->M; g.N = a->N; g.Cin = a->Cin; g.taps = a->taps; g.lda = a->lda; g.ldc = a->ldc; g.T = a->T;
   g.dil = a->dil; g.pad_left = a->pad_left; g.pad_mode = a->pad_mode; g.in_up = a->in_up < 1 ? 1 : a->in_up;
@@ -51,8 +59,25 @@ int itts_gemm(const itts_gemm_args* a, itts_stream stream) {
   for (int i = 0; i < 8; ++i) g.phase_shift[i] = a->phase_shift[i];
   g.bias = a->bias; g.bias_bstride = a->bias_bstride; g.act = a->act; g.scale = a->scale; g.shift = a->shift;
   g.act2 = a->act2; g.R = a->R; g.ldr = a->ldr; g.alpha = a->alpha; g.ADD = a->ADD; g.ldadd = a->ldadd; g.beta = a->beta;
+}
+
+int itts_gemm(const itts_gemm_args* a, itts_stream stream) {
+  (void)hipGetLastError();  // drop stale errors left by other HIP users (torch)
+  if (!a) {
+    set_error("itts_gemm: null args");
+    return E_INVALID;
+  }
+  GemmArgs g;
+  to_gemm_args(a, g);
   if (a->force_simple) return gemm_simple(g, a->dtype_a, a->dtype_w, a->dtype_c, (hipStream_t)stream);
   return gemm(g, a->dtype_a, a->dtype_w, a->dtype_c, (hipStream_t)stream);
+}
+
+int itts_gemm_which(const itts_gemm_args* a) {
+  if (!a) return E_INVALID;
+  GemmArgs g;
+  to_gemm_args(a, g);
+  return a->force_simple ? 0 : gemm_which(g, a->dtype_a, a->dtype_w, a->dtype_c);
 }
 
 int itts_layernorm(void* y, int dtype_y, const void* x, int dtype_x, const float* gamma, const float* beta, int rows,

@@ -1,0 +1,318 @@
+// bf16 shift-GEMM, 256 x 256 tile, eight phases per two K-tiles (third generation of gemm_mfma.hip / gemm_glds.hip for the
+// LARGE regular shapes: BigVGAN AMPBlock convs at C >= 384, conv_pre, the GPT prefill / latent-pass projections at batch;
+// BigVGAN/models.py:20-81,149-161, gpt/model.py:521-589).  Same contract as gemm_mfma_kernel:
+//     C[m, n] = epilogue(sum_{tap, c} A[row(m, tap), c] * W[n, tap * Cin + c]).
+//
+// Structure (cdna_hip_programming.md section 5, "the 256^2 8-phase template", rebuilt for this contract):
+//   * one 512-thread workgroup per CU: 8 waves as 2 (M) x 4 (N), 128 x 64 outputs per wave = 8 x 4 accumulator tiles of
+//     v_mfma_f32_16x16x32_bf16 (128 accumulator VGPRs);
+//   * K is consumed 64 channels per K-tile; a K-tile is FOUR phases, one per quadrant (64 rows x 32 columns of the wave's
+//     output: 16 MFMAs), in the order (A0,B0) (A0,B1) (A1,B1) (A1,B0): a phase re-reads only the operand half that changed
+//     (12 / 4 / 8 / 4 ds_read_b128);
+//   * operands go global -> LDS by global_load_lds_dwordx4 (no VGPR staging) in 16 KB CHUNKS that follow the quadrants - chunk
+//     A-q0 holds rows 0..63 of BOTH wave rows (tile rows 0..63 and 128..191), B-q0 columns 0..31 of all four wave columns -
+//     so the first phase of a K-tile needs two chunks, the next three one each; rows are linear 128-byte lines, the bank
+//     swizzle lives on the SOURCE address (slot p of row r holds k-chunk p ^ ((r >> 1) & 7)), as in gemm_glds.hip;
+//   * two LDS buffers of four chunks (128 KiB); every phase stages ONE chunk, four to five phases ahead of its first read
+//     (tile t stages B0(t+1), B1(t+1), A1(t+1), A0(t+2)), and waits with a COUNTED s_waitcnt vmcnt(6): three chunks stay in
+//     flight across every barrier - the loop never drains the DMA queue;
+//   * two raw s_barriers per phase: [ds_read + stage + waits] barrier [16 MFMAs] barrier, and the second wave row runs half a
+//     phase behind the first (one extra barrier up front), so on every SIMD one wave multiplies while the other loads.
+// Hazards, by construction (g = 4 * tile + phase; a chunk staged in phase q is first read in phase q + 4 or q + 5):
+//   RAW  the wait that retires a chunk (vmcnt(6) at the end of the load segment of phase g - 1, by every wave, both wave rows)
+//        is followed by a barrier every wave passes before any wave's load segment of phase g;
+//   WAR  ds_reads are retired (lgkmcnt(0)) BEFORE the barrier that ends their load segment, and a chunk slot is re-staged no
+//        earlier than one phase after its last read (B0: read again in phase 3 of its tile, re-staged in phase 0 of the next).
+// Conv addressing, zero page for padded rows, epilogue and XCD-aware tile order as gemm_glds.hip.
+#include "itts_kernels.h"
+
+namespace itts {
+namespace {
+
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+__device__ uint4 g_zero_page8[16];  // 256 bytes of zeros: the source of out-of-range conv rows
+
+__device__ __forceinline__ int reflect_i8(int t, int T) {
+  if (t < 0) t = -t;
+  if (t >= T) t = 2 * (T - 1) - t;
+  return t;
+}
+
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                   (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
+}
+
+constexpr int PBM = 256, PBN = 256, PBK = 64, PROW = PBK * 2;  // 128-byte LDS rows
+constexpr int PCHUNK = 128 * PROW;                             // 16 KiB: one staging chunk
+constexpr int PBUF = 4 * PCHUNK;                               // one K-tile: A rows 0..255, then W rows 0..255
+
+template <typename TC>
+__global__ __launch_bounds__(512) void gemm_p8_kernel(GemmArgs g, int tiles_m, int tiles_n) {
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * PBUF];  // ONE LDS object
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  // ---- XCD-aware, bijective remap: consecutive logical ids (= the column tiles of one row tile) land on one XCD ----
+  const int nwg = gridDim.x, orig = blockIdx.x;
+  const int q8 = nwg >> 3, r8 = nwg & 7, xcd = orig & 7;
+  const int wgid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
+  const int tm = wgid / tiles_n, tn = wgid - tm * tiles_n;
+  const int m0 = tm * PBM, n0 = tn * PBN;
+  const bf16_t* __restrict__ A = (const bf16_t*)g.A;
+  const int K = g.taps * g.Cin;
+  const bf16_t* __restrict__ W = (const bf16_t*)g.W;
+  const int T = g.T > 0 ? g.T : g.M;
+  const int nk = g.taps * (g.Cin / PBK);
+  const int shift0 = g.phase_shift[0] - g.pad_left;
+
+  // ---- loader: a chunk is 128 rows; wave w fills chunk rows [16w, 16w + 16) with two instructions of 8 rows ----
+  const int lrow = lane >> 3, pslot = lane & 7;
+  int a_t[2][2], a_b[2][2];  // [A half][instruction]: time index inside the batch item (or far negative), first row of the item
+  int l_sw[2];               // logical k offset (elements) this lane fetches, per instruction (same for A and W rows)
+  const bf16_t* w_src[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int ci = wave * 16 + i * 8 + lrow;  // row inside the chunk
+    l_sw[i] = (pslot ^ ((ci >> 1) & 7)) * 8;  // ((tile row) >> 1) & 7 == ((chunk row) >> 1) & 7: the maps below add multiples of 16
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int ar = (ci >> 6) * 128 + h * 64 + (ci & 63);  // A-q(h): tile row
+      const int m = m0 + ar;
+      if (m < g.M) {
+        const int b = m / T;
+        a_t[h][i] = m - b * T;
+        a_b[h][i] = b * T;
+      } else {
+        a_t[h][i] = -(1 << 28);
+        a_b[h][i] = 0;
+      }
+      const int wrow = (ci >> 5) * 64 + h * 32 + (ci & 31);  // B-q(h): tile column
+      w_src[h][i] = W + (size_t)min(n0 + wrow, g.N - 1) * K + l_sw[i];
+    }
+  }
+  const bf16_t* zp = reinterpret_cast<const bf16_t*>(g_zero_page8) + pslot * 8;
+  // LDS byte offset (inside a buffer) of the first row of this wave's instruction i, per chunk kind
+  const int ci0 = wave * 16;
+  auto stage_A = [&](int buf, int h, int kt) {  // A-q(h) of K-tile kt (clamped past the end: a harmless re-read)
+    const int ktc = min(kt, nk - 1);
+    const int cpt = g.Cin / PBK;
+    const int tap = ktc / cpt, c0 = (ktc - tap * cpt) * PBK;
+    const int off = shift0 + tap * g.dil;
+    unsigned char* base = smem + buf * PBUF;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int ci = ci0 + i * 8;
+      int ts = a_t[h][i] + off;
+      if (g.pad_mode == PAD_REFLECT && a_t[h][i] >= 0) ts = reflect_i8(ts, T);
+      const bool ok = ts >= 0 && ts < T;
+      const bf16_t* src = ok ? A + (size_t)(a_b[h][i] + ts) * g.lda + c0 + l_sw[i] : zp;
+      glds16(src, base + ((ci >> 6) * 128 + h * 64 + (ci & 63)) * PROW);
+    }
+  };
+  auto stage_B = [&](int buf, int h, int kt) {
+    const int ktc = min(kt, nk - 1);
+    unsigned char* base = smem + buf * PBUF + 2 * PCHUNK;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int ci = ci0 + i * 8;
+      glds16(w_src[h][i] + (size_t)ktc * PBK, base + ((ci >> 5) * 64 + h * 32 + (ci & 31)) * PROW);
+    }
+  };
+
+  f32x4v acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4v{0.f, 0.f, 0.f, 0.f};
+  const int fr = lane & 15, fq = lane >> 4;
+  const int sx = (fr >> 1) & 7;  // swizzle key of this lane's fragment rows (rows fr + multiples of 16)
+  // byte offsets inside a buffer: A row wr * 128 + mi * 16 + fr, W row wc * 64 + nj * 16 + fr, k-step ks -> slot (4 ks + fq) ^ sx
+  const int a_rd = (wr * 128 + fr) * PROW, b_rd = 2 * PCHUNK + (wc * 64 + fr) * PROW;
+  const int ko0 = ((0 + fq) ^ sx) << 4, ko1 = ((4 + fq) ^ sx) << 4;
+  bf16x8 af[4][2], bfr[2][2];
+  auto read_A = [&](int buf, int h) {
+    const unsigned char* p = smem + buf * PBUF + a_rd + h * 64 * PROW;
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+      af[mi][0] = *reinterpret_cast<const bf16x8*>(p + mi * 16 * PROW + ko0);
+      af[mi][1] = *reinterpret_cast<const bf16x8*>(p + mi * 16 * PROW + ko1);
+    }
+  };
+  auto read_B = [&](int buf, int h) {
+    const unsigned char* p = smem + buf * PBUF + b_rd + h * 32 * PROW;
+#pragma unroll
+    for (int nj = 0; nj < 2; ++nj) {
+      bfr[nj][0] = *reinterpret_cast<const bf16x8*>(p + nj * 16 * PROW + ko0);
+      bfr[nj][1] = *reinterpret_cast<const bf16x8*>(p + nj * 16 * PROW + ko1);
+    }
+  };
+#define P8_LOAD_END()                                  \
+  asm volatile("s_waitcnt vmcnt(6)" ::: "memory");     \
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   \
+  __builtin_amdgcn_sched_barrier(0);                   \
+  __builtin_amdgcn_s_barrier();                        \
+  __builtin_amdgcn_sched_barrier(0);
+#define P8_COMPUTE(AH, BH)                                                                                             \
+  __builtin_amdgcn_s_setprio(1);                                                                                       \
+  _Pragma("unroll") for (int mi = 0; mi < 4; ++mi) _Pragma("unroll") for (int nj = 0; nj < 2; ++nj) {                   \
+    acc[(AH) * 4 + mi][(BH) * 2 + nj] =                                                                                 \
+        __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mi][0], bfr[nj][0], acc[(AH) * 4 + mi][(BH) * 2 + nj], 0, 0, 0);     \
+    acc[(AH) * 4 + mi][(BH) * 2 + nj] =                                                                                 \
+        __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mi][1], bfr[nj][1], acc[(AH) * 4 + mi][(BH) * 2 + nj], 0, 0, 0);     \
+  }                                                                                                                    \
+  __builtin_amdgcn_s_setprio(0);                                                                                       \
+  __builtin_amdgcn_sched_barrier(0);                                                                                   \
+  __builtin_amdgcn_s_barrier();                                                                                        \
+  __builtin_amdgcn_sched_barrier(0);
+
+  // ---- prologue: what phases -5 .. -1 would have staged ----
+  stage_A(0, 0, 0);
+  stage_B(0, 0, 0);
+  stage_B(0, 1, 0);
+  stage_A(0, 1, 0);
+  stage_A(1, 0, 1);
+  asm volatile("s_waitcnt vmcnt(6)" ::: "memory");  // A0(0), B0(0) of this wave have landed
+  __builtin_amdgcn_s_barrier();
+  if (wr == 1) __builtin_amdgcn_s_barrier();  // the second wave row runs half a phase behind the first
+  __builtin_amdgcn_sched_barrier(0);
+
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    // phase 0: quadrant (A0, B0); stage B0(t + 1)
+    read_A(buf, 0);
+    read_B(buf, 0);
+    stage_B(buf ^ 1, 0, kt + 1);
+    P8_LOAD_END()
+    P8_COMPUTE(0, 0)
+    // phase 1: (A0, B1); stage B1(t + 1)
+    read_B(buf, 1);
+    stage_B(buf ^ 1, 1, kt + 1);
+    P8_LOAD_END()
+    P8_COMPUTE(0, 1)
+    // phase 2: (A1, B1); stage A1(t + 1)
+    read_A(buf, 1);
+    stage_A(buf ^ 1, 1, kt + 1);
+    P8_LOAD_END()
+    P8_COMPUTE(1, 1)
+    // phase 3: (A1, B0); stage A0(t + 2)
+    read_B(buf, 0);
+    stage_A(buf, 0, kt + 2);
+    P8_LOAD_END()
+    P8_COMPUTE(1, 0)
+  }
+#undef P8_LOAD_END
+#undef P8_COMPUTE
+  if (wr == 0) __builtin_amdgcn_s_barrier();  // the barrier count of the second wave row
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the overshoot stages (clamped re-reads) must land before the LDS is released
+
+  // ---- epilogue: the accumulators go through LDS (free now) so that a lane owns 8 CONSECUTIVE columns of a row: bias / act /
+  //      BN affine / residual / accumulate on vectors, one 16-byte store per 8 outputs.  Every wave stages its own 128 x 64 block
+  //      in four rounds of 32 rows (a wave-private LDS region: no workgroup barrier, the wave's DS operations execute in order) ----
+  __builtin_amdgcn_s_barrier();  // every wave is through its last fragment reads: the staging buffers may be overwritten
+  TC* __restrict__ C = (TC*)g.C;
+  const TC* __restrict__ R = (const TC*)g.R;
+  const TC* __restrict__ ADD = (const TC*)g.ADD;
+  const bool plain = g.act == ACT_NONE && g.act2 == ACT_NONE && !g.scale && !g.shift;
+  constexpr int EST = 68;  // floats per staged row (64 + 4: rows 272 bytes apart)
+  float* est = reinterpret_cast<float*>(smem) + wave * 32 * EST;
+  const int er = lane >> 3, ec = (lane & 7) * 8;  // read-back: row er + 8 * it, columns ec .. ec + 7
+  const int ncol = n0 + wc * 64 + ec;
+  const bool vec_ok = ncol + 8 <= g.N && (g.ldc % 8) == 0 && (!R || g.ldr % 8 == 0) && (!ADD || g.ldadd % 8 == 0);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+#pragma unroll
+    for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+      for (int nj = 0; nj < 4; ++nj)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) est[(mh * 16 + fq * 4 + r) * EST + nj * 16 + fr] = acc[2 * q + mh][nj][r];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    for (int it = 0; it < 4; ++it) {
+      const int row = it * 8 + er;
+      const int m = m0 + wr * 128 + q * 32 + row;
+      if (m >= g.M || ncol >= g.N) continue;
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = est[row * EST + ec + e];
+      const float* brow = g.bias ? g.bias + (g.bias_bstride ? (size_t)(m / T) * g.bias_bstride : 0) : nullptr;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int n = min(ncol + e, g.N - 1);
+        if (brow) v[e] += brow[n];
+        if (!plain) {
+          v[e] = act_apply(g.act, v[e]);
+          v[e] = v[e] * (g.scale ? g.scale[n] : 1.f) + (g.shift ? g.shift[n] : 0.f);
+          v[e] = act_apply(g.act2, v[e]);
+        }
+      }
+      if (vec_ok && sizeof(TC) == 2) {
+        if (R) {
+          const bf16x8 rv = *reinterpret_cast<const bf16x8*>(R + (size_t)m * g.ldr + ncol);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += __uint_as_float((unsigned)(unsigned short)rv[e] << 16);
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] *= g.alpha;
+        if (ADD) {
+          const bf16x8 av = *reinterpret_cast<const bf16x8*>(ADD + (size_t)m * g.ldadd + ncol);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += g.beta * __uint_as_float((unsigned)(unsigned short)av[e] << 16);
+        }
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const bf16_t t = (bf16_t)v[e];
+          o[e] = __builtin_bit_cast(short, t);
+        }
+        *reinterpret_cast<bf16x8*>(C + (size_t)m * g.ldc + ncol) = o;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int n = ncol + e;
+          if (n < g.N) {
+            float x = v[e];
+            if (R) x += ldf(R + (size_t)m * g.ldr + n);
+            x *= g.alpha;
+            if (ADD) x += g.beta * ldf(ADD + (size_t)m * g.ldadd + n);
+            stf(C + (size_t)m * g.ldc + n, x);
+          }
+        }
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the read-back is done before the next round overwrites the region
+  }
+}
+
+template <typename TC>
+int launch_p8(const GemmArgs& g, hipStream_t s) {
+  const int tiles_m = (g.M + PBM - 1) / PBM, tiles_n = (g.N + PBN - 1) / PBN;
+  hipLaunchKernelGGL((gemm_p8_kernel<TC>), dim3(tiles_m * tiles_n), dim3(512), 0, s, g, tiles_m, tiles_n);
+  ITTS_HIP_CHECK(hipGetLastError());
+  return OK;
+}
+
+}  // namespace
+
+// Large regular shapes only: >= 2 K-tiles, enough 256 x 256 tiles to fill the 256 CUs at least once and a half, N a multiple
+// of 128 (a half-empty last column tile wastes a quarter of a 384-wide GEMM, still ahead of the 128-tile kernels there).
+bool gemm_p8_supported(const GemmArgs& g, int ta, int tw, int tc) {
+  if (ta != BF16 || tw != BF16 || (tc != BF16 && tc != F32)) return false;
+  if (g.Cin % 64 != 0 || g.lda % 8 != 0 || g.in_up != 1 || g.nphase != 1) return false;
+  if (((uintptr_t)g.A & 15) || ((uintptr_t)g.W & 15)) return false;
+  if (g.N < 256 || g.N % 128 != 0 || (long)g.taps * g.Cin < 256) return false;
+  const long tiles = (long)((g.M + PBM - 1) / PBM) * ((g.N + PBN - 1) / PBN);
+  return tiles >= 384;
+}
+
+int gemm_p8(const GemmArgs& g, int ta, int tw, int tc, hipStream_t s) {
+  ITTS_REQUIRE(g.A && g.W && g.C, "gemm_p8: null pointer");
+  ITTS_REQUIRE(gemm_p8_supported(g, ta, tw, tc), "gemm_p8: unsupported shape/dtype");
+  const int T = g.T > 0 ? g.T : g.M;
+  ITTS_REQUIRE(g.M % T == 0 && g.lda >= g.Cin && g.ldc >= g.N, "gemm_p8: bad dims");
+  return tc == BF16 ? launch_p8<bf16_t>(g, s) : launch_p8<float>(g, s);
+}
+
+}  // namespace itts

@@ -90,6 +90,7 @@ def run_gemm(lib, A, W, Cshape, dt_a, dt_w, dt_c, force_simple=0, **kw):
             continue
         setattr(g, k, v)
     g.dtype_a, g.dtype_w, g.dtype_c, g.force_simple = dt_a, dt_w, dt_c, force_simple
+    run_gemm.which = int(lib.itts_gemm_which(C.byref(g)))  # kernel family the dispatcher took (include/itts_hip.h)
     L.check(lib.itts_gemm(C.byref(g), stream()))
     torch.cuda.synchronize()
     return Cout
@@ -529,3 +530,63 @@ def test_gemm_glds_transposed_conv(lib):
                    ldc=u * Cout, T=T, dil=-1, pad_left=0, nphase=u, phase_shift=[(ph + p) // u for ph in range(u)],
                    bias=bias.to(DEV), bias_bstride=Cout)
     assert relerr(out.float().transpose(1, 2), ref) < 2e-2
+
+
+# ---- 256 x 256 eight-phase GEMM (gemm_p8.hip): the large regular shapes at batch (BigVGAN C >= 384 convs, conv_pre, GPT projections) ---
+P8_CASES = [
+    # B, T, Cin, Cout, k, dil, mode       (>= 384 tiles of 256 x 256, so the dispatcher takes the eight-phase kernel)
+    (2, 16384, 384, 768, 7, 3, "zeros"),    # 42 K-tiles, dilated taps, zero padding at both ends of both batch items
+    (2, 24576, 192, 512, 3, 5, "reflect"),  # 9 K-tiles (ODD: the pipeline's overshoot stages), reflect padding in the DMA source
+    (3, 16400, 384, 384, 3, 1, "zeros"),    # N = 384: half-empty second column tile; M not a multiple of 256, item boundaries inside tiles
+    (1, 32768, 1280, 3840, 1, 1, "zeros"),  # plain linear (GPT c_attn at batch): 20 K-tiles, 15 column tiles
+]
+
+
+@pytest.mark.parametrize("case", P8_CASES)
+@pytest.mark.parametrize("out_f32", [False, True])
+def test_gemm_p8_conv(lib, case, out_f32):
+    import os
+
+    B, T, Cin, Cout, k, dil, mode = case
+    x = rnd(f"p8.x{case}", (B, Cin, T)).to(torch.bfloat16)
+    w = rnd(f"p8.w{case}", (Cout, Cin, k), 1.0 / np.sqrt(Cin * k)).to(torch.bfloat16)
+    bias = rnd(f"p8.b{case}", (B, Cout), 0.1)
+    pad = dil * (k - 1) // 2
+    xp = F.pad(x.float(), (pad, pad), mode="reflect") if mode == "reflect" else F.pad(x.float(), (pad, pad))
+    ref = F.conv1d(xp, w.float(), None, dilation=dil) + bias[:, :, None]
+    res = rnd(f"p8.r{case}", (B, Cout, T)).to(torch.float32 if out_f32 else torch.bfloat16)
+    add = rnd(f"p8.a{case}", (B, Cout, T)).to(torch.float32 if out_f32 else torch.bfloat16)
+    ref = (ref + res.float()) * (1.0 / 3.0) + 0.5 * add.float()
+    A = x.transpose(1, 2).contiguous().to(DEV)
+    W = torch.from_numpy(pack.conv_w(w.float().numpy())).to(torch.bfloat16).to(DEV)
+    R, ADD = res.transpose(1, 2).contiguous().to(DEV), add.transpose(1, 2).contiguous().to(DEV)
+    outs, which = [], []
+    for env in (None, "1"):  # the eight-phase kernel, then the register-staged one on the same arguments
+        if env:
+            os.environ["ITTS_GEMM_FORCE_OLD"] = env
+        try:
+            outs.append(run_gemm(lib, A, W, (B, T, Cout), L.BF16, L.BF16, L.F32 if out_f32 else L.BF16, 0, M=B * T, N=Cout, Cin=Cin,
+                                 taps=k, lda=Cin, ldc=Cout, T=T, dil=dil, pad_left=pad, pad_mode=1 if mode == "reflect" else 0,
+                                 bias=bias.to(DEV), bias_bstride=Cout, R=R, ldr=Cout, alpha=1.0 / 3.0, ADD=ADD, ldadd=Cout, beta=0.5))
+            which.append(run_gemm.which)
+        finally:
+            os.environ.pop("ITTS_GEMM_FORCE_OLD", None)
+    assert which == [3, 1], which
+    assert relerr(outs[0].float().transpose(1, 2), ref) < (3e-3 if out_f32 else 2e-2)
+    # both kernels accumulate the same bf16 products in fp32: they agree far inside the bf16 output rounding
+    assert relerr(outs[0].float(), outs[1].float()) < (1e-4 if out_f32 else 1e-2)
+    # a staging race would show as rare wrong tiles: the WORST element, not only the norm, against the other kernel
+    d = (outs[0].float() - outs[1].float()).abs().max().item()
+    assert d < (2e-3 if out_f32 else 6e-2), d
+
+
+def test_gemm_p8_repeats_are_identical(lib):
+    """The pipeline keeps three chunks in flight across every barrier: a missing wait shows as run-to-run differences."""
+    B, T, Cin, Cout, k = 2, 16384, 768, 768, 3
+    x = rnd("p8r.x", (B, T, Cin)).to(torch.bfloat16).to(DEV)
+    W = torch.from_numpy(pack.conv_w(rnd("p8r.w", (Cout, Cin, k), 1.0 / np.sqrt(Cin * k)).float().numpy())).to(torch.bfloat16).to(DEV)
+    outs = [run_gemm(lib, x, W, (B, T, Cout), L.BF16, L.BF16, L.BF16, 0, M=B * T, N=Cout, Cin=Cin, taps=k, lda=Cin, ldc=Cout, T=T,
+                     dil=1, pad_left=1) for _ in range(6)]
+    assert run_gemm.which == 3
+    for o in outs[1:]:
+        assert torch.equal(o, outs[0])

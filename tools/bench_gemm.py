@@ -14,7 +14,7 @@ import torch  # noqa: E402
 from itts_hip import lib as L  # noqa: E402
 
 
-def run(lib, M, T, N, Cin, taps, dil, nphase=1, reps=10, old=False):
+def run(lib, M, T, N, Cin, taps, dil, nphase=1, reps=10, old=False, p8=True):
     dev = "cuda:0"
     A = torch.randn(M, Cin, device=dev).to(torch.bfloat16)
     W = (torch.randn(nphase, N, taps * Cin, device=dev) / (taps * Cin) ** 0.5).to(torch.bfloat16)
@@ -29,6 +29,8 @@ def run(lib, M, T, N, Cin, taps, dil, nphase=1, reps=10, old=False):
         os.environ["ITTS_GEMM_FORCE_OLD"] = "1"
     else:
         os.environ.pop("ITTS_GEMM_FORCE_OLD", None)
+    os.environ["ITTS_GEMM_P8"] = "1" if p8 else "0"
+    which = int(lib.itts_gemm_which(C.byref(g)))
     s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     for _ in range(2):
         L.check(lib.itts_gemm(C.byref(g), s))
@@ -39,7 +41,7 @@ def run(lib, M, T, N, Cin, taps, dil, nphase=1, reps=10, old=False):
     e1.record()
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 1e3 / reps
-    return us, 2.0 * M * N * nphase * taps * Cin / us / 1e6
+    return us, 2.0 * M * N * nphase * taps * Cin / us / 1e6, which
 
 
 def main():
@@ -61,11 +63,14 @@ def main():
     n = 32 + 107 + 482
     for nm, N, K in (("latent c_attn", 3840, 1280), ("latent c_proj", 1280, 1280), ("latent c_fc", 5120, 1280), ("latent proj2", 1280, 5120)):
         shapes.append((nm, rows * n, rows * n, N, K, 1, 1, 1))
-    print(f"{'shape':28s} {'M':>9s}  {'glds us':>9s} {'TF/s':>7s}   {'old us':>9s} {'TF/s':>7s}  speedup")
+    names = {0: "valu", 1: "mfma", 2: "glds", 3: "p8", 4: "convlds"}
+    print(f"{'shape':28s} {'M':>9s}  {'default':>8s} {'us':>9s} {'TF/s':>7s}   {'no-p8':>7s} {'us':>9s} {'TF/s':>7s}   {'old us':>9s} {'TF/s':>7s}  default vs no-p8")
     for nm, M, T, N, Cin, taps, dil, nph in shapes:
         new = run(lib, M, T, N, Cin, taps, dil, nph)
+        mid = run(lib, M, T, N, Cin, taps, dil, nph, p8=False)
         old = run(lib, M, T, N, Cin, taps, dil, nph, old=True)
-        print(f"{nm:28s} {M:9d}  {new[0]:9.1f} {new[1]:7.1f}   {old[0]:9.1f} {old[1]:7.1f}  {old[0] / new[0]:5.2f}x", flush=True)
+        print(f"{nm:28s} {M:9d}  {names[new[2]]:>8s} {new[0]:9.1f} {new[1]:7.1f}   {names[mid[2]]:>7s} {mid[0]:9.1f} {mid[1]:7.1f}   {old[0]:9.1f} {old[1]:7.1f}  "
+              f"{mid[0] / new[0]:5.2f}x", flush=True)
 
 
 if __name__ == "__main__":
