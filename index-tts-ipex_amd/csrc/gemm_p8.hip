@@ -23,7 +23,11 @@
 //        is followed by a barrier every wave passes before any wave's load segment of phase g;
 //   WAR  ds_reads are retired (lgkmcnt(0)) BEFORE the barrier that ends their load segment, and a chunk slot is re-staged no
 //        earlier than one phase after its last read (B0: read again in phase 3 of its tile, re-staged in phase 0 of the next).
-// Conv addressing, zero page for padded rows, epilogue and XCD-aware tile order as gemm_glds.hip.
+// Conv addressing, zero page for padded rows and XCD-aware tile order as gemm_glds.hip; the polyphase transposed convs (nphase > 1)
+// run as extra column tiles with their own tap shift and weight slab.
+// Two geometries, same per-wave work (128 x 64 outputs): 2 x 4 waves = 256 x 256 tile (N a multiple of 256) and 4 x 2 waves =
+// 512 x 128 tile (N a multiple of 128 only: 384-wide convs would leave a quarter of a 256-wide column tile empty); the second one
+// stages 80 KB per K-tile (4 + 4 + 1 + 1 DMA instructions per thread) and fills the 160 KB of LDS exactly.
 #include "itts_kernels.h"
 
 namespace itts {
@@ -45,40 +49,52 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst) {
                                    (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
 }
 
-constexpr int PBM = 256, PBN = 256, PBK = 64, PROW = PBK * 2;  // 128-byte LDS rows
-constexpr int PCHUNK = 128 * PROW;                             // 16 KiB: one staging chunk
-constexpr int PBUF = 4 * PCHUNK;                               // one K-tile: A rows 0..255, then W rows 0..255
+constexpr int PBK = 64, PROW = PBK * 2;  // 128-byte LDS rows
 
-template <typename TC>
+#define P8_STR_(x) #x
+#define P8_STR(x) P8_STR_(x)
+
+template <int WM, int WN, typename TC>
 __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmArgs g, int tiles_m, int tiles_n) {
+  static_assert(WM * WN == 8 && (WM == 2 || WM == 4), "8 waves as 2 x 4 or 4 x 2");
+  constexpr int PBM = WM * 128, PBN = WN * 64;
+  constexpr int PBUF = (PBM + PBN) * PROW;  // one K-tile: A rows 0 .. PBM - 1, then W rows 0 .. PBN - 1
+  constexpr int BOFF = PBM * PROW;          // W rows behind the A rows
+  constexpr int NA = WM, NB_ = WN / 2;      // DMA instructions per thread for an A / a B chunk (a chunk = the rows of one quadrant half)
   __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * PBUF];  // ONE LDS object
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wr = wave >> 2, wc = wave & 3;
+  const int wr = wave / WN, wc = wave % WN;
+  const int grp = wave >> 2;  // waves w and w + 4 share a SIMD: the second group runs half a phase behind the first
   // ---- XCD-aware, bijective remap: consecutive logical ids (= the column tiles of one row tile) land on one XCD ----
   const int nwg = gridDim.x, orig = blockIdx.x;
   const int q8 = nwg >> 3, r8 = nwg & 7, xcd = orig & 7;
   const int wgid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
-  const int tm = wgid / tiles_n, tn = wgid - tm * tiles_n;
+  const int per_phase = tiles_m * tiles_n;
+  const int phase = wgid / per_phase, rem = wgid - phase * per_phase;
+  const int tm = rem / tiles_n, tn = rem - tm * tiles_n;
   const int m0 = tm * PBM, n0 = tn * PBN;
   const bf16_t* __restrict__ A = (const bf16_t*)g.A;
   const int K = g.taps * g.Cin;
-  const bf16_t* __restrict__ W = (const bf16_t*)g.W;
+  const bf16_t* __restrict__ W = (const bf16_t*)g.W + (size_t)phase * g.N * K;
   const int T = g.T > 0 ? g.T : g.M;
   const int nk = g.taps * (g.Cin / PBK);
-  const int shift0 = g.phase_shift[0] - g.pad_left;
+  const int shift0 = g.phase_shift[phase] - g.pad_left;
 
-  // ---- loader: a chunk is 128 rows; wave w fills chunk rows [16w, 16w + 16) with two instructions of 8 rows ----
+  // ---- loader: an A chunk is WM * 64 rows (rows h * 64 .. + 63 of every wave row), a B chunk WN * 32 rows; instruction i of wave w
+  //      fills chunk rows [64 i + 8 w, + 8) ----
   const int lrow = lane >> 3, pslot = lane & 7;
-  int a_t[2][2], a_b[2][2];  // [A half][instruction]: time index inside the batch item (or far negative), first row of the item
-  int l_sw[2];               // logical k offset (elements) this lane fetches, per instruction (same for A and W rows)
-  const bf16_t* w_src[2][2];
+  // (chunk row ci = 64 i + 8 w + lrow maps to tile row (ci / 64) * 128 + h * 64 + ci % 64 (A) or (ci / 32) * 64 + h * 32 + ci % 32 (B):
+  //  multiples of 8 are added to lrow, so bits 1..3 of the tile row are bits 1..3 of 8 w + lrow: the swizzle key is ((8 w + lrow) >> 1) & 7)
+  const int skey = ((wave * 8 + lrow) >> 1) & 7;
+  const int l_sw2 = (pslot ^ skey) * 8;  // logical k offset (elements) this lane fetches
+  int a_t[2][NA], a_b[2][NA];  // [A half][instruction]: time index inside the batch item (or far negative), first row of the item
+  const bf16_t* w_src[2][NB_];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int ci = wave * 16 + i * 8 + lrow;  // row inside the chunk
-    l_sw[i] = (pslot ^ ((ci >> 1) & 7)) * 8;  // ((tile row) >> 1) & 7 == ((chunk row) >> 1) & 7: the maps below add multiples of 16
+  for (int h = 0; h < 2; ++h) {
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
+    for (int i = 0; i < NA; ++i) {
+      const int ci = i * 64 + wave * 8 + lrow;
       const int ar = (ci >> 6) * 128 + h * 64 + (ci & 63);  // A-q(h): tile row
       const int m = m0 + ar;
       if (m < g.M) {
@@ -89,35 +105,50 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmArgs g, int tiles_m, i
         a_t[h][i] = -(1 << 28);
         a_b[h][i] = 0;
       }
+    }
+#pragma unroll
+    for (int i = 0; i < NB_; ++i) {
+      const int ci = i * 64 + wave * 8 + lrow;
       const int wrow = (ci >> 5) * 64 + h * 32 + (ci & 31);  // B-q(h): tile column
-      w_src[h][i] = W + (size_t)min(n0 + wrow, g.N - 1) * K + l_sw[i];
+      w_src[h][i] = W + (size_t)min(n0 + wrow, g.N - 1) * K + l_sw2;
     }
   }
   const bf16_t* zp = reinterpret_cast<const bf16_t*>(g_zero_page8) + pslot * 8;
-  // LDS byte offset (inside a buffer) of the first row of this wave's instruction i, per chunk kind
-  const int ci0 = wave * 16;
+  // Source pointer of every (half, instruction), carried from K-tile to K-tile: inside a tap the next K-tile is the next 64 channels
+  // of the same rows (+ 128 bytes, or + 0 on the zero page), so the row arithmetic (tap shift, reflect, range test, 64-bit row
+  // offset: ~25 VALU instructions per DMA) runs once per tap instead of once per K-tile - the load segment of a phase has to stay
+  // shorter than the other wave group's 16 MFMAs (~260 cycles).
+  const bf16_t* a_ptr[2][NA];
+  int a_inc[2][NA];
+  const int cpt = g.Cin / PBK;
   auto stage_A = [&](int buf, int h, int kt) {  // A-q(h) of K-tile kt (clamped past the end: a harmless re-read)
     const int ktc = min(kt, nk - 1);
-    const int cpt = g.Cin / PBK;
-    const int tap = ktc / cpt, c0 = (ktc - tap * cpt) * PBK;
-    const int off = shift0 + tap * g.dil;
+    const int tap = ktc / cpt, cc = ktc - tap * cpt;
     unsigned char* base = smem + buf * PBUF;
+    if (cc == 0 || kt >= nk) {  // wave-uniform: first channel chunk of a tap (or an overshoot stage): resolve the rows
+      const int off = shift0 + tap * g.dil;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int ci = ci0 + i * 8;
-      int ts = a_t[h][i] + off;
-      if (g.pad_mode == PAD_REFLECT && a_t[h][i] >= 0) ts = reflect_i8(ts, T);
-      const bool ok = ts >= 0 && ts < T;
-      const bf16_t* src = ok ? A + (size_t)(a_b[h][i] + ts) * g.lda + c0 + l_sw[i] : zp;
-      glds16(src, base + ((ci >> 6) * 128 + h * 64 + (ci & 63)) * PROW);
+      for (int i = 0; i < NA; ++i) {
+        int ts = a_t[h][i] + off;
+        if (g.pad_mode == PAD_REFLECT && a_t[h][i] >= 0) ts = reflect_i8(ts, T);
+        const bool ok = ts >= 0 && ts < T;
+        a_ptr[h][i] = ok ? A + (size_t)(a_b[h][i] + ts) * g.lda + cc * PBK + l_sw2 : zp;
+        a_inc[h][i] = ok ? PBK : 0;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      const int ci = i * 64 + wave * 8;
+      glds16(a_ptr[h][i], base + ((ci >> 6) * 128 + h * 64 + (ci & 63)) * PROW);
+      a_ptr[h][i] += a_inc[h][i];
     }
   };
   auto stage_B = [&](int buf, int h, int kt) {
     const int ktc = min(kt, nk - 1);
-    unsigned char* base = smem + buf * PBUF + 2 * PCHUNK;
+    unsigned char* base = smem + buf * PBUF + BOFF;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int ci = ci0 + i * 8;
+    for (int i = 0; i < NB_; ++i) {
+      const int ci = i * 64 + wave * 8;
       glds16(w_src[h][i] + (size_t)ktc * PBK, base + ((ci >> 5) * 64 + h * 32 + (ci & 31)) * PROW);
     }
   };
@@ -130,7 +161,7 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmArgs g, int tiles_m, i
   const int fr = lane & 15, fq = lane >> 4;
   const int sx = (fr >> 1) & 7;  // swizzle key of this lane's fragment rows (rows fr + multiples of 16)
   // byte offsets inside a buffer: A row wr * 128 + mi * 16 + fr, W row wc * 64 + nj * 16 + fr, k-step ks -> slot (4 ks + fq) ^ sx
-  const int a_rd = (wr * 128 + fr) * PROW, b_rd = 2 * PCHUNK + (wc * 64 + fr) * PROW;
+  const int a_rd = (wr * 128 + fr) * PROW, b_rd = BOFF + (wc * 64 + fr) * PROW;
   const int ko0 = ((0 + fq) ^ sx) << 4, ko1 = ((4 + fq) ^ sx) << 4;
   bf16x8 af[4][2], bfr[2][2];
   auto read_A = [&](int buf, int h) {
@@ -149,9 +180,11 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmArgs g, int tiles_m, i
       bfr[nj][1] = *reinterpret_cast<const bf16x8*>(p + nj * 16 * PROW + ko1);
     }
   };
-#define P8_LOAD_END()                                  \
-  asm volatile("s_waitcnt vmcnt(6)" ::: "memory");     \
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   \
+  // vmcnt counts: what may stay in flight behind the chunk the NEXT phase reads (issue order per tile: B0' B1' A1' A0'')
+  constexpr int VM03 = 2 * NA + NB_, VM1 = NA + 2 * NB_;  // end of phases 0 / 2 / 3, end of phase 1
+#define P8_LOAD_END(N)                                                   \
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");              \
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                    \
   __builtin_amdgcn_sched_barrier(0);                   \
   __builtin_amdgcn_s_barrier();                        \
   __builtin_amdgcn_sched_barrier(0);
@@ -174,9 +207,9 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmArgs g, int tiles_m, i
   stage_B(0, 1, 0);
   stage_A(0, 1, 0);
   stage_A(1, 0, 1);
-  asm volatile("s_waitcnt vmcnt(6)" ::: "memory");  // A0(0), B0(0) of this wave have landed
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VM03) : "memory");  // A0(0), B0(0) of this wave have landed
   __builtin_amdgcn_s_barrier();
-  if (wr == 1) __builtin_amdgcn_s_barrier();  // the second wave row runs half a phase behind the first
+  if (grp == 1) __builtin_amdgcn_s_barrier();  // the second wave group runs half a phase behind the first
   __builtin_amdgcn_sched_barrier(0);
 
   for (int kt = 0; kt < nk; ++kt) {
@@ -185,27 +218,27 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmArgs g, int tiles_m, i
     read_A(buf, 0);
     read_B(buf, 0);
     stage_B(buf ^ 1, 0, kt + 1);
-    P8_LOAD_END()
+    P8_LOAD_END(VM03)
     P8_COMPUTE(0, 0)
     // phase 1: (A0, B1); stage B1(t + 1)
     read_B(buf, 1);
     stage_B(buf ^ 1, 1, kt + 1);
-    P8_LOAD_END()
+    P8_LOAD_END(VM1)
     P8_COMPUTE(0, 1)
     // phase 2: (A1, B1); stage A1(t + 1)
     read_A(buf, 1);
     stage_A(buf ^ 1, 1, kt + 1);
-    P8_LOAD_END()
+    P8_LOAD_END(VM03)
     P8_COMPUTE(1, 1)
     // phase 3: (A1, B0); stage A0(t + 2)
     read_B(buf, 0);
     stage_A(buf, 0, kt + 2);
-    P8_LOAD_END()
+    P8_LOAD_END(VM03)
     P8_COMPUTE(1, 0)
   }
 #undef P8_LOAD_END
 #undef P8_COMPUTE
-  if (wr == 0) __builtin_amdgcn_s_barrier();  // the barrier count of the second wave row
+  if (grp == 0) __builtin_amdgcn_s_barrier();  // the barrier count of the second wave group
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the overshoot stages (clamped re-reads) must land before the LDS is released
 
   // ---- epilogue: the accumulators go through LDS (free now) so that a lane owns 8 CONSECUTIVE columns of a row: bias / act /
@@ -219,8 +252,9 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmArgs g, int tiles_m, i
   constexpr int EST = 68;  // floats per staged row (64 + 4: rows 272 bytes apart)
   float* est = reinterpret_cast<float*>(smem) + wave * 32 * EST;
   const int er = lane >> 3, ec = (lane & 7) * 8;  // read-back: row er + 8 * it, columns ec .. ec + 7
-  const int ncol = n0 + wc * 64 + ec;
-  const bool vec_ok = ncol + 8 <= g.N && (g.ldc % 8) == 0 && (!R || g.ldr % 8 == 0) && (!ADD || g.ldadd % 8 == 0);
+  const int ncol = n0 + wc * 64 + ec;  // column inside this phase's N
+  const int pcol = phase * g.N;        // ... and where the phase's columns start in C / R / ADD
+  const bool vec_ok = ncol + 8 <= g.N && (pcol % 8) == 0 && (g.ldc % 8) == 0 && (!R || g.ldr % 8 == 0) && (!ADD || g.ldadd % 8 == 0);
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
 #pragma unroll
@@ -250,14 +284,14 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmArgs g, int tiles_m, i
       }
       if (vec_ok && sizeof(TC) == 2) {
         if (R) {
-          const bf16x8 rv = *reinterpret_cast<const bf16x8*>(R + (size_t)m * g.ldr + ncol);
+          const bf16x8 rv = *reinterpret_cast<const bf16x8*>(R + (size_t)m * g.ldr + pcol + ncol);
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] += __uint_as_float((unsigned)(unsigned short)rv[e] << 16);
         }
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] *= g.alpha;
         if (ADD) {
-          const bf16x8 av = *reinterpret_cast<const bf16x8*>(ADD + (size_t)m * g.ldadd + ncol);
+          const bf16x8 av = *reinterpret_cast<const bf16x8*>(ADD + (size_t)m * g.ldadd + pcol + ncol);
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] += g.beta * __uint_as_float((unsigned)(unsigned short)av[e] << 16);
         }
@@ -267,17 +301,17 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmArgs g, int tiles_m, i
           const bf16_t t = (bf16_t)v[e];
           o[e] = __builtin_bit_cast(short, t);
         }
-        *reinterpret_cast<bf16x8*>(C + (size_t)m * g.ldc + ncol) = o;
+        *reinterpret_cast<bf16x8*>(C + (size_t)m * g.ldc + pcol + ncol) = o;
       } else {
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           const int n = ncol + e;
           if (n < g.N) {
             float x = v[e];
-            if (R) x += ldf(R + (size_t)m * g.ldr + n);
+            if (R) x += ldf(R + (size_t)m * g.ldr + pcol + n);
             x *= g.alpha;
-            if (ADD) x += g.beta * ldf(ADD + (size_t)m * g.ldadd + n);
-            stf(C + (size_t)m * g.ldc + n, x);
+            if (ADD) x += g.beta * ldf(ADD + (size_t)m * g.ldadd + pcol + n);
+            stf(C + (size_t)m * g.ldc + pcol + n, x);
           }
         }
       }
@@ -286,24 +320,27 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmArgs g, int tiles_m, i
   }
 }
 
-template <typename TC>
+template <int WM, int WN, typename TC>
 int launch_p8(const GemmArgs& g, hipStream_t s) {
-  const int tiles_m = (g.M + PBM - 1) / PBM, tiles_n = (g.N + PBN - 1) / PBN;
-  hipLaunchKernelGGL((gemm_p8_kernel<TC>), dim3(tiles_m * tiles_n), dim3(512), 0, s, g, tiles_m, tiles_n);
+  constexpr int BMt = WM * 128, BNt = WN * 64;
+  const int tiles_m = (g.M + BMt - 1) / BMt, tiles_n = (g.N + BNt - 1) / BNt;
+  hipLaunchKernelGGL((gemm_p8_kernel<WM, WN, TC>), dim3(tiles_m * tiles_n * g.nphase), dim3(512), 0, s, g, tiles_m, tiles_n);
   ITTS_HIP_CHECK(hipGetLastError());
   return OK;
 }
 
 }  // namespace
 
-// Large regular shapes only: >= 2 K-tiles, enough 256 x 256 tiles to fill the 256 CUs at least once and a half, N a multiple
-// of 128 (a half-empty last column tile wastes a quarter of a 384-wide GEMM, still ahead of the 128-tile kernels there).
+// Large regular shapes only: >= 4 K-tiles, enough tiles to fill the 256 CUs at least once and a half; N a multiple of 256 takes the
+// 256 x 256 tile, a multiple of 128 the 512 x 128 tile.
+static bool p8_wide(const GemmArgs& g) { return g.N % 256 == 0; }
 bool gemm_p8_supported(const GemmArgs& g, int ta, int tw, int tc) {
   if (ta != BF16 || tw != BF16 || (tc != BF16 && tc != F32)) return false;
-  if (g.Cin % 64 != 0 || g.lda % 8 != 0 || g.in_up != 1 || g.nphase != 1) return false;
+  if (g.Cin % 64 != 0 || g.lda % 8 != 0 || g.in_up != 1 || g.nphase < 1 || g.nphase > 8) return false;
   if (((uintptr_t)g.A & 15) || ((uintptr_t)g.W & 15)) return false;
   if (g.N < 256 || g.N % 128 != 0 || (long)g.taps * g.Cin < 256) return false;
-  const long tiles = (long)((g.M + PBM - 1) / PBM) * ((g.N + PBN - 1) / PBN);
+  const int bm = p8_wide(g) ? 256 : 512, bn = p8_wide(g) ? 256 : 128;
+  const long tiles = (long)((g.M + bm - 1) / bm) * ((g.N + bn - 1) / bn) * g.nphase;
   return tiles >= 384;
 }
 
@@ -311,8 +348,9 @@ int gemm_p8(const GemmArgs& g, int ta, int tw, int tc, hipStream_t s) {
   ITTS_REQUIRE(g.A && g.W && g.C, "gemm_p8: null pointer");
   ITTS_REQUIRE(gemm_p8_supported(g, ta, tw, tc), "gemm_p8: unsupported shape/dtype");
   const int T = g.T > 0 ? g.T : g.M;
-  ITTS_REQUIRE(g.M % T == 0 && g.lda >= g.Cin && g.ldc >= g.N, "gemm_p8: bad dims");
-  return tc == BF16 ? launch_p8<bf16_t>(g, s) : launch_p8<float>(g, s);
+  ITTS_REQUIRE(g.M % T == 0 && g.lda >= g.Cin && g.ldc >= g.N * g.nphase, "gemm_p8: bad dims");
+  if (p8_wide(g)) return tc == BF16 ? launch_p8<2, 4, bf16_t>(g, s) : launch_p8<2, 4, float>(g, s);
+  return tc == BF16 ? launch_p8<4, 2, bf16_t>(g, s) : launch_p8<4, 2, float>(g, s);
 }
 
 }  // namespace itts

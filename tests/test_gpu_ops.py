@@ -537,7 +537,8 @@ P8_CASES = [
     # B, T, Cin, Cout, k, dil, mode       (>= 384 tiles of 256 x 256, so the dispatcher takes the eight-phase kernel)
     (2, 16384, 384, 768, 7, 3, "zeros"),    # 42 K-tiles, dilated taps, zero padding at both ends of both batch items
     (2, 24576, 192, 512, 3, 5, "reflect"),  # 9 K-tiles (ODD: the pipeline's overshoot stages), reflect padding in the DMA source
-    (3, 16400, 384, 384, 3, 1, "zeros"),    # N = 384: half-empty second column tile; M not a multiple of 256, item boundaries inside tiles
+    (3, 22000, 384, 384, 3, 1, "zeros"),    # N = 384: the 512 x 128 geometry; M not a multiple of 512, item boundaries inside tiles
+    (2, 24576, 256, 640, 11, 5, "reflect"),  # N = 640 = 5 x 128 (512 x 128 tiles), 44 K-tiles, reflect
     (1, 32768, 1280, 3840, 1, 1, "zeros"),  # plain linear (GPT c_attn at batch): 20 K-tiles, 15 column tiles
 ]
 
@@ -590,3 +591,34 @@ def test_gemm_p8_repeats_are_identical(lib):
     assert run_gemm.which == 3
     for o in outs[1:]:
         assert torch.equal(o, outs[0])
+
+
+@pytest.mark.parametrize("dims", [(2, 6144, 1536, 768), (2, 12288, 768, 384)])
+def test_gemm_p8_transposed_conv(lib, dims):
+    """ConvTranspose1d(k = 8, stride 4) as four polyphase column-tile groups of the eight-phase kernel (BigVGAN ups 0 / 1 at batch:
+    N = 768 on 256 x 256 tiles, N = 384 on 512 x 128 tiles), against torch and against the register-staged kernel."""
+    import os
+
+    B, T, Cin, Cout = dims
+    k, u = 8, 4
+    p = (k - u) // 2
+    x = rnd(f"p8t.x{dims}", (B, Cin, T)).to(torch.bfloat16)
+    w = rnd(f"p8t.w{dims}", (Cin, Cout, k), 1.0 / np.sqrt(Cin * k / u)).to(torch.bfloat16)
+    bias = rnd(f"p8t.b{dims}", (B, Cout), 0.1)
+    ref = F.conv_transpose1d(x.float(), w.float(), None, stride=u, padding=p) + bias[:, :, None]
+    A = x.transpose(1, 2).contiguous().to(DEV)
+    W = torch.from_numpy(pack.convT_w(w.float().numpy(), u, p)).to(torch.bfloat16).to(DEV)
+    outs, which = [], []
+    for env in (None, "1"):
+        if env:
+            os.environ["ITTS_GEMM_FORCE_OLD"] = env
+        try:
+            outs.append(run_gemm(lib, A, W, (B, T * u, Cout), L.BF16, L.BF16, L.BF16, 0, M=B * T, N=Cout, Cin=Cin, taps=k // u, lda=Cin,
+                                 ldc=u * Cout, T=T, dil=-1, pad_left=0, nphase=u, phase_shift=[(ph + p) // u for ph in range(u)],
+                                 bias=bias.to(DEV), bias_bstride=Cout))
+            which.append(run_gemm.which)
+        finally:
+            os.environ.pop("ITTS_GEMM_FORCE_OLD", None)
+    assert which == [3, 1], which
+    assert relerr(outs[0].float().transpose(1, 2), ref) < 2e-2
+    assert relerr(outs[0].float(), outs[1].float()) < 1e-2
