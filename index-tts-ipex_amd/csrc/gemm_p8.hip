@@ -338,7 +338,7 @@ bool gemm_p8_supported(const GemmArgs& g, int ta, int tw, int tc) {
   if (ta != BF16 || tw != BF16 || (tc != BF16 && tc != F32)) return false;
   if (g.Cin % 64 != 0 || g.lda % 8 != 0 || g.in_up != 1 || g.nphase < 1 || g.nphase > 8) return false;
   if (((uintptr_t)g.A & 15) || ((uintptr_t)g.W & 15)) return false;
-  if (g.N < 256 || g.N % 128 != 0 || (long)g.taps * g.Cin < 256) return false;
+  if (g.N < 192 || g.N % 64 != 0 || (long)g.taps * g.Cin < 256) return false;
   const int bm = p8_wide(g) ? 256 : 512, bn = p8_wide(g) ? 256 : 128;
   const long tiles = (long)((g.M + bm - 1) / bm) * ((g.N + bn - 1) / bn) * g.nphase;
   return tiles >= 384;
