@@ -43,7 +43,8 @@ def parse():
     ap.add_argument("--text-tokens", type=int, default=105)
     ap.add_argument("--mel-tokens", type=int, default=480)
     ap.add_argument("--prompt-frames", type=int, default=511)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "fp32"],
+                    help="engine storage dtype: bf16 (BASELINE config 2), f16 = IEEE half (the reference's is_fp16=True), fp32 (parity engine)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--micro", action="store_true", help="tiny config (plumbing check)")
     ap.add_argument("--gpt-fp8", action="store_true",
@@ -288,7 +289,7 @@ def measure(eng, cfg, a, BU, steps, warmup, rank, world, product_loop=False):
     audio_s = samples / 24000.0
     # ---- roofline of the dominant kernel group: the per-token decode step ----
     D, NL, V = g["model_dim"], g["layers"], g["number_mel_codes"]
-    esz = 2 if a.dtype == "bf16" else 4
+    esz = 2 if a.dtype in ("bf16", "f16") else 4
     w_params = NL * (12 * D * D + 13 * D) + 4 * D + D * V + V
     s_bar = (32 + L + 2 + 1) + T / 2.0
     kv_per_pos = 2 * NL * D * esz
@@ -395,7 +396,7 @@ def main():
                        "weights_replicate_s": round(getattr(eng, "replicate_s", 0.0), 3),
                        "collectives_in_timed_region": 0,
                        "ranks_on_persistent_engine": "all" if int(lo[0]) == 1 else "NOT all"}
-        if dist.get_backend() == "nccl" and a.dtype == "bf16" and not a.micro and os.environ.get("ITTS_ENGINE", "1") != "0":
+        if dist.get_backend() == "nccl" and a.dtype in ("bf16", "f16") and not a.micro and os.environ.get("ITTS_ENGINE", "1") != "0":
             assert int(lo[0]) == 1, "a rank fell back from the persistent decode engine to the launch path"
     # the default run also measures, next to the headline line (the same per-GPU workload at every N, so the driver's
     # scaling curve compares like with like): 32 utterances per GPU = 64 decode rows - BASELINE config 3 at one GPU, BASELINE

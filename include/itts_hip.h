@@ -38,6 +38,11 @@ typedef struct itts_engine itts_engine;
 
 const char* itts_last_error(void);
 int itts_abi_version(void);
+/* The 16-bit storage type behind dtype code ITTS_BF16 in THIS build of the library: 0 = bfloat16 (libitts_hip.so), 1 = IEEE
+ * binary16 (libitts_hip_f16.so: the same sources with -DITTS_HALF_F16 - the reference's GPU precision, `is_fp16=True` =
+ * fp16 autocast / .half(), indextts/infer.py:39,44,52).  Weights, activations and the K/V cache are stored in it; accumulation is
+ * fp32 in both.  The f16 build has no fp8 weight copies (BASELINE config 5 is a bf16-build mode). */
+int itts_half_is_f16(void);
 
 /* ---- operator level -------------------------------------------------------------------------------- */
 

@@ -100,7 +100,7 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(AttnArgs a) {
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
         const bf16x8 kf = *reinterpret_cast<const bf16x8*>(&sK[nt * 16 + fr][ks * 32 + fg * 8]);
-        s[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[ks], kf, s[nt], 0, 0, 0);
+        s[nt] = half_mfma16(qf[ks], kf, s[nt]);
       }
     }
     // ---- mask + online softmax (rows fg*4 + r, columns fr + 16 nt) ----
@@ -149,7 +149,7 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(AttnArgs a) {
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
         const bf16x8 vf = *reinterpret_cast<const bf16x8*>(&sVt[t * 16 + fr][ks * 32 + fg * 8]);
-        oacc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf[ks], vf, oacc[t], 0, 0, 0);
+        oacc[t] = half_mfma16(pf[ks], vf, oacc[t]);
       }
   }
 #pragma unroll

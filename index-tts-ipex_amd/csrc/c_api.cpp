@@ -41,6 +41,13 @@ extern "C" {
 
 const char* itts_last_error(void) { return last_error(); }
 int itts_abi_version(void) { return 4; }
+int itts_half_is_f16(void) {
+#ifdef ITTS_HALF_F16
+  return 1;
+#else
+  return 0;
+#endif
+}
 
 int itts_snake_aa_fwd(void* dst, const void* src, const float* up12, const float* down12, const float* log_alpha,
                       const float* log_beta, int B, int C, int T, int dtype, int layout, itts_stream stream) {
@@ -185,6 +192,12 @@ int itts_engine_bind_tensor(itts_engine* e, const char* name, const void* ptr, i
     set_error("itts_engine_bind_tensor: bad argument");
     return E_INVALID;
   }
+#ifdef ITTS_HALF_F16
+  if (dtype == FP8) {  // the fp8 readers expand to bf16 pairs (v_cvt_scalef32_pk_bf16_fp8): BASELINE config 5 is a bf16-build mode
+    set_error("itts_engine_bind_tensor: fp8 weight copies are not supported by the f16 build of the library");
+    return E_INVALID;
+  }
+#endif
   Tensor t;
   t.p = ptr;
   t.dt = dtype;

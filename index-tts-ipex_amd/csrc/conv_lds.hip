@@ -121,7 +121,7 @@ __global__ __launch_bounds__(256) void conv_lds_kernel(GemmArgs g, int tiles_per
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
-          for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], wf[j], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < NT; ++j) acc[i][j] = half_mfma16(af[i], wf[j], acc[i][j]);
         c0 += 32;
         if (c0 >= C) {
           c0 = 0;

@@ -20,7 +20,7 @@ template <> struct Vec8<bf16_t> {
   __device__ __forceinline__ void load(const bf16_t* p) { raw = *reinterpret_cast<const uint4*>(p); }
   __device__ __forceinline__ float get(int i) const {
     const uint32_t w = (&raw.x)[i >> 1];
-    return __uint_as_float((i & 1) ? (w & 0xFFFF0000u) : (w << 16));
+    return (i & 1) ? half_hi(w) : half_lo(w);
   }
 };
 template <> struct Vec8<float> {

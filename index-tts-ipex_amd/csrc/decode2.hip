@@ -23,7 +23,7 @@ template <> struct V8<bf16_t> {
   __device__ __forceinline__ void load(const bf16_t* p) { raw = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p)); }
   __device__ __forceinline__ float get(int i) const {
     const uint32_t w = raw[i >> 1];
-    return __uint_as_float((i & 1) ? (w & 0xFFFF0000u) : (w << 16));
+    return (i & 1) ? half_hi(w) : half_lo(w);
   }
 };
 template <> struct V8<float> {
@@ -230,7 +230,7 @@ __global__ __launch_bounds__(256) void gemv2_kernel(GemvArgs g) {
 //     16-byte weight fragment instead of 8 cvt + 8 fma (the kernels are short enough to be issue-bound);
 //   * the output can be written as bf16 (gelu(fc) feeding proj2) to halve the next kernel's LDS fill.
 // ---------------------------------------------------------------------------------------------
-typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef bf16_t bf16x2_t __attribute__((ext_vector_type(2)));
 
 template <int CTRL>
 __device__ __forceinline__ float dpp_add(float v) {
@@ -263,7 +263,7 @@ __device__ __forceinline__ uint32_t pack_bf16(float a, float b) {
 }
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float dot2(uint32_t a, uint32_t b, float c) {
-  return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, a), __builtin_bit_cast(bf16x2_t, b), c, false);
+  return half_dot2(a, b, c);
 }
 
 // PRO: 0 plain, 1 LayerNorm without affine (gamma/beta are folded into W by the packer), 2 LayerNorm(affine) then
@@ -724,7 +724,7 @@ template <> struct CacheVec<bf16_t> {
 #endif
   __device__ __forceinline__ float get(int i) const {
     const uint32_t w = (&raw.x)[i >> 1];
-    return __uint_as_float((i & 1) ? (w & 0xFFFF0000u) : (w << 16));
+    return (i & 1) ? half_hi(w) : half_lo(w);
   }
 };
 template <> struct CacheVec<float> {

@@ -55,7 +55,7 @@ namespace {
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef bf16_t bf16x2_t __attribute__((ext_vector_type(2)));
 typedef unsigned long long u64;
 
 template <int CTRL>
@@ -78,10 +78,10 @@ __device__ __forceinline__ uint32_t pack_bf16(float a, float b) {
   return __builtin_bit_cast(uint32_t, v);
 }
 __device__ __forceinline__ float dot2(uint32_t a, uint32_t b, float c) {
-  return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, a), __builtin_bit_cast(bf16x2_t, b), c, false);
+  return half_dot2(a, b, c);
 }
-__device__ __forceinline__ float bf16_lo(uint32_t w) { return __uint_as_float(w << 16); }
-__device__ __forceinline__ float bf16_hi(uint32_t w) { return __uint_as_float(w & 0xFFFF0000u); }
+__device__ __forceinline__ float bf16_lo(uint32_t w) { return half_lo(w); }
+__device__ __forceinline__ float bf16_hi(uint32_t w) { return half_hi(w); }
 
 struct KVec {  // 8 bf16 of one cache row (decode2.hip CacheVec<bf16_t>)
   u32x4 raw;

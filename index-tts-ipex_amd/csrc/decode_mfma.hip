@@ -195,7 +195,7 @@ __global__ __launch_bounds__(512) void skinny_mfma_kernel(GemvArgs g) {
         for (int t = 0; t < NT; ++t)
 #pragma unroll
           for (int bt = 0; bt < BT; ++bt)
-            acc[t][bt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[u][bt], wf[u][t], acc[t][bt], 0, 0, 0);
+            acc[t][bt] = half_mfma16(xf[u][bt], wf[u][t], acc[t][bt]);
       }
     }
   }

@@ -67,8 +67,8 @@ __global__ __launch_bounds__(256) void layernorm_vec_kernel(TO* __restrict__ y, 
       v[i][0] = t.x; v[i][1] = t.y; v[i][2] = t.z; v[i][3] = t.w;
     } else {
       const uint2 t = *reinterpret_cast<const uint2*>(xr + kc);
-      v[i][0] = __uint_as_float(t.x << 16); v[i][1] = __uint_as_float(t.x & 0xFFFF0000u);
-      v[i][2] = __uint_as_float(t.y << 16); v[i][3] = __uint_as_float(t.y & 0xFFFF0000u);
+      v[i][0] = half_lo(t.x); v[i][1] = half_hi(t.x);
+      v[i][2] = half_lo(t.y); v[i][3] = half_hi(t.y);
     }
   }
   float s = 0.f;

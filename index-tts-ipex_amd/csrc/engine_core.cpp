@@ -47,10 +47,16 @@ int Engine::tap(const char* name, const void* p, int dt, int64_t n, hipStream_t 
     ITTS_HIP_CHECK(hipMemcpyAsync(tmp.data(), p, n * 2, hipMemcpyDeviceToHost, s));
     ITTS_HIP_CHECK(hipStreamSynchronize(s));
     for (int64_t i = 0; i < n; ++i) {
+#ifdef ITTS_HALF_F16
+      _Float16 h;
+      memcpy(&h, &tmp[i], 2);
+      v[i] = (float)h;
+#else
       uint32_t u = (uint32_t)tmp[i] << 16;
       float f;
       memcpy(&f, &u, 4);
       v[i] = f;
+#endif
     }
   }
   return OK;

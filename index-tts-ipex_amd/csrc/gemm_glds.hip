@@ -144,7 +144,7 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(GemmArgs g, int tiles
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], wf[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < NT; ++j) acc[i][j] = half_mfma16(af[i], wf[j], acc[i][j]);
     }
     __syncthreads();  // stage kt + 1 has landed (vmcnt(0) in front of the barrier) and stage kt is free to be refilled
   }

@@ -167,7 +167,7 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmArgs g) {
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
-          for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < NT; ++j) acc[i][j] = half_mfma16(af[i], bfr[j], acc[i][j]);
       }
       if (NBUF == 1) __syncthreads();  // every wave has consumed the buffer before it is overwritten
       store_pair(NBUF == 2 ? (buf ^ 1) : 0, st[(d + 1) % DEPTH]);

@@ -192,9 +192,9 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmArgs g, int tiles_m, i
   __builtin_amdgcn_s_setprio(1);                                                                                       \
   _Pragma("unroll") for (int mi = 0; mi < 4; ++mi) _Pragma("unroll") for (int nj = 0; nj < 2; ++nj) {                   \
     acc[(AH) * 4 + mi][(BH) * 2 + nj] =                                                                                 \
-        __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mi][0], bfr[nj][0], acc[(AH) * 4 + mi][(BH) * 2 + nj], 0, 0, 0);     \
+        half_mfma16(af[mi][0], bfr[nj][0], acc[(AH) * 4 + mi][(BH) * 2 + nj]);     \
     acc[(AH) * 4 + mi][(BH) * 2 + nj] =                                                                                 \
-        __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mi][1], bfr[nj][1], acc[(AH) * 4 + mi][(BH) * 2 + nj], 0, 0, 0);     \
+        half_mfma16(af[mi][1], bfr[nj][1], acc[(AH) * 4 + mi][(BH) * 2 + nj]);     \
   }                                                                                                                    \
   __builtin_amdgcn_s_setprio(0);                                                                                       \
   __builtin_amdgcn_sched_barrier(0);                                                                                   \
@@ -286,14 +286,14 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmArgs g, int tiles_m, i
         if (R) {
           const bf16x8 rv = *reinterpret_cast<const bf16x8*>(R + (size_t)m * g.ldr + pcol + ncol);
 #pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] += __uint_as_float((unsigned)(unsigned short)rv[e] << 16);
+          for (int e = 0; e < 8; ++e) v[e] += half_bits((unsigned short)rv[e]);
         }
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] *= g.alpha;
         if (ADD) {
           const bf16x8 av = *reinterpret_cast<const bf16x8*>(ADD + (size_t)m * g.ldadd + pcol + ncol);
 #pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] += g.beta * __uint_as_float((unsigned)(unsigned short)av[e] << 16);
+          for (int e = 0; e < 8; ++e) v[e] += g.beta * half_bits((unsigned short)av[e]);
         }
         bf16x8 o;
 #pragma unroll

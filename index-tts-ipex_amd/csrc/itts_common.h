@@ -6,7 +6,15 @@
 
 namespace itts {
 
+// The 16-bit storage type of the engine ("half"): bfloat16 in libitts_hip.so, IEEE binary16 in libitts_hip_f16.so, which is
+// the SAME sources compiled with -DITTS_HALF_F16 - the reference's GPU precision (`is_fp16=True` is fp16 autocast / .half(),
+// indextts/infer.py:39,44,52).  Every kernel is written against `bf16_t` and the helpers below; in the f16 build the name is a
+// misnomer for _Float16 (weights, activations, K/V cache in binary16; fp32 accumulation everywhere as before).
+#ifdef ITTS_HALF_F16
+typedef _Float16 bf16_t;
+#else
 typedef __bf16 bf16_t;
+#endif
 typedef _Float16 f16_t;
 
 enum DType : int { F32 = 0, BF16 = 1, I32 = 2, I64 = 3, FP8 = 4, F16 = 5 };  // F16: operator-level boundary only (itts_snake_aa_fwd)  // FP8 = OCP e4m3fn bytes (weights only)
@@ -51,10 +59,57 @@ const char* last_error();
 // ---- device helpers ----
 __device__ __forceinline__ float ldf(const float* p) { return *p; }
 __device__ __forceinline__ float ldf(const bf16_t* p) { return (float)(*p); }
+#ifndef ITTS_HALF_F16  // (the same type there)
 __device__ __forceinline__ float ldf(const f16_t* p) { return (float)(*p); }
+#endif
 __device__ __forceinline__ void stf(float* p, float v) { *p = v; }
 __device__ __forceinline__ void stf(bf16_t* p, float v) { *p = (bf16_t)v; }
+#ifndef ITTS_HALF_F16
 __device__ __forceinline__ void stf(f16_t* p, float v) { *p = (f16_t)v; }
+#endif
+
+// ---- the half type at the bit level: two halves of a 32-bit word, the 16x16x32 matrix instruction, the 2-way dot product ----
+typedef bf16_t half2_t __attribute__((ext_vector_type(2)));
+typedef short half8_bits __attribute__((ext_vector_type(8)));  // MFMA fragments travel as 8 x 16 bits
+typedef float f32x4_acc __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float half_lo(uint32_t w) {  // element 0 (low 16 bits) of a pair
+#ifdef ITTS_HALF_F16
+  return (float)__builtin_bit_cast(_Float16, (unsigned short)(w & 0xFFFFu));
+#else
+  return __uint_as_float(w << 16);
+#endif
+}
+__device__ __forceinline__ float half_hi(uint32_t w) {
+#ifdef ITTS_HALF_F16
+  return (float)__builtin_bit_cast(_Float16, (unsigned short)(w >> 16));
+#else
+  return __uint_as_float(w & 0xFFFF0000u);
+#endif
+}
+__device__ __forceinline__ float half_bits(unsigned short h) {
+#ifdef ITTS_HALF_F16
+  return (float)__builtin_bit_cast(_Float16, h);
+#else
+  return __uint_as_float((uint32_t)h << 16);
+#endif
+}
+__device__ __forceinline__ float half_dot2(uint32_t a, uint32_t b, float c) {  // c + a.lo * b.lo + a.hi * b.hi, fp32 accumulate
+#ifdef ITTS_HALF_F16
+  typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+  return __builtin_amdgcn_fdot2(__builtin_bit_cast(h2, a), __builtin_bit_cast(h2, b), c, false);  // v_dot2_f32_f16
+#else
+  typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+  return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(b2, a), __builtin_bit_cast(b2, b), c, false);  // v_dot2c_f32_bf16
+#endif
+}
+__device__ __forceinline__ f32x4_acc half_mfma16(half8_bits a, half8_bits b, f32x4_acc c) {  // v_mfma_f32_16x16x32_{bf16,f16}
+#ifdef ITTS_HALF_F16
+  typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, a), __builtin_bit_cast(h8, b), c, 0, 0, 0);
+#else
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+#endif
+}
 
 __device__ __forceinline__ float act_apply(int act, float x) {
   switch (act) {

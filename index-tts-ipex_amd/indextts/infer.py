@@ -22,7 +22,8 @@ Same constructor and methods (`extract_features`, `infer`, `infer_fast`, `set_gr
   * the text normaliser is built and loaded as in infer.py:69-71; its third-party written-form normalisers (`tn` /
     `wetext`) are used when installed and skipped with a RuntimeWarning otherwise (punctuation folding, pinyin and name
     protection always apply);
-  * `is_fp16=True` selects the bf16 throughput engine, `False` the fp32 parity engine; `use_cuda_kernel` is accepted
+  * `is_fp16=True` selects the IEEE-half engine (the reference's own GPU precision; ITTS_HALF=bf16: the bfloat16 engine, same
+    speed), `False` the fp32 parity engine; `use_cuda_kernel` is accepted
     and ignored (the fused HIP activation is always used).
 There is no CPU fallback: without a GPU / libitts_hip.so construction raises."""
 from __future__ import annotations
@@ -57,7 +58,12 @@ class IndexTTS:
         self.use_cuda_kernel = True
         self.cfg = cfg if cfg is not None else icfg.load_yaml(cfg_path)
         self.model_dir = model_dir
-        self.dtype = torch.bfloat16 if self.is_fp16 else torch.float32
+        # is_fp16=True is IEEE half in the reference (autocast(dtype=torch.float16) + .half(), infer.py:39,44,52): the f16 build of the
+        # library.  ITTS_HALF=bf16 selects the bfloat16 engine instead (same speed, 8 instead of 11 significand bits, wider range)
+        self.half = os.environ.get("ITTS_HALF", "f16") if self.is_fp16 else None
+        if self.half not in (None, "f16", "bf16"):
+            raise ValueError(f"ITTS_HALF={self.half}: expected f16 or bf16")
+        self.dtype = (torch.float16 if self.half == "f16" else torch.bfloat16) if self.is_fp16 else torch.float32
         self.stop_mel_token = self.cfg.gpt.stop_mel_token
         sds = dict(state_dicts or {})
         if "gpt" not in sds:
@@ -68,7 +74,7 @@ class IndexTTS:
             self.bigvgan_path = os.path.join(model_dir, self.cfg.bigvgan_checkpoint)
             sds["bigvgan"] = read_state_dict(self.bigvgan_path, key="generator")
             print(">> bigvgan weights restored from:", self.bigvgan_path)
-        self.engine = ieng.Engine(self.cfg, "bf16" if self.is_fp16 else "fp32", self.device)
+        self.engine = ieng.Engine(self.cfg, self.half if self.is_fp16 else "fp32", self.device)
         self.engine.load_packed(pack.pack_gpt(sds["gpt"], self.cfg))
         self.engine.load_packed(pack.pack_bigvgan(sds["bigvgan"], self.cfg))
         if "dvae" in sds:

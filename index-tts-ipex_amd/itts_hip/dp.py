@@ -74,13 +74,14 @@ def replicate_packed(engine, packers: Sequence, src: int = 0):
         if ws == 1:
             arenas.append(engine.load_packed(fn()))
             continue
-        arena = ieng.WeightArena(fn(), engine.dt, engine.device) if rank == src else None
+        half = getattr(engine, "half_dtype", torch.bfloat16)  # the engine's 16-bit storage type (float16 for the f16 build)
+        arena = ieng.WeightArena(fn(), engine.dt, engine.device, half) if rank == src else None
         on_host = dist.get_backend() != "nccl"
         buf = None if arena is None else (arena.buf.cpu() if on_host else arena.buf)
         buf, manifest = broadcast_arena(buf, None if arena is None else arena.manifest, src=src)
         if arena is None:
             arena = ieng.WeightArena.__new__(ieng.WeightArena)
-            arena.dtype, arena.manifest, arena.nbytes = engine.dt, manifest, int(buf.numel())
+            arena.dtype, arena.manifest, arena.nbytes, arena.half = engine.dt, manifest, int(buf.numel()), half
             arena.buf = buf.to(engine.device) if on_host else buf
         engine.load_packed(None, arena=arena)
         arenas.append(arena)

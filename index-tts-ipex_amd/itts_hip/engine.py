@@ -55,8 +55,10 @@ def make_config(cfg, dtype: int, max_batch: int = 64) -> L.Config:
 class WeightArena:
     """All packed tensors in ONE device buffer (256-byte aligned slots) + a manifest."""
 
-    def __init__(self, packed: Dict[str, Tuple[str, np.ndarray]], dtype: int, device):
+    def __init__(self, packed: Dict[str, Tuple[str, np.ndarray]], dtype: int, device, half=torch.bfloat16):
+        """half: the torch dtype of the engine's 16-bit storage type (bfloat16, or float16 for the f16 build of the library)."""
         self.dtype = dtype
+        self.half = half
         self.manifest: List[Tuple[str, int, int, Tuple[int, ...]]] = []  # name, offset, dt, shape
         off = 0
         for name, (tag, arr) in packed.items():
@@ -74,7 +76,7 @@ class WeightArena:
                 continue
             t = torch.from_numpy(np.ascontiguousarray(arr, dtype=np.float32))
             if dt == L.BF16:
-                t = t.to(torch.bfloat16)
+                t = t.to(half)
             n = t.numel() * t.element_size()
             self.buf[o:o + n].copy_(t.reshape(-1).view(torch.uint8), non_blocking=False)
 
@@ -82,7 +84,7 @@ class WeightArena:
         for n, o, dt, shape in self.manifest:
             if n == name:
                 nb = int(np.prod(shape)) * _DT_BYTES[dt]
-                return self.buf[o:o + nb].view(_TORCH_DT[dt]).view(*shape)
+                return self.buf[o:o + nb].view(self.half if dt == L.BF16 else _TORCH_DT[dt]).view(*shape)
         raise KeyError(name)
 
 
@@ -90,22 +92,29 @@ class Engine:
     def __init__(self, cfg, dtype: str = "bf16", device: str = "cuda:0", max_batch: int = 64):
         if not torch.cuda.is_available():
             raise RuntimeError("itts_hip.Engine needs an MI355X (no CPU fallback in the product path)")
-        self.lib = L.load()
+        # "f16": IEEE half storage (the reference's GPU precision, infer.py:39,44,52) = the second build of the library, in
+        # which the 16-bit dtype code means binary16; everything else is the same engine
+        self.half_name = "f16" if dtype in ("f16", "fp16", "half") else "bf16"
+        self.lib = L.load(self.half_name)
         self.cfg = cfg
-        self.dt = {"fp32": L.F32, "f32": L.F32, "bf16": L.BF16}[dtype]
-        self.tdt = _TORCH_DT[self.dt]
+        self.dt = {"fp32": L.F32, "f32": L.F32, "bf16": L.BF16, "f16": L.BF16, "fp16": L.BF16, "half": L.BF16}[dtype]
+        self.half_dtype = torch.float16 if self.half_name == "f16" else torch.bfloat16
+        self.tdt = self.half_dtype if self.dt == L.BF16 else _TORCH_DT[self.dt]
         self.device = torch.device(device)
         torch.cuda.set_device(self.device)
         self.stream = torch.cuda.Stream(device=self.device)
         self.ccfg = make_config(cfg, self.dt, max_batch)
         h = C.c_void_p()
-        L.check(self.lib.itts_engine_create(C.byref(self.ccfg), C.byref(h)), "engine_create")
+        self._ck(self.lib.itts_engine_create(C.byref(self.ccfg), C.byref(h)), "engine_create")
         self.h = h
         self.arenas: List[WeightArena] = []
         # one engine = one decode state + captured graphs: callers on several host threads (the reference web UI starts a
         # worker thread per request into one IndexTTS, webui.py:441-452) serialise on this lock in the drop-in classes
         self.lock = threading.RLock()
         self.up_total = int(np.prod(cfg["bigvgan"]["upsample_rates"]))
+
+    def _ck(self, status, what=""):
+        L.check(status, what, self.lib)
 
     def __del__(self):
         try:
@@ -118,23 +127,23 @@ class Engine:
 
     # ---- weights ----
     def load_packed(self, packed: Dict[str, Tuple[str, np.ndarray]], arena: Optional[WeightArena] = None):
-        a = arena or WeightArena(packed, self.dt, self.device)
+        a = arena or WeightArena(packed, self.dt, self.device, self.half_dtype)
         self.arenas.append(a)
         base = a.buf.data_ptr()
         for name, off, dt, shape in a.manifest:
             dims = (C.c_int64 * len(shape))(*shape)
-            L.check(self.lib.itts_engine_bind_tensor(self.h, name.encode(), C.c_void_p(base + off), dt, len(shape), dims),
+            self._ck(self.lib.itts_engine_bind_tensor(self.h, name.encode(), C.c_void_p(base + off), dt, len(shape), dims),
                     f"bind {name}")
         return a
 
     def finalize(self):
-        L.check(self.lib.itts_engine_finalize(self.h), "finalize")
+        self._ck(self.lib.itts_engine_finalize(self.h), "finalize")
 
     def debug(self, taps: bool = False, force_simple: bool = False, no_graph: bool = False, fuse: bool = False,
               no_engine: bool = False, engine: bool = False):
         """no_engine: keep the five-launches-per-layer decode step instead of the persistent decode engine; engine: use
         the persistent engine (where it applies) whatever ITTS_ENGINE / the built-in default says (A/B, parity tests)."""
-        L.check(self.lib.itts_debug_enable(self.h, int(taps) | (int(force_simple) << 1) | (int(no_graph) << 2) | (int(fuse) << 3)
+        self._ck(self.lib.itts_debug_enable(self.h, int(taps) | (int(force_simple) << 1) | (int(no_graph) << 2) | (int(fuse) << 3)
                                            | (int(no_engine) << 4) | (int(engine) << 5)))
 
     def fetch_tap(self, name: str) -> np.ndarray:
@@ -168,9 +177,9 @@ class Engine:
         out = torch.empty(1, self.ccfg.cond_latents, self.ccfg.model_dim, dtype=torch.float32, device=self.device)
         self._enter()
         if length is not None and int(length) < F:
-            L.check(self.lib.itts_conditioning_padded(self.h, mel.data_ptr(), int(length), F, out.data_ptr(), self._s()), "conditioning")
+            self._ck(self.lib.itts_conditioning_padded(self.h, mel.data_ptr(), int(length), F, out.data_ptr(), self._s()), "conditioning")
         else:
-            L.check(self.lib.itts_conditioning(self.h, mel.data_ptr(), F, out.data_ptr(), self._s()), "conditioning")
+            self._ck(self.lib.itts_conditioning(self.h, mel.data_ptr(), F, out.data_ptr(), self._s()), "conditioning")
         self._exit()
         mel.record_stream(self.stream)
         return out
@@ -181,7 +190,7 @@ class Engine:
         B, F, _ = mel.shape
         out = torch.empty(B, self.ccfg.bv_spk_dim, dtype=torch.float32, device=self.device)
         self._enter()
-        L.check(self.lib.itts_ecapa(self.h, mel.data_ptr(), B, F, out.data_ptr(), self._s()), "ecapa")
+        self._ck(self.lib.itts_ecapa(self.h, mel.data_ptr(), B, F, out.data_ptr(), self._s()), "ecapa")
         self._exit()
         mel.record_stream(self.stream)
         return out
@@ -194,9 +203,9 @@ class Engine:
         cond = cond.to(device=self.device, dtype=torch.float32).contiguous().view(-1, self.ccfg.model_dim)
         per_row = cond.shape[0] == B * self.ccfg.cond_latents and B > 1  # one prompt per row (a batch of prompts)
         assert per_row or cond.shape[0] == self.ccfg.cond_latents, cond.shape
-        L.check(self.lib.itts_gpt_set_cond_per_row(self.h, int(per_row)), "gpt_set_cond_per_row")
+        self._ck(self.lib.itts_gpt_set_cond_per_row(self.h, int(per_row)), "gpt_set_cond_per_row")
         self._enter()
-        L.check(self.lib.itts_gpt_prefill(self.h, cond.data_ptr(), ids.ctypes.data_as(C.c_void_p), B, Lt, max_gen,
+        self._ck(self.lib.itts_gpt_prefill(self.h, cond.data_ptr(), ids.ctypes.data_as(C.c_void_p), B, Lt, max_gen,
                                           float(repetition_penalty), int(suppress_stop), self._s()), "gpt_prefill")
         self._gen = (B, max_gen)
 
@@ -205,10 +214,10 @@ class Engine:
         """HF GenerationMixin.sample configuration (infer.py:116-124) for the following prefill/decode calls;
         uniforms [max_gen, B] float32 in [0, 1) are the draws (step k, row b)."""
         if not do_sample:
-            L.check(self.lib.itts_gpt_set_sampling(self.h, 0, 0, 1.0, 1.0, None, 0), "gpt_set_sampling")
+            self._ck(self.lib.itts_gpt_set_sampling(self.h, 0, 0, 1.0, 1.0, None, 0), "gpt_set_sampling")
             return
         u = np.ascontiguousarray(uniforms, dtype=np.float32)
-        L.check(self.lib.itts_gpt_set_sampling(self.h, 1, int(top_k), float(top_p), float(temperature),
+        self._ck(self.lib.itts_gpt_set_sampling(self.h, 1, int(top_k), float(top_p), float(temperature),
                                                u.ctypes.data_as(C.c_void_p), u.size), "gpt_set_sampling")
 
     def set_beam_sample(self, num_beams: int, top_k: int = 30, top_p: float = 0.8, temperature: float = 1.0,
@@ -219,15 +228,15 @@ class Engine:
         generations.  num_beams <= 1 switches beams off.  num_return_sequences: the n best hypotheses per row (fetch
         returns [B * n, max_gen], best first)."""
         if num_beams <= 1:
-            L.check(self.lib.itts_gpt_set_beams(self.h, 1, 1, 1, 1.0, 1.0, 0.0, None, 0), "gpt_set_beams")
-            L.check(self.lib.itts_gpt_set_beam_returns(self.h, 1), "gpt_set_beam_returns")
+            self._ck(self.lib.itts_gpt_set_beams(self.h, 1, 1, 1, 1.0, 1.0, 0.0, None, 0), "gpt_set_beams")
+            self._ck(self.lib.itts_gpt_set_beam_returns(self.h, 1), "gpt_set_beam_returns")
             self._nb, self._nret = 1, 1
             return
-        L.check(self.lib.itts_gpt_set_beam_returns(self.h, int(num_return_sequences)), "gpt_set_beam_returns")
+        self._ck(self.lib.itts_gpt_set_beam_returns(self.h, int(num_return_sequences)), "gpt_set_beam_returns")
         self._nret = int(num_return_sequences)
         dev_draws = do_sample and not host  # host: the caller warps and draws (any top_k), the library needs no uniforms
         u = np.ascontiguousarray(uniforms, dtype=np.float32) if dev_draws else None
-        L.check(self.lib.itts_gpt_set_beams(self.h, int(num_beams), int(bool(do_sample)), int(top_k), float(top_p), float(temperature),
+        self._ck(self.lib.itts_gpt_set_beams(self.h, int(num_beams), int(bool(do_sample)), int(top_k), float(top_p), float(temperature),
                                             float(length_penalty), u.ctypes.data_as(C.c_void_p) if dev_draws else None,
                                             u.size if dev_draws else 0), "gpt_set_beams")
         self._nb = int(num_beams)
@@ -235,37 +244,37 @@ class Engine:
     def set_forced(self, ids: Optional[np.ndarray]):
         """Forced tokens [B or 1, n] (int, -1 = free) for the first n steps of the following generations; None clears."""
         if ids is None or np.asarray(ids).size == 0:
-            L.check(self.lib.itts_gpt_set_forced(self.h, None, 0, 0), "gpt_set_forced")
+            self._ck(self.lib.itts_gpt_set_forced(self.h, None, 0, 0), "gpt_set_forced")
             return
         a = np.ascontiguousarray(np.atleast_2d(ids), dtype=np.int32)
-        L.check(self.lib.itts_gpt_set_forced(self.h, a.ctypes.data_as(C.c_void_p), a.shape[0], a.shape[1]), "gpt_set_forced")
+        self._ck(self.lib.itts_gpt_set_forced(self.h, a.ctypes.data_as(C.c_void_p), a.shape[0], a.shape[1]), "gpt_set_forced")
 
     def set_input_tokens(self, ids: Optional[np.ndarray]):
         """HF `input_tokens` [B or 1, n] (inference_speech, model.py:672-686) for the following generations: forced like
         set_forced, at the reference's positions (token k at mel position k + 1); None clears."""
         if ids is None or np.asarray(ids).size == 0:
-            L.check(self.lib.itts_gpt_set_input_tokens(self.h, None, 0, 0), "gpt_set_input_tokens")
+            self._ck(self.lib.itts_gpt_set_input_tokens(self.h, None, 0, 0), "gpt_set_input_tokens")
             return
         a = np.ascontiguousarray(np.atleast_2d(ids), dtype=np.int32)
-        L.check(self.lib.itts_gpt_set_input_tokens(self.h, a.ctypes.data_as(C.c_void_p), a.shape[0], a.shape[1]), "gpt_set_input_tokens")
+        self._ck(self.lib.itts_gpt_set_input_tokens(self.h, a.ctypes.data_as(C.c_void_p), a.shape[0], a.shape[1]), "gpt_set_input_tokens")
 
     def decode_mode(self) -> int:
         """1 if the last decode step ran on the persistent decode engine, 0 for the five-launches-per-block path."""
         return int(self.lib.itts_gpt_decode_mode(self.h))
 
     def decode(self, nsteps: int):
-        L.check(self.lib.itts_gpt_decode(self.h, nsteps, self._s()), "gpt_decode")
+        self._ck(self.lib.itts_gpt_decode(self.h, nsteps, self._s()), "gpt_decode")
 
     def status(self) -> Tuple[int, int]:
         a, b = C.c_int(), C.c_int()
-        L.check(self.lib.itts_gpt_status(self.h, C.byref(a), C.byref(b), self._s()), "gpt_status")
+        self._ck(self.lib.itts_gpt_status(self.h, C.byref(a), C.byref(b), self._s()), "gpt_status")
         return a.value, b.value
 
     def fetch(self, logits: bool = False):
         B, mg = self._gen
         codes = np.empty((B * (getattr(self, "_nret", 1) if getattr(self, "_nb", 1) > 1 else 1), mg), dtype=np.int32)
         lg = np.empty((B * getattr(self, "_nb", 1), self.ccfg.number_mel_codes), dtype=np.float32) if logits else None
-        L.check(self.lib.itts_gpt_fetch(self.h, codes.ctypes.data_as(C.c_void_p),
+        self._ck(self.lib.itts_gpt_fetch(self.h, codes.ctypes.data_as(C.c_void_p),
                                         lg.ctypes.data_as(C.c_void_p) if logits else None, self._s()), "gpt_fetch")
         return (codes, lg) if logits else codes
 
@@ -308,7 +317,7 @@ class Engine:
                                                temperature, seed, uniforms, typical_mass)
         typical = bool(typical_mass)
         if typical:  # typical_sampling=True (model.py:690-697): TypicalLogitsWarper behind the repetition penalty, in every mode
-            L.check(self.lib.itts_gpt_set_typical(self.h, float(typical_mass)), "gpt_set_typical")
+            self._ck(self.lib.itts_gpt_set_typical(self.h, float(typical_mass)), "gpt_set_typical")
         if beams:
             if uniforms is None and do_sample:
                 uniforms = np.random.default_rng(seed).random((max_gen, nrow, 2 * num_beams), dtype=np.float32)
@@ -335,7 +344,7 @@ class Engine:
             self._exit()
         finally:
             if typical:
-                L.check(self.lib.itts_gpt_set_typical(self.h, 0.0), "gpt_set_typical")
+                self._ck(self.lib.itts_gpt_set_typical(self.h, 0.0), "gpt_set_typical")
             if beams:
                 self.set_beam_sample(1)
             elif do_sample:
@@ -363,7 +372,7 @@ class Engine:
         unfinished = np.ones(nrow, dtype=bool)
         out = np.full((nrow, max_gen), stop, dtype=np.int64)
         n = 0
-        L.check(self.lib.itts_gpt_set_host_sampling(self.h, 1), "gpt_set_host_sampling")
+        self._ck(self.lib.itts_gpt_set_host_sampling(self.h, 1), "gpt_set_host_sampling")
         try:
             self.prefill(cond, text_ids, max_gen, repetition_penalty, suppress_stop)
             for k in range(max_gen):
@@ -371,7 +380,7 @@ class Engine:
                 toks = infer_core.host_sample_step(lg, seen, float(repetition_penalty), float(temperature), top_k, top_p,
                                                    float(typical_mass or 0.0), uniforms[k], stop, bool(suppress_stop))
                 toks = np.where(unfinished, toks, stop).astype(np.int32)
-                L.check(self.lib.itts_gpt_commit(self.h, toks.ctypes.data_as(C.c_void_p), self._s()), "gpt_commit")
+                self._ck(self.lib.itts_gpt_commit(self.h, toks.ctypes.data_as(C.c_void_p), self._s()), "gpt_commit")
                 out[:, k] = toks
                 n = k + 1
                 for r in range(nrow):
@@ -382,7 +391,7 @@ class Engine:
                 self.decode(1)
             self._exit()
         finally:
-            L.check(self.lib.itts_gpt_set_host_sampling(self.h, 0), "gpt_set_host_sampling")
+            self._ck(self.lib.itts_gpt_set_host_sampling(self.h, 0), "gpt_set_host_sampling")
         return out[:, :n]
 
     def _generate_host_beams(self, cond, text_ids, max_gen, repetition_penalty, suppress_stop, top_k, top_p, temperature, seed,
@@ -402,23 +411,23 @@ class Engine:
         scores = np.empty(items * nb, dtype=np.float32)
         done = np.empty(items, dtype=np.int32)
         step = C.c_int()
-        L.check(self.lib.itts_gpt_set_host_sampling(self.h, 1), "gpt_set_host_sampling")
+        self._ck(self.lib.itts_gpt_set_host_sampling(self.h, 1), "gpt_set_host_sampling")
         try:
             self.set_beam_sample(nb, top_k, top_p, temperature, None, do_sample=True, length_penalty=length_penalty,
                                  num_return_sequences=num_return_sequences, host=True)
             self.prefill(cond, text_ids, max_gen, repetition_penalty, suppress_stop)
             while True:
-                L.check(self.lib.itts_gpt_beam_state(self.h, hist.ctypes.data_as(C.c_void_p), scores.ctypes.data_as(C.c_void_p),
+                self._ck(self.lib.itts_gpt_beam_state(self.h, hist.ctypes.data_as(C.c_void_p), scores.ctypes.data_as(C.c_void_p),
                                                      done.ctypes.data_as(C.c_void_p), C.byref(step), self._s()), "gpt_beam_state")
                 k = step.value
                 if k >= max_gen or done.all():
                     break
                 lg = np.empty((items * nb, self.ccfg.number_mel_codes), dtype=np.float32)
-                L.check(self.lib.itts_gpt_fetch(self.h, None, lg.ctypes.data_as(C.c_void_p), self._s()), "gpt_fetch")
+                self._ck(self.lib.itts_gpt_fetch(self.h, None, lg.ctypes.data_as(C.c_void_p), self._s()), "gpt_fetch")
                 psc, ptok, pbeam = infer_core.host_beam_step(lg, hist, k, scores, done, nb, float(repetition_penalty), float(temperature),
                                                              top_k, top_p, float(typical_mass or 0.0), u[k], stop, bool(suppress_stop),
                                                              start)
-                L.check(self.lib.itts_gpt_commit_beams(self.h, psc.ctypes.data_as(C.c_void_p), ptok.ctypes.data_as(C.c_void_p),
+                self._ck(self.lib.itts_gpt_commit_beams(self.h, psc.ctypes.data_as(C.c_void_p), ptok.ctypes.data_as(C.c_void_p),
                                                        pbeam.ctypes.data_as(C.c_void_p), self._s()), "gpt_commit_beams")
                 if k + 1 >= max_gen:
                     break
@@ -428,7 +437,7 @@ class Engine:
             self._exit()
         finally:
             self.set_beam_sample(1)
-            L.check(self.lib.itts_gpt_set_host_sampling(self.h, 0), "gpt_set_host_sampling")
+            self._ck(self.lib.itts_gpt_set_host_sampling(self.h, 0), "gpt_set_host_sampling")
         n = 0
         for row in codes:
             hit = np.nonzero(row == stop)[0]
@@ -442,7 +451,7 @@ class Engine:
         cond = cond.to(device=self.device, dtype=torch.float32).contiguous().view(-1, self.ccfg.model_dim)
         out = torch.empty(1, c.shape[0], self.ccfg.model_dim, dtype=self.tdt, device=self.device)
         self._enter()
-        L.check(self.lib.itts_gpt_latent(self.h, cond.data_ptr(), t.ctypes.data_as(C.c_void_p), t.shape[0],
+        self._ck(self.lib.itts_gpt_latent(self.h, cond.data_ptr(), t.ctypes.data_as(C.c_void_p), t.shape[0],
                                          c.ctypes.data_as(C.c_void_p), c.shape[0], out.data_ptr(), self._s()), "gpt_latent")
         self._exit()
         return out
@@ -457,7 +466,7 @@ class Engine:
         cond = cond.to(device=self.device, dtype=torch.float32).contiguous().view(-1, self.ccfg.model_dim)
         out = torch.empty(int(cl.sum()), self.ccfg.model_dim, dtype=self.tdt, device=self.device)
         self._enter()
-        L.check(self.lib.itts_gpt_latent_batch(self.h, cond.data_ptr(), tcat.ctypes.data_as(C.c_void_p),
+        self._ck(self.lib.itts_gpt_latent_batch(self.h, cond.data_ptr(), tcat.ctypes.data_as(C.c_void_p),
                                                tl.ctypes.data_as(C.c_void_p), ccat.ctypes.data_as(C.c_void_p),
                                                cl.ctypes.data_as(C.c_void_p), len(ts), out.data_ptr(), self._s()),
                 "gpt_latent_batch")
@@ -475,7 +484,7 @@ class Engine:
         spk = spk.to(device=self.device, dtype=torch.float32).contiguous().view(B, -1)
         out = torch.empty(B, 1, T * self.up_total, dtype=torch.float32, device=self.device)
         self._enter()
-        L.check(self.lib.itts_bigvgan(self.h, lat.data_ptr(), spk.data_ptr(), B, T, out.data_ptr(), self._s()), "bigvgan")
+        self._ck(self.lib.itts_bigvgan(self.h, lat.data_ptr(), spk.data_ptr(), B, T, out.data_ptr(), self._s()), "bigvgan")
         self._exit()
         lat.record_stream(self.stream)
         spk.record_stream(self.stream)
@@ -488,7 +497,7 @@ class Engine:
         Tc = _dvae_code_len(T, self.ccfg.dv_layers)
         codes = np.empty((B, Tc), dtype=np.int32)
         self._enter()
-        L.check(self.lib.itts_dvae_encode(self.h, mel.data_ptr(), B, T, codes.ctypes.data_as(C.c_void_p), self._s()), "dvae_encode")
+        self._ck(self.lib.itts_dvae_encode(self.h, mel.data_ptr(), B, T, codes.ctypes.data_as(C.c_void_p), self._s()), "dvae_encode")
         self._exit()
         return codes.astype(np.int64)
 
@@ -517,7 +526,7 @@ class Engine:
         up = 2 ** self.ccfg.dv_layers
         out = torch.empty(B, T * up, ch, dtype=self.tdt, device=self.device)
         self._enter()
-        L.check(self.lib.itts_dvae_decode(self.h, c.ctypes.data_as(C.c_void_p), B, T, out.data_ptr(), self._s()), "dvae_decode")
+        self._ck(self.lib.itts_dvae_decode(self.h, c.ctypes.data_as(C.c_void_p), B, T, out.data_ptr(), self._s()), "dvae_decode")
         self._exit()
         return out.transpose(1, 2)
 

@@ -12,6 +12,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.normpath(os.path.join(_HERE, "..", "csrc"))
 LIB_PATH = os.environ.get("ITTS_HIP_LIB", os.path.join(CSRC, "libitts_hip.so"))
+LIB_PATH_F16 = os.environ.get("ITTS_HIP_LIB_F16", os.path.join(CSRC, "libitts_hip_f16.so"))  # the same sources, IEEE half storage
 
 F32, BF16 = 0, 1
 FP8 = 4  # OCP e4m3fn bytes (GPT decode weights, BASELINE config 5)
@@ -54,10 +55,12 @@ class Config(C.Structure):
 
 
 _lib = None
+_lib_f16 = None
 
 _PROTOS = {
     "itts_last_error": (C.c_char_p, []),
     "itts_abi_version": (i32, []),
+    "itts_half_is_f16": (i32, []),
     "itts_gpt_set_beam_returns": (i32, [vp, i32]),
     "itts_snake_aa_fwd": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "itts_gemm": (i32, [C.POINTER(GemmArgs), vp]),
@@ -107,26 +110,37 @@ def exported_symbols():
     return sorted(_PROTOS)
 
 
-def load():
-    """dlopen the library and attach prototypes.  No GPU work happens here."""
-    global _lib
+def load(half: str = "bf16"):
+    """dlopen the library and attach prototypes.  No GPU work happens here.  half = "f16": the build whose 16-bit storage type
+    is IEEE binary16 (libitts_hip_f16.so) - a second, independent library object with its own engines and error state."""
+    global _lib, _lib_f16
+    if half == "f16":
+        if _lib_f16 is None:
+            _lib_f16 = _open(LIB_PATH_F16)
+            assert _lib_f16.itts_half_is_f16() == 1
+        return _lib_f16
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
+    _lib = _open(LIB_PATH)
+    assert _lib.itts_half_is_f16() == 0
+    return _lib
+
+
+def _open(path):
+    if not os.path.exists(path):
         raise RuntimeError(
-            f"libitts_hip.so not found at {LIB_PATH}: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            f"{os.path.basename(path)} not found at {path}: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             f"or `make -C {CSRC}` (there is no CPU fallback)")
     # torch ships its own libamdhip64; the process must run ONE HIP runtime, and device pointers / streams come from
     # torch, so torch's copy has to be the one already loaded when this library resolves its HIP symbols (loading
     # libitts_hip first pulls in /opt/rocm's runtime and the engine then sees no device)
     import torch  # noqa: F401
 
-    lib = C.CDLL(LIB_PATH)
+    lib = C.CDLL(path)
     for name, (res, args) in _PROTOS.items():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
-    _lib = lib
     return lib
 
 
@@ -138,9 +152,9 @@ class HandoffTimeout(RuntimeError):
     object has switched to the launch path; generating again is safe (Engine.generate does it once)."""
 
 
-def check(status: int, what: str = ""):
+def check(status: int, what: str = "", lib=None):
     if status != 0:
-        msg = load().itts_last_error().decode("utf-8", "replace")
+        msg = (lib or load()).itts_last_error().decode("utf-8", "replace")
         if status == E_HANDOFF:
             raise HandoffTimeout(f"libitts_hip {what} failed ({status}): {msg}")
         raise RuntimeError(f"libitts_hip {what} failed ({status}): {msg}")
