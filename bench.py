@@ -305,7 +305,7 @@ def measure(eng, cfg, a, BU, steps, warmup, rank, world, product_loop=False):
     # mean S and dtype match it
     traffic, traffic_src = None, None
     try:
-        pm = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_decode.json"))
+        pm = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_decode.json") or f.endswith("_pmc_decode_b32.json"))
         for f in reversed(pm):
             pj = json.load(open(os.path.join(ROOT, "profiles", f)))
             if (int(pj.get("decode_rows", -1)) == B * a.beams and abs(float(pj.get("mean_S", -1)) - s_bar) <= 2.0 and a.dtype == "bf16"

@@ -25,7 +25,7 @@ nsamp = max((c for k, c in cnt.items() if "sampler" in k), default=1)
 steps = neng if neng > nsamp else max(nsamp - 1, 1)
 dec = 0.0
 for k, v in tot.items():
-    if "gemv" in k or "decode_attn" in k or "sampler" in k or "decode_engine" in k:
+    if "gemv" in k or "decode_attn" in k or "sampler" in k or "decode_engine" in k or "skinny_mfma" in k or "ln_rows" in k:
         per = v / cnt[k]
         launches_in_loop = cnt[k] - (1 if cnt[k] % steps == 1 else 0)
         dec += per * launches_in_loop

@@ -43,6 +43,29 @@ json.dump({"kernels_head": head, "engine": "$(echo ${ITTS_ENGINE:-1})", "mel_tok
           open("$out/pmc_decode.json", "w"), indent=1)
 print(open("$out/pmc_decode.json").read())
 PY
+# BASELINE config 3's decode step (64 rows: 97 skinny MFMA projections + 49 LayerNorm + 24 cache attention + sampler per step): the
+# same two passes on `--batch 32`, 48 steps behind a text prefix lengthened so that the mean sequence length is the timed run's
+# (S = 32 + 320 + 3 + 24 = 379 against 380: same kernels, same grids, same bytes per step; ~8 k counted dispatches)
+for c in FETCH_SIZE WRITE_SIZE; do
+  timeout -k 10 500 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $out/pmc32_$c -- python3 $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --batch 32 --mel-tokens 48 --text-tokens 320 --no-graph --no-cpu-baseline --no-also > $out/pmc32_$c.json 2> $out/pmc32_$c.err
+  f=$(find $out/pmc32_$c -name "*counter_collection.csv" | head -1)
+  python3 $GRAFT_REPO_ROOT/tools/pmc_summary.py "$f" $c $out/pmc32_${c}_step.json > $out/pmc32_$c.txt
+  rm -rf $out/pmc32_$c
+  head -12 $out/pmc32_$c.txt | cut -c1-170
+done
+python3 - <<PY
+import json
+f = json.load(open("$out/pmc32_FETCH_SIZE_step.json")); w = json.load(open("$out/pmc32_WRITE_SIZE_step.json"))
+D, NL, V, B, L, T = 1280, 24, 8194, 64, 320, 48
+alg = (NL * (12 * D * D + 13 * D) + 4 * D + D * V + V) * 2 + B * 2 * NL * D * 2 * ((32 + L + 2 + 1) + T / 2.0)
+hbm = (2.0 * f["per_step_units"] + w["per_step_units"]) * 1024
+import subprocess
+head = subprocess.run(["git", "-C", "$GRAFT_REPO_ROOT", "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip() or "$(cat $GRAFT_REPO_ROOT/.git_head 2>/dev/null)"
+json.dump({"kernels_head": head, "engine": "0", "mel_tokens": T, "text_tokens": L, "mean_S": (32 + L + 2 + 1) + T / 2.0, "decode_rows": B, "fetch_kib_raw_per_step": f["per_step_units"], "write_kib_per_step": w["per_step_units"],
+           "hbm_bytes_per_step": hbm, "algorithmic_bytes_per_step": alg, "traffic_over_algorithmic": hbm / alg},
+          open("$out/pmc_decode_b32.json", "w"), indent=1)
+print(open("$out/pmc_decode_b32.json").read())
+PY
 if [ -n "$SEGV_PROBE" ]; then
   # the r02 SIGSEGV: ONE full-length pass of the 122-launches-per-step path (58 k counted dispatches) with Python's
   # faulthandler on, so the dump says where the process was - inside a library call of ours, or in the tool's finalisation
