@@ -717,7 +717,7 @@ __global__ __launch_bounds__(1024) void decode_engine_kernel(EngArgs a) {
         __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): nothing the compiler counts stays pending past the gather branch
       } else {
         wait_own(own_lds, NCW * phase, rt);
-        sweep2<(NB * D / 2 + 255) / 256, false>(G - LSTRIDE + OH2, NB * D / 2, tl, rt, [&](int i, uint32_t v) { xf[i] = __uint_as_float(v); }, rt.first_delay);
+        sweep2<(NB * D / 2 + 255) / 256, false>(G - LSTRIDE + OH2, NB * D / 2 / a.fake_div, tl, rt, [&](int i, uint32_t v) { xf[i] = __uint_as_float(v); }, rt.first_delay);
       }
       if (early_kv) kv_issue(Ic0{}, IcE{});
     } else if (lw) {
@@ -1001,7 +1001,7 @@ __global__ __launch_bounds__(1024) void decode_engine_kernel(EngArgs a) {
     // ================= P4: residual stream -> LN2 -> c_fc -> gelu_new =================
     if (gw) {
       wait_own(own_lds, NCW * phase, rt);
-      sweep2<(NB * D / 2 + 255) / 256, false>(G + OH1, NB * D / 2, tl, rt, [&](int i, uint32_t v) { xf[i] = __uint_as_float(v); }, rt.first_delay);
+      sweep2<(NB * D / 2 + 255) / 256, false>(G + OH1, NB * D / 2 / a.fake_div, tl, rt, [&](int i, uint32_t v) { xf[i] = __uint_as_float(v); }, rt.first_delay);
     } else if (lw) {
       dma_wait_keep<0>();  // c_fc (and, before it, mlp.c_proj)
     }
@@ -1053,7 +1053,7 @@ __global__ __launch_bounds__(1024) void decode_engine_kernel(EngArgs a) {
     // ================= P5: gelu(fc) -> mlp.c_proj + residual =================
     if (gw) {
       wait_own(own_lds, NCW * phase, rt);
-      sweep2<(NB * D + 255) / 256, false>(G + OACT, NB * D, tl, rt, [&](int i, uint32_t v) { xa[i] = v; }, a.act_delay);
+      sweep2<(NB * D + 255) / 256, false>(G + OACT, NB * D / a.fake_div, tl, rt, [&](int i, uint32_t v) { xa[i] = v; }, a.act_delay);
     } else if (lw && HALFB) {
       wait_own(own_lds, NCW * phase, rt);  // every compute wave is through c_fc: slot A is free
       dma_rows_part<HO, 4 * D, 2 * D, 2 * D>(w.w2, nullptr, cu * HO, S0, ll);  // second half of mlp.c_proj -> A

@@ -47,6 +47,7 @@ struct EngArgs {
   unsigned long long* cand = nullptr;  // [B][256][2] hand-off granules of the candidates (tail of the granule buffer)
   int early_fc = 0;                   // > 0: c_fc requested this many x 64 clocks behind c_attn on the workgroups without attention
   int early_kv = 1;                   // the attention workgroups request their cache rows at the head of the block (0: behind c_attn, the r03 placement)
+  int fake_div = 1;                   // TIMING PROBE ONLY (ITTS_ENG_FAKE_DIV): gather 1 / fake_div of the h and gelu(fc) edges - wrong results
   int thin_fc = 0;                    // the loader keeps at most 12 c_fc requests in flight (they run beside a gather)
   float* dbg = nullptr;               // debugging aid (ITTS_TAP_LAYER): qkv [B][3D], h1 [B][D], act [B][4D], h2 [B][D] of block dbg_layer
   int dbg_layer = -1;

@@ -778,6 +778,8 @@ int Engine::decode_step_launch(hipStream_t s) {
     static const int e_early = getenv("ITTS_ENGINE_EARLY_FC") ? atoi(getenv("ITTS_ENGINE_EARLY_FC")) : -1;
     ea.early_fc = e_early >= 0 ? e_early : 74;  // tools/ab_early.sh, tools/eng_pacing_rows.sh (profiles/r03_engine_early_fc.txt)
     ea.first_delay = e_fd;
+    static const int e_fake = getenv("ITTS_ENG_FAKE_DIV") ? atoi(getenv("ITTS_ENG_FAKE_DIV")) : 1;
+    ea.fake_div = e_fake < 1 ? 1 : e_fake;
     static const int e_ekv = getenv("ITTS_ENGINE_EARLY_KV") ? atoi(getenv("ITTS_ENGINE_EARLY_KV")) : 1;
     ea.early_kv = e_ekv;
     static const int e_cd = getenv("ITTS_ENGINE_CTX_DELAY") ? atoi(getenv("ITTS_ENGINE_CTX_DELAY")) : 0;

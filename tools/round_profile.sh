@@ -44,10 +44,14 @@ json.dump({"kernels_head": head, "engine": "$(echo ${ITTS_ENGINE:-1})", "mel_tok
 print(open("$out/pmc_decode.json").read())
 PY
 # BASELINE config 3's decode step (64 rows: 97 skinny MFMA projections + 49 LayerNorm + 24 cache attention + sampler per step): the
-# same two passes on `--batch 32`, 48 steps behind a text prefix lengthened so that the mean sequence length is the timed run's
-# (S = 32 + 320 + 3 + 24 = 379 against 380: same kernels, same grids, same bytes per step; ~8 k counted dispatches)
+# same two passes on `--batch 32`, 24 steps behind a text prefix lengthened so that the mean sequence length is the timed run's
+# (S = 32 + 332 + 3 + 12 = 379 against 380: same kernels, same grids, same bytes per step; ~4 k counted dispatches).  A counted
+# dispatch takes tens of ms here, so the pass runs in the background with a heartbeat (gpurun kills a silent command after 7 min).
+if [ -z "$SKIP_PMC32" ]; then
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout -k 10 500 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $out/pmc32_$c -- python3 $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --batch 32 --mel-tokens 48 --text-tokens 320 --no-graph --no-cpu-baseline --no-also > $out/pmc32_$c.json 2> $out/pmc32_$c.err
+  (timeout -k 10 900 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $out/pmc32_$c -- python3 $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --batch 32 --mel-tokens 24 --text-tokens 332 --no-graph --no-cpu-baseline --no-also > $out/pmc32_$c.json 2> $out/pmc32_$c.err) &
+  pid=$!
+  while kill -0 $pid 2>/dev/null; do echo "[pmc32 $c] running $(date +%T)"; sleep 45; done
   f=$(find $out/pmc32_$c -name "*counter_collection.csv" | head -1)
   python3 $GRAFT_REPO_ROOT/tools/pmc_summary.py "$f" $c $out/pmc32_${c}_step.json > $out/pmc32_$c.txt
   rm -rf $out/pmc32_$c
@@ -56,7 +60,7 @@ done
 python3 - <<PY
 import json
 f = json.load(open("$out/pmc32_FETCH_SIZE_step.json")); w = json.load(open("$out/pmc32_WRITE_SIZE_step.json"))
-D, NL, V, B, L, T = 1280, 24, 8194, 64, 320, 48
+D, NL, V, B, L, T = 1280, 24, 8194, 64, 332, 24
 alg = (NL * (12 * D * D + 13 * D) + 4 * D + D * V + V) * 2 + B * 2 * NL * D * 2 * ((32 + L + 2 + 1) + T / 2.0)
 hbm = (2.0 * f["per_step_units"] + w["per_step_units"]) * 1024
 import subprocess
@@ -66,6 +70,7 @@ json.dump({"kernels_head": head, "engine": "0", "mel_tokens": T, "text_tokens": 
           open("$out/pmc_decode_b32.json", "w"), indent=1)
 print(open("$out/pmc_decode_b32.json").read())
 PY
+fi
 if [ -n "$SEGV_PROBE" ]; then
   # the r02 SIGSEGV: ONE full-length pass of the 122-launches-per-step path (58 k counted dispatches) with Python's
   # faulthandler on, so the dump says where the process was - inside a library call of ours, or in the tool's finalisation
