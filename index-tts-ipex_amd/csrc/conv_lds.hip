@@ -16,7 +16,16 @@
 // 16-byte reads always share a bank quartet (r03 counters: 6.9 M conflict cycles on 3.8 M active ones; the "odd multiple of
 // 16 bytes" pitch was derived for contiguous 16-lane groups), with this key the sixteen land on sixteen different quartets for
 // every row offset a tap adds.  The staged weight rows use the same 64-byte image.
+//
+// ACT (r04): Activation1d - the anti-aliased SnakeBeta that precedes EVERY one of these convolutions (a -> conv, models.py:65-74) -
+// runs inside this kernel: the raw rows (tile + halo + 6 on either side for the FIR windows, replicate-clamped) are staged once,
+// every lane slides down one channel (itts_snake_dev.h: the stand-alone kernel's loop, same operations) and writes the bf16
+// result straight into the MFMA planes.  The stand-alone pass read and wrote the whole tensor once more per convolution: on these
+// stages (HBM-bound convolutions, VALU-bound activation) that was 4 of the 10 tensor passes of an AMP iteration.
+#include <cstdlib>
+
 #include "itts_kernels.h"
+#include "itts_snake_dev.h"
 
 namespace itts {
 namespace {
@@ -30,13 +39,15 @@ constexpr int PROWE = 32;  // bf16 per activation-plane row (64 bytes)
 __device__ __forceinline__ int swz4(int row) { return (row >> 1) & 2; }
 
 // MT x NT 16x16 tiles per wave, WAVES_M x WAVES_N waves (= 4)
-template <int MT, int NT, int WAVES_M, int WAVES_N>
+template <int MT, int NT, int WAVES_M, int WAVES_N, bool ACT>
 __global__ __launch_bounds__(256) void conv_lds_kernel(GemmArgs g, int tiles_per_item, int HR, int CP) {
   constexpr int BM = WAVES_M * MT * 16, NP = WAVES_N * NT * 16;
   constexpr int WROWS = (NP + 63) / 64;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  // LDS: [planes][staged weights], or with ACT [planes][raw tile] with the staged weights on top of the raw tile once it is dead
   bf16_t* sA = reinterpret_cast<bf16_t*>(smem);                              // [CP / 32 planes][HR][32] (CP = channels rounded up to 32)
   bf16_t* sW = reinterpret_cast<bf16_t*>(smem + (size_t)HR * CP * 2);        // [2][NP][WROW]
+  bf16_t* sX = sW;                                                           // ACT: raw rows [HR + 12][C], row j = x[clamp(tlo - 6 + j)]
   float* sC = reinterpret_cast<float*>(smem);                                // epilogue: [BM][NP + 4]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
@@ -46,7 +57,7 @@ __global__ __launch_bounds__(256) void conv_lds_kernel(GemmArgs g, int tiles_per
   const bf16_t* __restrict__ W = (const bf16_t*)g.W;
 
   // ---- resident input tile: rows t0 - pad_left + i, zero outside [0, T); pad columns zero ----
-  {
+  if constexpr (!ACT) {
     // (row, 16-byte column) of vector v = tid + 256 * step, stepped without a division per vector
     const int vpr = CP >> 3, cv = C >> 3, nvec = HR * vpr;
     const int di = 256 / vpr, dq = 256 - di * vpr;
@@ -61,6 +72,51 @@ __global__ __launch_bounds__(256) void conv_lds_kernel(GemmArgs g, int tiles_per
       if (q < cv && ts >= 0 && ts < T) val = *reinterpret_cast<const u32x4*>(A + (size_t)ts * g.lda + q * 8);
       *reinterpret_cast<u32x4*>(sA + ((size_t)(q >> 2) * HR + i) * PROWE + (((q & 3) ^ swz4(i)) << 3)) = val;
     }
+  } else {
+    const int tlo = t0 - g.pad_left;  // time of plane row 0
+    {  // raw rows, replicate-clamped (Activation1d pads its input and its up-sampled signal by replication, resample.py:24-33)
+      const int cv = C >> 3, nvec = (HR + 12) * cv;
+      const int di = 256 / cv, dq = 256 - di * cv;
+      int i = tid / cv, q = tid - i * cv;
+      for (int v = tid; v < nvec; v += 256, i += di, q += dq) {
+        if (q >= cv) {
+          q -= cv;
+          ++i;
+        }
+        int ts = tlo - 6 + i;
+        ts = ts < 0 ? 0 : (ts >= T ? T - 1 : ts);
+        *reinterpret_cast<u32x4*>(sX + (size_t)i * C + q * 8) = *reinterpret_cast<const u32x4*>(A + (size_t)ts * g.lda + q * 8);
+      }
+    }
+    // the channels behind C of the last plane multiply as zero whatever they hold (cok), but must be finite: clear them
+    if ((C & 31) != 0) {
+      const int padv = (CP - C) >> 3, cvv = C >> 3;  // 16-byte slots per row to clear
+      for (int v = tid; v < HR * padv; v += 256) {
+        const int i = v / padv, q = cvv + (v - i * padv);
+        *reinterpret_cast<u32x4*>(sA + ((size_t)(q >> 2) * HR + i) * PROWE + (((q & 3) ^ swz4(i)) << 3)) = u32x4{0u, 0u, 0u, 0u};
+      }
+    }
+    __syncthreads();
+    const int runs = 256 / C, c = tid % C, run = tid / C;
+    if (run < runs) {
+      const int per = (HR + runs - 1) / runs;
+      const int i0 = run * per, i1 = min(i0 + per, HR);  // plane rows [i0, i1) = times tlo + i
+      const float ea = expf(g.pre_alpha[c]);
+      const float inv_b = 1.f / (expf(g.pre_beta[c]) + 1e-9f);
+      float fu[12], fd[12];
+#pragma unroll
+      for (int i = 0; i < 12; ++i) fu[i] = fd[i] = g.pre_filt[i];
+      const int pl = c >> 5, sl = (c & 31) >> 3, el = c & 7;
+      auto put = [&](int i, float y) {
+        sA[((size_t)pl * HR + i) * PROWE + ((sl ^ swz4(i)) << 3) + el] = (bf16_t)y;
+      };
+      // rows whose time lies outside [0, T) are the convolution's ZERO padding (of the activated signal)
+      const int ta = max(tlo + i0, 0), tb = min(tlo + i1, T);
+      for (int i = i0; i < min(i1, -tlo); ++i) put(i, 0.f);
+      for (int i = max(i0, T - tlo); i < i1; ++i) put(i, 0.f);
+      if (ta < tb) snake_run<bf16_t, true>(sX + c, C, tlo - 6, ta, tb, T, ea, inv_b, fu, fd, [&](int t, float y) { put(t - tlo, y); });
+    }
+    __syncthreads();  // the planes are complete and the raw tile is dead: the staged weights may take its place
   }
   const int cpt = (C + 31) >> 5, nchunk = g.taps * cpt, npair = (nchunk + 1) >> 1;
   const int lr = tid >> 2, lq = tid & 3;
@@ -220,21 +276,22 @@ __global__ __launch_bounds__(256) void conv_lds_kernel(GemmArgs g, int tiles_per
 // LDS bytes per activation row over all planes (bf16 elements): channels rounded up to whole 32-channel k-steps
 inline int row_pitch(int C) { return (C + 31) / 32 * 32; }
 
-template <int MT, int NT, int WAVES_M, int WAVES_N>
+template <int MT, int NT, int WAVES_M, int WAVES_N, bool ACT>
 int launch(const GemmArgs& g, hipStream_t s) {
   constexpr int BM = WAVES_M * MT * 16, NP = WAVES_N * NT * 16;
   const int HR = BM + (g.taps - 1) * g.dil, CP = row_pitch(g.Cin);
-  const size_t lds_main = (size_t)HR * CP * 2 + (size_t)2 * NP * WROW * 2;
+  const size_t lds_w = (size_t)2 * NP * WROW * 2, lds_raw = ACT ? (size_t)(HR + 12) * g.Cin * 2 : 0;
+  const size_t lds_main = (size_t)HR * CP * 2 + (lds_w > lds_raw ? lds_w : lds_raw);
   const size_t lds_epi = (size_t)BM * (NP + 4) * 4;
   const size_t lds = lds_main > lds_epi ? lds_main : lds_epi;
   const int B = g.M / g.T, tiles = (g.T + BM - 1) / BM;
   static bool attr_done = false;
   if (!attr_done) {
-    ITTS_HIP_CHECK(hipFuncSetAttribute((const void*)conv_lds_kernel<MT, NT, WAVES_M, WAVES_N>,
+    ITTS_HIP_CHECK(hipFuncSetAttribute((const void*)conv_lds_kernel<MT, NT, WAVES_M, WAVES_N, ACT>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_done = true;
   }
-  hipLaunchKernelGGL((conv_lds_kernel<MT, NT, WAVES_M, WAVES_N>), dim3(B * tiles), dim3(256), lds, s, g, tiles, HR, CP);
+  hipLaunchKernelGGL((conv_lds_kernel<MT, NT, WAVES_M, WAVES_N, ACT>), dim3(B * tiles), dim3(256), lds, s, g, tiles, HR, CP);
   ITTS_HIP_CHECK(hipGetLastError());
   return OK;
 }
@@ -252,12 +309,27 @@ bool conv_lds_supported(const GemmArgs& g, int ta, int tw, int tc) {
   return true;
 }
 
+// Activation1d inside the kernel: one lane per channel and run, at least two runs (Cin <= 96 of 256 threads)
+bool conv_lds_act_supported(const GemmArgs& g, int ta, int tw, int tc) {
+  const bool off = getenv("ITTS_NO_CONV_ACT") != nullptr;  // A/B switch (read per call): Activation1d as its own launch
+  return !off && g.pre_alpha && g.pre_beta && g.pre_filt && conv_lds_supported(g, ta, tw, tc) && g.lda == g.Cin;
+}
+
 int conv_lds(const GemmArgs& g, hipStream_t s) {
   ITTS_REQUIRE(g.A && g.W && g.C, "conv_lds: null pointer");
   ITTS_REQUIRE(conv_lds_supported(g, BF16, BF16, BF16), "conv_lds: unsupported shape");
-  if (g.N <= 32) return launch<4, 2, 4, 1>(g, s);
-  if (g.N <= 48) return launch<4, 3, 4, 1>(g, s);
-  return launch<4, 3, 2, 2>(g, s);
+  if (g.pre_alpha) {
+    ITTS_REQUIRE(conv_lds_act_supported(g, BF16, BF16, BF16), "conv_lds: fused activation unsupported for this shape");
+    // Tile heights measured on 64 x 480 frames (r04): C = 48 gains from 128-row tiles (3 workgroups per CU instead of 2: the
+    // activation phase of one overlaps the matrix phase of another; 248.9 -> 242.5 ms per vocoder pass), C = 24 loses with them
+    // (257.5) and C = 96 is indifferent to 64-row tiles (244.1 vs 243.4)
+    if (g.N <= 32) return launch<4, 2, 4, 1, true>(g, s);
+    if (g.N <= 48) return launch<2, 3, 4, 1, true>(g, s);
+    return launch<4, 3, 2, 2, true>(g, s);
+  }
+  if (g.N <= 32) return launch<4, 2, 4, 1, false>(g, s);
+  if (g.N <= 48) return launch<4, 3, 4, 1, false>(g, s);
+  return launch<4, 3, 2, 2, false>(g, s);
 }
 
 }  // namespace itts

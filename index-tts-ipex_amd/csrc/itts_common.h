@@ -166,6 +166,11 @@ struct GemmArgs {
   const void* ADD = nullptr;  // element type TC
   int ldadd = 0;
   float beta = 0.f;
+  // Activation1d in front of the convolution (AMPBlock1: x -> act -> conv, BigVGAN/models.py:65-74), applied while the input tile
+  // is staged - only the kernels that say so in conv_lds_act_supported() take it; A is then the PRE-activation tensor
+  const float* pre_alpha = nullptr;  // log-scale alpha / beta [Cin] of the SnakeBeta, the 12-tap kaiser-sinc filter (up = down)
+  const float* pre_beta = nullptr;
+  const float* pre_filt = nullptr;
 };
 
 }  // namespace itts

@@ -15,8 +15,10 @@ int gemm_glds(const GemmArgs& g, int ta, int tw, int tc, hipStream_t s);
 bool gemm_p8_supported(const GemmArgs& g, int ta, int tw, int tc);  // 256 x 256 tile, 8-phase LDS-DMA pipeline (gemm_p8.hip)
 int gemm_p8(const GemmArgs& g, int ta, int tw, int tc, hipStream_t s);
 bool conv_lds_supported(const GemmArgs& g, int ta, int tw, int tc);
+bool conv_lds_act_supported(const GemmArgs& g, int ta, int tw, int tc);  // ... with Activation1d fused into the tile load (g.pre_*)
 int conv_lds(const GemmArgs& g, hipStream_t s);
 int gemm(const GemmArgs& g, int ta, int tw, int tc, hipStream_t s);  // dispatcher
+int gemm_which(const GemmArgs& g, int ta, int tw, int tc);           // the kernel family the dispatcher takes: 0 VALU, 1 mfma, 2 glds, 3 p8, 4 conv_lds
 
 // ---- anti-aliased SnakeBeta (snake.hip); x,y [B,T,C] ----
 int snake_aa(void* y, const void* x, const float* log_alpha, const float* log_beta, const float* up12,

@@ -282,15 +282,26 @@ int Engine::bigvgan(const void* latent, const float* spk, int B, int T, float* w
       void* xb = alloc(nel * es);
       void* t1 = alloc(nel * es);
       void* t2 = alloc(nel * es);
+      // a -> conv (AMPBlock1, models.py:65-74): on the narrow stages the convolution applies Activation1d itself while it stages its
+      // input tile (conv_lds.hip ACT), elsewhere the activation is its own launch into `tact`
+      auto act_conv = [&](GemmArgs& q, const void* xraw, const float* la, const float* lb, void* tact, int wdt) -> int {
+        q.A = xraw;
+        q.pre_alpha = la;
+        q.pre_beta = lb;
+        q.pre_filt = bv.filter;
+        if (!force_simple && gemm_which(q, adt, wdt, adt) == 4 && conv_lds_act_supported(q, adt, wdt, adt)) return conv(q, adt, wdt, adt, s);
+        q.pre_alpha = q.pre_beta = q.pre_filt = nullptr;
+        K(snake_aa(tact, xraw, la, lb, bv.filter, bv.filter, B, Tc, ch, adt, s));
+        q.A = tact;
+        return conv(q, adt, wdt, adt, s);
+      };
       for (int j = 0; j < nk; ++j) {
         const AmpW& A = bv.res[i * nk + j];
         const int ks = c.bv_res_kernels[j];
         const void* cur = xu;
         for (int l = 0; l < nd; ++l) {
           const int d = c.bv_res_dils[j][l];
-          K(snake_aa(t1, cur, A.a1[l], A.b1[l], bv.filter, bv.filter, B, Tc, ch, adt, s));
           GemmArgs g;
-          g.A = t1;
           g.W = A.c1[l].w;
           g.C = t2;
           g.M = B * Tc;
@@ -302,10 +313,8 @@ int Engine::bigvgan(const void* latent, const float* spk, int B, int T, float* w
           g.dil = d;
           g.pad_left = (ks * d - d) / 2;
           g.bias = A.c1[l].b;
-          ITTS_TRY(conv(g, adt, A.c1[l].dt, adt, s));
-          K(snake_aa(t1, t2, A.a2[l], A.b2[l], bv.filter, bv.filter, B, Tc, ch, adt, s));
+          ITTS_TRY(act_conv(g, cur, A.a1[l], A.b1[l], t1, A.c1[l].dt));
           GemmArgs h;
-          h.A = t1;
           h.W = A.c2[l].w;
           h.M = B * Tc;
           h.N = ch;
@@ -331,7 +340,7 @@ int Engine::bigvgan(const void* latent, const float* spk, int B, int T, float* w
           } else {
             h.C = (cur == xa) ? xb : xa;
           }
-          ITTS_TRY(conv(h, adt, A.c2[l].dt, adt, s));
+          ITTS_TRY(act_conv(h, t2, A.a2[l], A.b2[l], t1, A.c2[l].dt));
           cur = h.C;
           if (i == 0 && j == 0 && l == nd - 1 && nk == 1) ITTS_TRY(tap("bv_amp0", xs, adt, (int64_t)nel, s));
         }

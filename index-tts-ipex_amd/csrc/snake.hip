@@ -15,6 +15,7 @@
 #include <cstdlib>
 
 #include "itts_kernels.h"
+#include "itts_snake_dev.h"
 
 namespace itts {
 namespace {
@@ -164,93 +165,10 @@ __global__ __launch_bounds__(256) void snake_aa_lds_kernel(T* __restrict__ y, co
       fu[i] = up12[i];
       fd[i] = dn12[i];
     }
-    auto act = [&](float u) {
-      const float sn = FAST ? __sinf(u * ea) : sinf(u * ea);
-      return u + inv_b * sn * sn;
-    };
-    const T* col = sx + c;
-    // x[clamp(t)] of this channel for t in [t0 - 6, t0 + TT + 6): the replicate padding was resolved when the tile was
-    // loaded (row i holds x[clamp(t0 - 6 + i)]), so this is a plain row lookup
-    auto xin = [&](int t) { return ldf(col + (t - (t0 - 6)) * CT); };
-    const int mlast = 2 * Tn - 1;
-    auto v_at = [&](int m) {
-      m = m < 0 ? 0 : (m > mlast ? mlast : m);
-      const int q = m >> 1;
-      float u = 0.f;
-      if (m & 1) {
-#pragma unroll
-        for (int r = 0; r < 6; ++r) u = fmaf(fu[2 * r], xin(q + 3 - r), u);
-      } else {
-#pragma unroll
-        for (int r = 0; r < 6; ++r) u = fmaf(fu[2 * r + 1], xin(q + 2 - r), u);
-      }
-      return act(2.f * u);
-    };
     const int ts = t0 + run * RUNL;
     const int te = min(ts + RUNL, Tn);
-    if (ts < Tn) {
-      float v[12], xs[6];
-#if defined(SNAKE_EXPERIMENT) && SNAKE_EXPERIMENT == 2
-#pragma unroll
-      for (int j = 0; j < 10; ++j) v[j] = xin(ts + j - 5);
-#else
-#pragma unroll
-      for (int j = 0; j < 10; ++j) v[j] = v_at(2 * ts - 5 + j);
-#endif
-#pragma unroll
-      for (int i = 0; i < 6; ++i) xs[i] = xin(ts + i);
-      const T* px = col + (ts + 6 - (t0 - 6)) * CT;  // next input row to enter the window
-      T* po = so + (ts - t0) * CT + c;
-      if (2 * (te - 1) + 6 <= mlast) {
-        // interior run (every tile but the last of a sequence): no end-of-stream selects; unrolled by the rotation
-        // period of the two register windows so the shifts become renames
-#pragma unroll 6
-        for (int t = ts; t < te; ++t) {
-          float uo = 0.f, ue = 0.f;
-#pragma unroll
-          for (int r = 0; r < 6; ++r) {
-            uo = fmaf(fu[2 * r], xs[5 - r], uo);
-            ue = fmaf(fu[2 * r + 1], xs[5 - r], ue);
-          }
-          v[10] = act(2.f * uo);
-          v[11] = act(2.f * ue);
-          float o = 0.f;
-#pragma unroll
-          for (int j = 0; j < 12; ++j) o = fmaf(fd[j], v[j], o);
-          stf(po, o);
-          po += CT;
-#pragma unroll
-          for (int j = 0; j < 10; ++j) v[j] = v[j + 2];
-#pragma unroll
-          for (int i = 0; i < 5; ++i) xs[i] = xs[i + 1];
-          xs[5] = ldf(px);
-          px += CT;
-        }
-      } else {
-        for (int t = ts; t < te; ++t) {
-          float uo = 0.f, ue = 0.f;
-#pragma unroll
-          for (int r = 0; r < 6; ++r) {
-            uo = fmaf(fu[2 * r], xs[5 - r], uo);
-            ue = fmaf(fu[2 * r + 1], xs[5 - r], ue);
-          }
-          const float vprev = v[9];
-          v[10] = (2 * t + 5 <= mlast) ? act(2.f * uo) : vprev;
-          v[11] = (2 * t + 6 <= mlast) ? act(2.f * ue) : v[10];
-          float o = 0.f;
-#pragma unroll
-          for (int j = 0; j < 12; ++j) o = fmaf(fd[j], v[j], o);
-          stf(po, o);
-          po += CT;
-#pragma unroll
-          for (int j = 0; j < 10; ++j) v[j] = v[j + 2];
-#pragma unroll
-          for (int i = 0; i < 5; ++i) xs[i] = xs[i + 1];
-          xs[5] = ldf(px);
-          px += CT;
-        }
-      }
-    }
+    // row i of the tile holds x[clamp(t0 - 6 + i)] (the replicate padding was resolved when the tile was loaded)
+    if (ts < Tn) snake_run<T, FAST>(sx + c, CT, t0 - 6, ts, te, Tn, ea, inv_b, fu, fd, [&](int t, float o) { stf(so + (t - t0) * CT + c, o); });
   }
   __syncthreads();
   {

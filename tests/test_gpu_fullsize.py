@@ -299,3 +299,19 @@ def test_full_beam_sample_bf16_graph_replay_equals_eager_12_rows(eng16, mel):
     eng16.debug()
     assert res[0].shape == (4, n)
     assert np.array_equal(res[0], res[1]) and np.array_equal(res[0], res[2])
+
+
+def test_fused_activation_conv_equals_the_two_launches_bf16(eng16, mel, monkeypatch):
+    """The narrow-stage convolutions apply Activation1d while they stage their input tile (conv_lds.hip ACT, BigVGAN stages 4 - 6:
+    C = 96 / 48 / 24): the same operations in the same order as the stand-alone activation kernel, whose bf16 output the
+    convolution used to read back - so the waveform has to be the SAME BITS with the fusion on and off (ITTS_NO_CONV_ACT)."""
+    from itts_hip import prng
+
+    lat = torch.from_numpy(prng.tensor("bigvgan.latent.fuse", 5, (2, 40, CFG.bigvgan.gpt_dim), std=1.0, mean=0.0))
+    spk = eng16.ecapa(mel.transpose(1, 2)).expand(2, -1).contiguous()
+    a = eng16.bigvgan(lat, spk)
+    monkeypatch.setenv("ITTS_NO_CONV_ACT", "1")
+    b = eng16.bigvgan(lat, spk)
+    monkeypatch.delenv("ITTS_NO_CONV_ACT")
+    assert torch.isfinite(a).all() and float(a.abs().max()) > 1e-3
+    assert torch.equal(a, b), float((a - b).abs().max())
