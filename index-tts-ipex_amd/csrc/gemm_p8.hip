@@ -254,7 +254,7 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmArgs g, int tiles_m, i
   const int er = lane >> 3, ec = (lane & 7) * 8;  // read-back: row er + 8 * it, columns ec .. ec + 7
   const int ncol = n0 + wc * 64 + ec;  // column inside this phase's N
   const int pcol = phase * g.N;        // ... and where the phase's columns start in C / R / ADD
-  const bool vec_ok = ncol + 8 <= g.N && (pcol % 8) == 0 && (g.ldc % 8) == 0 && (!R || g.ldr % 8 == 0) && (!ADD || g.ldadd % 8 == 0);
+  const bool vec_ok = ncol + 8 <= g.N && (pcol % 8) == 0 && ((((uintptr_t)g.C | (uintptr_t)g.R | (uintptr_t)g.ADD) & 15) == 0) && (g.ldc % 8) == 0 && (!R || g.ldr % 8 == 0) && (!ADD || g.ldadd % 8 == 0);
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
 #pragma unroll
@@ -272,14 +272,38 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmArgs g, int tiles_m, i
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] = est[row * EST + ec + e];
       const float* brow = g.bias ? g.bias + (g.bias_bstride ? (size_t)(m / T) * g.bias_bstride : 0) : nullptr;
+      if (brow) {
+        if (vec_ok && (((uintptr_t)(brow + ncol)) & 15) == 0) {
+          const float4 b0 = *reinterpret_cast<const float4*>(brow + ncol), b1 = *reinterpret_cast<const float4*>(brow + ncol + 4);
+          v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+        } else {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const int n = min(ncol + e, g.N - 1);
-        if (brow) v[e] += brow[n];
-        if (!plain) {
-          v[e] = act_apply(g.act, v[e]);
-          v[e] = v[e] * (g.scale ? g.scale[n] : 1.f) + (g.shift ? g.shift[n] : 0.f);
-          v[e] = act_apply(g.act2, v[e]);
+          for (int e = 0; e < 8; ++e) v[e] += brow[min(ncol + e, g.N - 1)];
+        }
+      }
+      if (!plain) {
+        // (the activation switch outside the element loop; NewGELU - c_fc of the GPT blocks, the hot case - as x * sigmoid(2 u):
+        //  one v_exp and one v_rcp instead of tanhf's ~25 instructions, the same function)
+        if (g.act == ACT_GELU_NEW) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float x = v[e], u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
+            v[e] = x / (1.f + __expf(-2.f * u));
+          }
+        } else if (g.act != ACT_NONE) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = act_apply(g.act, v[e]);
+        }
+        if (g.scale || g.shift) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const int n = min(ncol + e, g.N - 1);
+            v[e] = v[e] * (g.scale ? g.scale[n] : 1.f) + (g.shift ? g.shift[n] : 0.f);
+          }
+        }
+        if (g.act2 != ACT_NONE) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = act_apply(g.act2, v[e]);
         }
       }
       if (vec_ok && sizeof(TC) == 2) {
@@ -302,6 +326,23 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmArgs g, int tiles_m, i
           o[e] = __builtin_bit_cast(short, t);
         }
         *reinterpret_cast<bf16x8*>(C + (size_t)m * g.ldc + pcol + ncol) = o;
+      } else if (vec_ok && sizeof(TC) == 4) {  // fp32 output (the GPT residual stream): two 16-byte accesses per operand
+        const float* Rf = reinterpret_cast<const float*>(R);
+        const float* Af = reinterpret_cast<const float*>(ADD);
+        float* Cf = reinterpret_cast<float*>(C);
+        if (Rf) {
+          const float4 r0 = *reinterpret_cast<const float4*>(Rf + (size_t)m * g.ldr + pcol + ncol), r1 = *reinterpret_cast<const float4*>(Rf + (size_t)m * g.ldr + pcol + ncol + 4);
+          v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w; v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] *= g.alpha;
+        if (Af) {
+          const float4 a0 = *reinterpret_cast<const float4*>(Af + (size_t)m * g.ldadd + pcol + ncol), a1 = *reinterpret_cast<const float4*>(Af + (size_t)m * g.ldadd + pcol + ncol + 4);
+          v[0] += g.beta * a0.x; v[1] += g.beta * a0.y; v[2] += g.beta * a0.z; v[3] += g.beta * a0.w;
+          v[4] += g.beta * a1.x; v[5] += g.beta * a1.y; v[6] += g.beta * a1.z; v[7] += g.beta * a1.w;
+        }
+        *reinterpret_cast<float4*>(Cf + (size_t)m * g.ldc + pcol + ncol) = float4{v[0], v[1], v[2], v[3]};
+        *reinterpret_cast<float4*>(Cf + (size_t)m * g.ldc + pcol + ncol + 4) = float4{v[4], v[5], v[6], v[7]};
       } else {
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
