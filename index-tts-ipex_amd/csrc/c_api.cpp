@@ -21,8 +21,10 @@ int gemm_which(const GemmArgs& g, int ta, int tw, int tc) {
   const bool old = no_glds || getenv("ITTS_GEMM_FORCE_OLD") != nullptr;  // (per call: the parity test runs both on one shape)
   // ITTS_GEMM_P8=0: without the 256 x 256 eight-phase kernel (A/B, read per call)
   const char* p8e = getenv("ITTS_GEMM_P8");
-  if (!old && !(p8e && atoi(p8e) == 0) && gemm_p8_supported(g, ta, tw, tc)) return 3;
+  const long p8_tiles = (!old && !(p8e && atoi(p8e) == 0)) ? gemm_p8_tiles(g, ta, tw, tc) : 0;
+  if (p8_tiles >= 200) return 3;
   if (!old && gemm_glds_supported(g, ta, tw, tc)) return 2;
+  if (p8_tiles >= 64) return 3;  // a quarter of the CUs busy with the deep pipeline still beats the register-staged kernel
   if (gemm_mfma_supported(g, ta, tw, tc)) return 1;
   return 0;
 }

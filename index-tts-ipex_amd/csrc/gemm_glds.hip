@@ -13,6 +13,8 @@
 //   * rows outside [0, T) of a batch item (conv zero padding) are fetched from a zero page - the DMA has no per-lane
 //     select - reflect padding is resolved in the source address;
 //   * workgroup ids are remapped so that the column tiles of one row tile share an XCD (their A rows hit that L2).
+#include <cstdlib>
+
 #include "itts_kernels.h"
 
 namespace itts {
@@ -180,7 +182,7 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(GemmArgs g, int tiles
         float v = acc[i][j][r];
         if (brow) v += brow[n];
         if (!plain) {
-          v = act_apply(g.act, v);
+          v = act_apply_fast(g.act, v);
           v = v * sc[j] + sh[j];
           v = act_apply(g.act2, v);
         }
@@ -215,8 +217,11 @@ bool gemm_glds_supported(const GemmArgs& g, int ta, int tw, int tc) {
   if (g.N < 64 || g.M < 256) return false;
   const int bn = (g.N % 128 != 0 && g.N % 64 == 0 && g.N < 256) ? 64 : 128;
   const long tiles = (long)((g.M + BM - 1) / BM) * ((g.N + bn - 1) / bn) * g.nphase;
-  if (tiles < 384 || g.nphase != 1) return false;
-  return bn == 64 || (long)g.taps * g.Cin >= 4096;
+  if (g.nphase != 1) return false;
+  // enough tiles to fill the chip twice over on the K-deep or 64-wide shapes; the narrow convolutions (N <= 512: the weight panel
+  // stays in L2) already pay from one tile per CU and K >= 1024 (measured: tools/bench_gemm.py --batch 1, profiles/r04_gemm_ab_b1.txt)
+  if (tiles >= 384 && (bn == 64 || (long)g.taps * g.Cin >= 4096)) return true;
+  return g.N <= 512 && tiles >= 256 && (long)g.taps * g.Cin >= 1024;
 }
 
 int gemm_glds(const GemmArgs& g, int ta, int tw, int tc, hipStream_t s) {

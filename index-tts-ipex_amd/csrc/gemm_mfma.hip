@@ -208,7 +208,7 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmArgs g) {
         float v = acc[i][j][r];
         if (brow) v += brow[n];
         if (!plain) {
-          v = act_apply(g.act, v);
+          v = act_apply_fast(g.act, v);
           v = v * sc[j] + sh[j];
           v = act_apply(g.act2, v);
         }

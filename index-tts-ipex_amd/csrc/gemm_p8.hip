@@ -28,6 +28,8 @@
 // Two geometries, same per-wave work (128 x 64 outputs): 2 x 4 waves = 256 x 256 tile (N a multiple of 256) and 4 x 2 waves =
 // 512 x 128 tile (N a multiple of 128 only: 384-wide convs would leave a quarter of a 256-wide column tile empty); the second one
 // stages 80 KB per K-tile (4 + 4 + 1 + 1 DMA instructions per thread) and fills the 160 KB of LDS exactly.
+#include <cstdlib>
+
 #include "itts_kernels.h"
 
 namespace itts {
@@ -375,15 +377,17 @@ int launch_p8(const GemmArgs& g, hipStream_t s) {
 // Large regular shapes only: >= 4 K-tiles, enough tiles to fill the 256 CUs at least once and a half; N a multiple of 256 takes the
 // 256 x 256 tile, a multiple of 128 the 512 x 128 tile.
 static bool p8_wide(const GemmArgs& g) { return g.N % 256 == 0; }
-bool gemm_p8_supported(const GemmArgs& g, int ta, int tw, int tc) {
-  if (ta != BF16 || tw != BF16 || (tc != BF16 && tc != F32)) return false;
-  if (g.Cin % 64 != 0 || g.lda % 8 != 0 || g.in_up != 1 || g.nphase < 1 || g.nphase > 8) return false;
-  if (((uintptr_t)g.A & 15) || ((uintptr_t)g.W & 15)) return false;
-  if (g.N < 192 || g.N % 64 != 0 || (long)g.taps * g.Cin < 256) return false;
+// Number of tiles the launch would have, 0 where the kernel cannot run the shape at all.  WHEN it is the right kernel is the
+// selector's business (c_api.cpp gemm_which): >= 200 tiles always; 64..199 where the 128-wide LDS-DMA kernel has no better claim.
+long gemm_p8_tiles(const GemmArgs& g, int ta, int tw, int tc) {
+  if (ta != BF16 || tw != BF16 || (tc != BF16 && tc != F32)) return 0;
+  if (g.Cin % 64 != 0 || g.lda % 8 != 0 || g.in_up != 1 || g.nphase < 1 || g.nphase > 8) return 0;
+  if (((uintptr_t)g.A & 15) || ((uintptr_t)g.W & 15)) return 0;
+  if (g.N < 192 || g.N % 64 != 0 || (long)g.taps * g.Cin < 256) return 0;
   const int bm = p8_wide(g) ? 256 : 512, bn = p8_wide(g) ? 256 : 128;
-  const long tiles = (long)((g.M + bm - 1) / bm) * ((g.N + bn - 1) / bn) * g.nphase;
-  return tiles >= 384;
+  return (long)((g.M + bm - 1) / bm) * ((g.N + bn - 1) / bn) * g.nphase;
 }
+bool gemm_p8_supported(const GemmArgs& g, int ta, int tw, int tc) { return gemm_p8_tiles(g, ta, tw, tc) >= 64; }
 
 int gemm_p8(const GemmArgs& g, int ta, int tw, int tc, hipStream_t s) {
   ITTS_REQUIRE(g.A && g.W && g.C, "gemm_p8: null pointer");

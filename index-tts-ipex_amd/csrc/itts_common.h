@@ -126,6 +126,17 @@ __device__ __forceinline__ float act_apply(int act, float x) {
   }
 }
 
+// The matrix-core GEMM epilogues (half-precision outputs): NewGELU as x * sigmoid(2 u) - one v_exp and one v_rcp instead of
+// tanhf's ~25 instructions, the same function (the decode step keeps its pinned tanhf form, decode_pinned.h; the fp32 parity
+// engine runs gemm_simple with act_apply)
+__device__ __forceinline__ float act_apply_fast(int act, float x) {
+  if (act == ACT_GELU_NEW) {
+    const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
+    return x / (1.f + __expf(-2.f * u));
+  }
+  return act_apply(act, x);
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
