@@ -10,6 +10,7 @@
  */
 #ifndef ITTS_HIP_H
 #define ITTS_HIP_H
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -72,6 +73,12 @@ int itts_gemm(const itts_gemm_args* args, itts_stream stream);
 /* Which kernel family itts_gemm takes for these arguments (no launch): 0 vector ALU, 1 register-staged MFMA, 2 LDS-DMA staged
  * 128-wide tiles, 3 the 256 x 256 eight-phase kernel, 4 the LDS-tiled narrow conv.  Tests and tools/bench_gemm.py use it. */
 int itts_gemm_which(const itts_gemm_args* args);
+/* itts_gemm with a caller-owned fp32 workspace (16-byte aligned, ws_bytes long): few-tile, deep-K shapes (M x N in fewer than 128
+ * tiles of 256 x 256, K >= 1024) split K over up to 8 workgroups per tile - raw sums into ws[split][M][N], a second launch adds
+ * them in split order (deterministic) and runs the epilogue.  Other shapes run exactly as itts_gemm.  itts_gemm_ksplit returns the
+ * split count the call would use (1 = none) without launching.  The engine's own GEMMs use a 64 MiB workspace of the engine. */
+int itts_gemm_ws(const itts_gemm_args* args, void* ws, size_t ws_bytes, itts_stream stream);
+int itts_gemm_ksplit(const itts_gemm_args* args, size_t ws_bytes);
 
 int itts_layernorm(void* y, int dtype_y, const void* x, int dtype_x, const float* gamma, const float* beta, int rows,
                    int D, float eps, itts_stream stream);

@@ -1,4 +1,5 @@
 // extern "C" boundary of libitts_hip (declared in include/itts_hip.h).
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 #include <new>
@@ -14,7 +15,33 @@ struct itts_engine {
 namespace itts {
 // which kernel family the dispatcher takes for a shape: 0 vector ALU, 1 register-staged MFMA (gemm_mfma), 2 LDS-DMA staged 128-wide
 // tiles (gemm_glds), 3 256 x 256 eight-phase (gemm_p8), 4 LDS-tiled narrow conv (conv_lds)
+// K split for the few-tile, deep-K shapes (batch-1 latent pass: 1242 rows x 1280 features over K = 5120 is 25 tiles of 256 x 256 - a
+// tenth of the CUs, each MFMA-bound for 70 us; BigVGAN conv_pre and stage 0 likewise): the tile's K-tiles go to S workgroups that
+// write raw fp32 sums to the caller's workspace, a second launch adds them in split order (deterministic) and runs the epilogue.
+// Returns S (1 = no split).  ITTS_GEMM_KSPLIT=0 turns it off, =n forces n where the shape is eligible (A/B, read per call).
+int gemm_ksplit_plan(const GemmArgs& g, int ta, int tw, int tc, size_t ws_bytes) {
+  const char* e = getenv("ITTS_GEMM_KSPLIT");
+  const int forced = e ? atoi(e) : -1;
+  if (forced == 0 || g.nphase != 1 || getenv("ITTS_GEMM_FORCE_OLD") || getenv("ITTS_NO_GEMM_GLDS")) return 1;
+  const char* p8e = getenv("ITTS_GEMM_P8");
+  if (p8e && atoi(p8e) == 0) return 1;
+  if (!getenv("ITTS_NO_CONV_LDS") && conv_lds_supported(g, ta, tw, tc)) return 1;
+  const long tiles = gemm_p8_tiles(g, ta, tw, tc);
+  const long nk = (long)g.taps * (g.Cin / 64);
+  // measured (tools/bench_gemm.py --batch 1 --ksplit, profiles/r04_gemm_ksplit_b1.txt): pays below 64 tiles with K >= 2048 (conv_pre
+  // 126 -> 50 us, stage-0 k = 11 conv 146 -> 67, latent mlp.c_proj 70 -> 41); at 75 - 100 tiles or K = 1280 the reduction launch
+  // costs more than the idle CUs did (c_attn 34 -> 36, c_proj 23 -> 27)
+  if (tiles <= 0 || tiles >= (forced > 0 ? 128 : 64) || nk < (forced > 0 ? 16 : 32)) return 1;
+  long S = forced > 0 ? forced : 224 / tiles;
+  S = std::min(S, 8L);
+  S = std::min(S, nk / 4);                                            // at least four K-tiles per split (the pipeline's fill)
+  S = std::min(S, (long)(ws_bytes / ((size_t)g.M * g.N * 4)));
+  while (S > 1 && (S - 1) * ((nk + S - 1) / S) >= nk) --S;            // every split owns at least one K-tile
+  return S < 2 ? 1 : (int)S;
+}
+
 int gemm_which(const GemmArgs& g, int ta, int tw, int tc) {
+  if (g.ksplit > 1) return 3;  // planned by gemm_ksplit_plan (Engine::conv): gemm_p8 with its reduction launch
   static const bool no_conv_lds = getenv("ITTS_NO_CONV_LDS") != nullptr;
   if (!no_conv_lds && conv_lds_supported(g, ta, tw, tc)) return 4;
   static const bool no_glds = getenv("ITTS_NO_GEMM_GLDS") != nullptr;  // A/B switch: the register-staged kernel everywhere
@@ -80,6 +107,32 @@ int itts_gemm(const itts_gemm_args* a, itts_stream stream) {
   to_gemm_args(a, g);
   if (a->force_simple) return gemm_simple(g, a->dtype_a, a->dtype_w, a->dtype_c, (hipStream_t)stream);
   return gemm(g, a->dtype_a, a->dtype_w, a->dtype_c, (hipStream_t)stream);
+}
+
+int itts_gemm_ws(const itts_gemm_args* a, void* ws, size_t ws_bytes, itts_stream stream) {
+  (void)hipGetLastError();
+  if (!a) {
+    set_error("itts_gemm_ws: null args");
+    return E_INVALID;
+  }
+  GemmArgs g;
+  to_gemm_args(a, g);
+  if (a->force_simple) return gemm_simple(g, a->dtype_a, a->dtype_w, a->dtype_c, (hipStream_t)stream);
+  if (ws && !((uintptr_t)ws & 15)) {
+    const int S = gemm_ksplit_plan(g, a->dtype_a, a->dtype_w, a->dtype_c, ws_bytes);
+    if (S > 1) {
+      g.ws = (float*)ws;
+      g.ksplit = S;
+    }
+  }
+  return gemm(g, a->dtype_a, a->dtype_w, a->dtype_c, (hipStream_t)stream);
+}
+
+int itts_gemm_ksplit(const itts_gemm_args* a, size_t ws_bytes) {
+  if (!a) return E_INVALID;
+  GemmArgs g;
+  to_gemm_args(a, g);
+  return a->force_simple ? 1 : gemm_ksplit_plan(g, a->dtype_a, a->dtype_w, a->dtype_c, ws_bytes);
 }
 
 int itts_gemm_which(const itts_gemm_args* a) {

@@ -199,6 +199,9 @@ struct Engine {
     return dry ? (void*)(uintptr_t)(0x1000 + a) : (void*)(ws + a);
   }
   int ws_reserve(size_t bytes, hipStream_t s);
+  // raw partial sums of K-split GEMMs (Engine::conv): [split][M][N] fp32, allocated at the first split launch
+  static constexpr size_t KSPLIT_WS_BYTES = size_t(64) << 20;
+  float* ksplit_ws = nullptr;
 
   // debug taps
   bool debug = false;

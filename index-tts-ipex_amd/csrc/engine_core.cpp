@@ -15,6 +15,7 @@ Engine::~Engine() {
                   d.hyp_score, d.hyp_len, d.hyp_order, d.hyp_n, d.hyp_worst, d.hyp_counter, d.beam_done};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
+  if (ksplit_ws) (void)hipFree(ksplit_ws);
   if (d.graph) (void)hipGraphExecDestroy(d.graph);
   if (d.graphK) (void)hipGraphExecDestroy(d.graphK);
 }
@@ -87,6 +88,20 @@ int Engine::lin(void* C, int tc, const void* A, int ta, int lda, const Lin& w, i
 int Engine::conv(GemmArgs& g, int ta, int tw, int tc, hipStream_t s) {
   if (dry) return OK;
   if (force_simple) return gemm_simple(g, ta, tw, tc, s);
+  // few-tile deep-K shapes split K over workgroups (this engine's own fp32 workspace: engines on other streams have theirs)
+  const int S = gemm_ksplit_plan(g, ta, tw, tc, KSPLIT_WS_BYTES);
+  if (S > 1) {
+    if (!ksplit_ws) {  // first use (prefill / latent / vocoder: never inside a graph capture)
+      if (hipMalloc((void**)&ksplit_ws, KSPLIT_WS_BYTES) != hipSuccess) {
+        (void)hipGetLastError();
+        ksplit_ws = nullptr;
+        set_error("K-split workspace allocation failed");
+        return E_NOMEM;
+      }
+    }
+    g.ws = ksplit_ws;
+    g.ksplit = S;
+  }
   return gemm(g, ta, tw, tc, s);
 }
 

@@ -56,6 +56,100 @@ constexpr int PBK = 64, PROW = PBK * 2;  // 128-byte LDS rows
 #define P8_STR_(x) #x
 #define P8_STR(x) P8_STR_(x)
 
+// The epilogue of 8 consecutive outputs (row m, columns ncol .. ncol + 7 of phase column block pcol), shared by the kernel and by
+// the split-K reduction so that both run the same operations in the same order.
+template <typename TC>
+__device__ __forceinline__ void p8_finish8(const GemmArgs& g, int T, int m, int ncol, int pcol, bool vec_ok, bool plain, float (&v)[8]) {
+  TC* __restrict__ C = (TC*)g.C;
+  const TC* __restrict__ R = (const TC*)g.R;
+  const TC* __restrict__ ADD = (const TC*)g.ADD;
+  const float* brow = g.bias ? g.bias + (g.bias_bstride ? (size_t)(m / T) * g.bias_bstride : 0) : nullptr;
+  if (brow) {
+    if (vec_ok && (((uintptr_t)(brow + ncol)) & 15) == 0) {
+      const float4 b0 = *reinterpret_cast<const float4*>(brow + ncol), b1 = *reinterpret_cast<const float4*>(brow + ncol + 4);
+      v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] += brow[min(ncol + e, g.N - 1)];
+    }
+  }
+  if (!plain) {
+    // (the activation switch outside the element loop; NewGELU - c_fc of the GPT blocks, the hot case - as x * sigmoid(2 u):
+    //  one v_exp and one v_rcp instead of tanhf's ~25 instructions, the same function)
+    if (g.act == ACT_GELU_NEW) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float x = v[e], u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
+        v[e] = x / (1.f + __expf(-2.f * u));
+      }
+    } else if (g.act != ACT_NONE) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = act_apply(g.act, v[e]);
+    }
+    if (g.scale || g.shift) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int n = min(ncol + e, g.N - 1);
+        v[e] = v[e] * (g.scale ? g.scale[n] : 1.f) + (g.shift ? g.shift[n] : 0.f);
+      }
+    }
+    if (g.act2 != ACT_NONE) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = act_apply(g.act2, v[e]);
+    }
+  }
+  if (vec_ok && sizeof(TC) == 2) {
+    if (R) {
+      const bf16x8 rv = *reinterpret_cast<const bf16x8*>(R + (size_t)m * g.ldr + pcol + ncol);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] += half_bits((unsigned short)rv[e]);
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] *= g.alpha;
+    if (ADD) {
+      const bf16x8 av = *reinterpret_cast<const bf16x8*>(ADD + (size_t)m * g.ldadd + pcol + ncol);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] += g.beta * half_bits((unsigned short)av[e]);
+    }
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const bf16_t t = (bf16_t)v[e];
+      o[e] = __builtin_bit_cast(short, t);
+    }
+    *reinterpret_cast<bf16x8*>(C + (size_t)m * g.ldc + pcol + ncol) = o;
+  } else if (vec_ok && sizeof(TC) == 4) {  // fp32 output (the GPT residual stream): two 16-byte accesses per operand
+    const float* Rf = reinterpret_cast<const float*>(R);
+    const float* Af = reinterpret_cast<const float*>(ADD);
+    float* Cf = reinterpret_cast<float*>(C);
+    if (Rf) {
+      const float4 r0 = *reinterpret_cast<const float4*>(Rf + (size_t)m * g.ldr + pcol + ncol), r1 = *reinterpret_cast<const float4*>(Rf + (size_t)m * g.ldr + pcol + ncol + 4);
+      v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w; v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] *= g.alpha;
+    if (Af) {
+      const float4 a0 = *reinterpret_cast<const float4*>(Af + (size_t)m * g.ldadd + pcol + ncol), a1 = *reinterpret_cast<const float4*>(Af + (size_t)m * g.ldadd + pcol + ncol + 4);
+      v[0] += g.beta * a0.x; v[1] += g.beta * a0.y; v[2] += g.beta * a0.z; v[3] += g.beta * a0.w;
+      v[4] += g.beta * a1.x; v[5] += g.beta * a1.y; v[6] += g.beta * a1.z; v[7] += g.beta * a1.w;
+    }
+    *reinterpret_cast<float4*>(Cf + (size_t)m * g.ldc + pcol + ncol) = float4{v[0], v[1], v[2], v[3]};
+    *reinterpret_cast<float4*>(Cf + (size_t)m * g.ldc + pcol + ncol + 4) = float4{v[4], v[5], v[6], v[7]};
+  } else {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int n = ncol + e;
+      if (n < g.N) {
+        float x = v[e];
+        if (R) x += ldf(R + (size_t)m * g.ldr + pcol + n);
+        x *= g.alpha;
+        if (ADD) x += g.beta * ldf(ADD + (size_t)m * g.ldadd + pcol + n);
+        stf(C + (size_t)m * g.ldc + pcol + n, x);
+      }
+    }
+  }
+}
+
 template <int WM, int WN, typename TC>
 __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmArgs g, int tiles_m, int tiles_n) {
   static_assert(WM * WN == 8 && (WM == 2 || WM == 4), "8 waves as 2 x 4 or 4 x 2");
@@ -73,14 +167,21 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmArgs g, int tiles_m, i
   const int q8 = nwg >> 3, r8 = nwg & 7, xcd = orig & 7;
   const int wgid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
   const int per_phase = tiles_m * tiles_n;
-  const int phase = wgid / per_phase, rem = wgid - phase * per_phase;
+  // K split (g.ksplit > 1, nphase == 1): the splits of one tile are consecutive logical ids (same XCD: they read different K ranges,
+  // but the tile's A and W rows interleave in the same L2 sets either way) - split = id % ksplit
+  const int split = g.ksplit > 1 ? wgid % g.ksplit : 0;
+  const int tid_ = g.ksplit > 1 ? wgid / g.ksplit : wgid;
+  const int phase = tid_ / per_phase, rem = tid_ - phase * per_phase;
   const int tm = rem / tiles_n, tn = rem - tm * tiles_n;
   const int m0 = tm * PBM, n0 = tn * PBN;
   const bf16_t* __restrict__ A = (const bf16_t*)g.A;
   const int K = g.taps * g.Cin;
   const bf16_t* __restrict__ W = (const bf16_t*)g.W + (size_t)phase * g.N * K;
   const int T = g.T > 0 ? g.T : g.M;
-  const int nk = g.taps * (g.Cin / PBK);
+  const int nk_all = g.taps * (g.Cin / PBK);
+  const int kper = (nk_all + g.ksplit - 1) / g.ksplit;
+  const int kt_lo = split * kper;                    // this workgroup's K-tiles [kt_lo, nk)
+  const int nk = min(nk_all, kt_lo + kper);          // (host: every split has at least one)
   const int shift0 = g.phase_shift[phase] - g.pad_left;
 
   // ---- loader: an A chunk is WM * 64 rows (rows h * 64 .. + 63 of every wave row), a B chunk WN * 32 rows; instruction i of wave w
@@ -127,7 +228,7 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmArgs g, int tiles_m, i
     const int ktc = min(kt, nk - 1);
     const int tap = ktc / cpt, cc = ktc - tap * cpt;
     unsigned char* base = smem + buf * PBUF;
-    if (cc == 0 || kt >= nk) {  // wave-uniform: first channel chunk of a tap (or an overshoot stage): resolve the rows
+    if (cc == 0 || kt >= nk || kt == kt_lo) {  // wave-uniform: first channel chunk of a tap, the split's first K-tile (or an overshoot stage): resolve the rows
       const int off = shift0 + tap * g.dil;
 #pragma unroll
       for (int i = 0; i < NA; ++i) {
@@ -204,18 +305,18 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmArgs g, int tiles_m, i
   __builtin_amdgcn_sched_barrier(0);
 
   // ---- prologue: what phases -5 .. -1 would have staged ----
-  stage_A(0, 0, 0);
-  stage_B(0, 0, 0);
-  stage_B(0, 1, 0);
-  stage_A(0, 1, 0);
-  stage_A(1, 0, 1);
+  stage_A(0, 0, kt_lo);
+  stage_B(0, 0, kt_lo);
+  stage_B(0, 1, kt_lo);
+  stage_A(0, 1, kt_lo);
+  stage_A(1, 0, kt_lo + 1);
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VM03) : "memory");  // A0(0), B0(0) of this wave have landed
   __builtin_amdgcn_s_barrier();
   if (grp == 1) __builtin_amdgcn_s_barrier();  // the second wave group runs half a phase behind the first
   __builtin_amdgcn_sched_barrier(0);
 
-  for (int kt = 0; kt < nk; ++kt) {
-    const int buf = kt & 1;
+  for (int kt = kt_lo; kt < nk; ++kt) {
+    const int buf = (kt - kt_lo) & 1;
     // phase 0: quadrant (A0, B0); stage B0(t + 1)
     read_A(buf, 0);
     read_B(buf, 0);
@@ -247,16 +348,13 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmArgs g, int tiles_m, i
   //      BN affine / residual / accumulate on vectors, one 16-byte store per 8 outputs.  Every wave stages its own 128 x 64 block
   //      in four rounds of 32 rows (a wave-private LDS region: no workgroup barrier, the wave's DS operations execute in order) ----
   __builtin_amdgcn_s_barrier();  // every wave is through its last fragment reads: the staging buffers may be overwritten
-  TC* __restrict__ C = (TC*)g.C;
-  const TC* __restrict__ R = (const TC*)g.R;
-  const TC* __restrict__ ADD = (const TC*)g.ADD;
   const bool plain = g.act == ACT_NONE && g.act2 == ACT_NONE && !g.scale && !g.shift;
   constexpr int EST = 68;  // floats per staged row (64 + 4: rows 272 bytes apart)
   float* est = reinterpret_cast<float*>(smem) + wave * 32 * EST;
   const int er = lane >> 3, ec = (lane & 7) * 8;  // read-back: row er + 8 * it, columns ec .. ec + 7
   const int ncol = n0 + wc * 64 + ec;  // column inside this phase's N
   const int pcol = phase * g.N;        // ... and where the phase's columns start in C / R / ADD
-  const bool vec_ok = ncol + 8 <= g.N && (pcol % 8) == 0 && ((((uintptr_t)g.C | (uintptr_t)g.R | (uintptr_t)g.ADD) & 15) == 0) && (g.ldc % 8) == 0 && (!R || g.ldr % 8 == 0) && (!ADD || g.ldadd % 8 == 0);
+  const bool vec_ok = ncol + 8 <= g.N && (pcol % 8) == 0 && ((((uintptr_t)g.C | (uintptr_t)g.R | (uintptr_t)g.ADD) & 15) == 0) && (g.ldc % 8) == 0 && (!g.R || g.ldr % 8 == 0) && (!g.ADD || g.ldadd % 8 == 0);
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
 #pragma unroll
@@ -273,102 +371,54 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmArgs g, int tiles_m, i
       float v[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] = est[row * EST + ec + e];
-      const float* brow = g.bias ? g.bias + (g.bias_bstride ? (size_t)(m / T) * g.bias_bstride : 0) : nullptr;
-      if (brow) {
-        if (vec_ok && (((uintptr_t)(brow + ncol)) & 15) == 0) {
-          const float4 b0 = *reinterpret_cast<const float4*>(brow + ncol), b1 = *reinterpret_cast<const float4*>(brow + ncol + 4);
-          v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
-        } else {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] += brow[min(ncol + e, g.N - 1)];
-        }
+      if (g.ksplit > 1) {  // raw sums of this split's K range (N % 64 == 0, nphase == 1: always whole 16-byte groups)
+        float* wp = g.ws + ((size_t)split * g.M + m) * g.N + ncol;
+        *reinterpret_cast<float4*>(wp) = float4{v[0], v[1], v[2], v[3]};
+        *reinterpret_cast<float4*>(wp + 4) = float4{v[4], v[5], v[6], v[7]};
+        continue;
       }
-      if (!plain) {
-        // (the activation switch outside the element loop; NewGELU - c_fc of the GPT blocks, the hot case - as x * sigmoid(2 u):
-        //  one v_exp and one v_rcp instead of tanhf's ~25 instructions, the same function)
-        if (g.act == ACT_GELU_NEW) {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            const float x = v[e], u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
-            v[e] = x / (1.f + __expf(-2.f * u));
-          }
-        } else if (g.act != ACT_NONE) {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = act_apply(g.act, v[e]);
-        }
-        if (g.scale || g.shift) {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            const int n = min(ncol + e, g.N - 1);
-            v[e] = v[e] * (g.scale ? g.scale[n] : 1.f) + (g.shift ? g.shift[n] : 0.f);
-          }
-        }
-        if (g.act2 != ACT_NONE) {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = act_apply(g.act2, v[e]);
-        }
-      }
-      if (vec_ok && sizeof(TC) == 2) {
-        if (R) {
-          const bf16x8 rv = *reinterpret_cast<const bf16x8*>(R + (size_t)m * g.ldr + pcol + ncol);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] += half_bits((unsigned short)rv[e]);
-        }
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] *= g.alpha;
-        if (ADD) {
-          const bf16x8 av = *reinterpret_cast<const bf16x8*>(ADD + (size_t)m * g.ldadd + pcol + ncol);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] += g.beta * half_bits((unsigned short)av[e]);
-        }
-        bf16x8 o;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const bf16_t t = (bf16_t)v[e];
-          o[e] = __builtin_bit_cast(short, t);
-        }
-        *reinterpret_cast<bf16x8*>(C + (size_t)m * g.ldc + pcol + ncol) = o;
-      } else if (vec_ok && sizeof(TC) == 4) {  // fp32 output (the GPT residual stream): two 16-byte accesses per operand
-        const float* Rf = reinterpret_cast<const float*>(R);
-        const float* Af = reinterpret_cast<const float*>(ADD);
-        float* Cf = reinterpret_cast<float*>(C);
-        if (Rf) {
-          const float4 r0 = *reinterpret_cast<const float4*>(Rf + (size_t)m * g.ldr + pcol + ncol), r1 = *reinterpret_cast<const float4*>(Rf + (size_t)m * g.ldr + pcol + ncol + 4);
-          v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w; v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
-        }
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] *= g.alpha;
-        if (Af) {
-          const float4 a0 = *reinterpret_cast<const float4*>(Af + (size_t)m * g.ldadd + pcol + ncol), a1 = *reinterpret_cast<const float4*>(Af + (size_t)m * g.ldadd + pcol + ncol + 4);
-          v[0] += g.beta * a0.x; v[1] += g.beta * a0.y; v[2] += g.beta * a0.z; v[3] += g.beta * a0.w;
-          v[4] += g.beta * a1.x; v[5] += g.beta * a1.y; v[6] += g.beta * a1.z; v[7] += g.beta * a1.w;
-        }
-        *reinterpret_cast<float4*>(Cf + (size_t)m * g.ldc + pcol + ncol) = float4{v[0], v[1], v[2], v[3]};
-        *reinterpret_cast<float4*>(Cf + (size_t)m * g.ldc + pcol + ncol + 4) = float4{v[4], v[5], v[6], v[7]};
-      } else {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const int n = ncol + e;
-          if (n < g.N) {
-            float x = v[e];
-            if (R) x += ldf(R + (size_t)m * g.ldr + pcol + n);
-            x *= g.alpha;
-            if (ADD) x += g.beta * ldf(ADD + (size_t)m * g.ldadd + pcol + n);
-            stf(C + (size_t)m * g.ldc + pcol + n, x);
-          }
-        }
-      }
+      p8_finish8<TC>(g, T, m, ncol, pcol, vec_ok, plain, v);
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the read-back is done before the next round overwrites the region
   }
+}
+
+// Second launch of a K-split GEMM: one thread per 8 consecutive outputs adds the splits' raw sums in split order (fixed: the result
+// does not depend on which workgroup finished first) and runs the epilogue of the unsplit kernel.
+template <typename TC>
+__global__ __launch_bounds__(256) void gemm_p8_reduce_kernel(GemmArgs g) {
+  const int groups = g.N / 8;
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long)g.M * groups) return;
+  const int m = (int)(i / groups), ncol = (int)(i - (long)m * groups) * 8;
+  float v[8];
+  const size_t plane = (size_t)g.M * g.N;
+  const float* wp = g.ws + (size_t)m * g.N + ncol;
+  {
+    const float4 a = *reinterpret_cast<const float4*>(wp), b = *reinterpret_cast<const float4*>(wp + 4);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+  }
+  for (int s = 1; s < g.ksplit; ++s) {
+    const float4 a = *reinterpret_cast<const float4*>(wp + s * plane), b = *reinterpret_cast<const float4*>(wp + s * plane + 4);
+    v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w; v[4] += b.x; v[5] += b.y; v[6] += b.z; v[7] += b.w;
+  }
+  const int T = g.T > 0 ? g.T : g.M;
+  const bool plain = g.act == ACT_NONE && g.act2 == ACT_NONE && !g.scale && !g.shift;
+  const bool vec_ok = ((((uintptr_t)g.C | (uintptr_t)g.R | (uintptr_t)g.ADD) & 15) == 0) && (g.ldc % 8) == 0 && (!g.R || g.ldr % 8 == 0) && (!g.ADD || g.ldadd % 8 == 0);
+  p8_finish8<TC>(g, T, m, ncol, 0, vec_ok, plain, v);
 }
 
 template <int WM, int WN, typename TC>
 int launch_p8(const GemmArgs& g, hipStream_t s) {
   constexpr int BMt = WM * 128, BNt = WN * 64;
   const int tiles_m = (g.M + BMt - 1) / BMt, tiles_n = (g.N + BNt - 1) / BNt;
-  hipLaunchKernelGGL((gemm_p8_kernel<WM, WN, TC>), dim3(tiles_m * tiles_n * g.nphase), dim3(512), 0, s, g, tiles_m, tiles_n);
+  hipLaunchKernelGGL((gemm_p8_kernel<WM, WN, TC>), dim3(tiles_m * tiles_n * g.nphase * g.ksplit), dim3(512), 0, s, g, tiles_m, tiles_n);
   ITTS_HIP_CHECK(hipGetLastError());
+  if (g.ksplit > 1) {
+    const long items = (long)g.M * (g.N / 8);
+    hipLaunchKernelGGL((gemm_p8_reduce_kernel<TC>), dim3((unsigned)((items + 255) / 256)), dim3(256), 0, s, g);
+    ITTS_HIP_CHECK(hipGetLastError());
+  }
   return OK;
 }
 
@@ -387,13 +437,16 @@ long gemm_p8_tiles(const GemmArgs& g, int ta, int tw, int tc) {
   const int bm = p8_wide(g) ? 256 : 512, bn = p8_wide(g) ? 256 : 128;
   return (long)((g.M + bm - 1) / bm) * ((g.N + bn - 1) / bn) * g.nphase;
 }
-bool gemm_p8_supported(const GemmArgs& g, int ta, int tw, int tc) { return gemm_p8_tiles(g, ta, tw, tc) >= 64; }
+bool gemm_p8_supported(const GemmArgs& g, int ta, int tw, int tc) { return gemm_p8_tiles(g, ta, tw, tc) * (g.ksplit > 1 ? g.ksplit : 1) >= 64; }
 
 int gemm_p8(const GemmArgs& g, int ta, int tw, int tc, hipStream_t s) {
   ITTS_REQUIRE(g.A && g.W && g.C, "gemm_p8: null pointer");
-  ITTS_REQUIRE(gemm_p8_supported(g, ta, tw, tc), "gemm_p8: unsupported shape/dtype");
+  ITTS_REQUIRE(gemm_p8_tiles(g, ta, tw, tc) > 0, "gemm_p8: unsupported shape/dtype");  // (whether it is the RIGHT kernel: gemm_which)
   const int T = g.T > 0 ? g.T : g.M;
   ITTS_REQUIRE(g.M % T == 0 && g.lda >= g.Cin && g.ldc >= g.N * g.nphase, "gemm_p8: bad dims");
+  ITTS_REQUIRE(g.ksplit >= 1 && (g.ksplit == 1 || (g.ws && g.nphase == 1 && !((uintptr_t)g.ws & 15) &&
+                                                  (long)(g.ksplit - 1) * ((g.taps * (g.Cin / PBK) + g.ksplit - 1) / g.ksplit) < (long)g.taps * (g.Cin / PBK))),
+               "gemm_p8: K split needs a workspace, one phase and a K-tile for every split");
   if (p8_wide(g)) return tc == BF16 ? launch_p8<2, 4, bf16_t>(g, s) : launch_p8<2, 4, float>(g, s);
   return tc == BF16 ? launch_p8<4, 2, bf16_t>(g, s) : launch_p8<4, 2, float>(g, s);
 }

@@ -182,6 +182,10 @@ struct GemmArgs {
   const float* pre_alpha = nullptr;  // log-scale alpha / beta [Cin] of the SnakeBeta, the 12-tap kaiser-sinc filter (up = down)
   const float* pre_beta = nullptr;
   const float* pre_filt = nullptr;
+  // K split over workgroups (gemm_p8 only; set by the selector, never by callers): split s of ksplit accumulates its share of the
+  // K-tiles into ws[s][M][N] (fp32, raw sums) and a second launch adds the shares in split order and runs the epilogue
+  float* ws = nullptr;
+  int ksplit = 1;
 };
 
 }  // namespace itts

@@ -13,7 +13,8 @@ int gemm_mfma(const GemmArgs& g, int ta, int tw, int tc, hipStream_t s);
 bool gemm_glds_supported(const GemmArgs& g, int ta, int tw, int tc);  // LDS-DMA staged 128 x 128 / 128 x 64 tiles (gemm_glds.hip)
 int gemm_glds(const GemmArgs& g, int ta, int tw, int tc, hipStream_t s);
 long gemm_p8_tiles(const GemmArgs& g, int ta, int tw, int tc);      // 0 = cannot run the shape
-bool gemm_p8_supported(const GemmArgs& g, int ta, int tw, int tc);  // 256 x 256 tile, 8-phase LDS-DMA pipeline (gemm_p8.hip)
+bool gemm_p8_supported(const GemmArgs& g, int ta, int tw, int tc);
+int gemm_ksplit_plan(const GemmArgs& g, int ta, int tw, int tc, size_t ws_bytes);  // K split of the few-tile deep-K shapes (c_api.cpp); 1 = none  // 256 x 256 tile, 8-phase LDS-DMA pipeline (gemm_p8.hip)
 int gemm_p8(const GemmArgs& g, int ta, int tw, int tc, hipStream_t s);
 bool conv_lds_supported(const GemmArgs& g, int ta, int tw, int tc);
 bool conv_lds_act_supported(const GemmArgs& g, int ta, int tw, int tc);  // ... with Activation1d fused into the tile load (g.pre_*)

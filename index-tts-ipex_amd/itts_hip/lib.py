@@ -65,6 +65,8 @@ _PROTOS = {
     "itts_snake_aa_fwd": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "itts_gemm": (i32, [C.POINTER(GemmArgs), vp]),
     "itts_gemm_which": (i32, [C.POINTER(GemmArgs)]),
+    "itts_gemm_ws": (i32, [C.POINTER(GemmArgs), vp, C.c_size_t, vp]),
+    "itts_gemm_ksplit": (i32, [C.POINTER(GemmArgs), C.c_size_t]),
     "itts_layernorm": (i32, [vp, i32, vp, i32, vp, vp, i32, i32, f32, vp]),
     "itts_attention": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, f32, i32, vp, i32, vp]),
     "itts_gemv": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, i32, i32, vp]),

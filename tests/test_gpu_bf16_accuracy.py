@@ -132,6 +132,35 @@ def test_bf16_latent(eng16s, mel, gold, control, accuracy):
     assert abs(float(np.sqrt((lat.astype(np.float64) ** 2).mean())) - float(g["latent_rms"])) < 1e-2 * float(g["latent_rms"])
 
 
+def test_ksplit_changes_only_the_summation_order(eng16s, mel, gold, control, accuracy, monkeypatch):
+    """The few-tile GEMMs of small batches (one-sentence prefill mlp.c_proj, batch-1 latent pass) split K over workgroups and add
+    the shares in split order (c_api.cpp gemm_ksplit_plan): a different fp32 summation order than the unsplit kernels of large
+    batches, so bit-identity ACROSS batch sizes holds only with ITTS_GEMM_KSPLIT=0 (tested in test_gpu_configs.py /
+    test_gpu_fullsize.py).  Here: what the order change costs - prefill logits and the T = 480 latent with and without the split
+    differ by less than the bf16 engine differs from the reference (control), and both modes meet the reference bound."""
+    g = gold("smooth_decode_b1")
+    cond = eng16s.conditioning(mel)
+    got = {}
+    for mode in ("auto", "0"):
+        if mode == "0":
+            monkeypatch.setenv("ITTS_GEMM_KSPLIT", "0")
+        eng16s.prefill(cond, np.repeat(g["text"].astype(np.int32), 2, 0), 4, 10.0, True)
+        lg = eng16s.fetch(logits=True)[1].copy()
+        eng16s._exit()
+        lat = eng16s.latent(cond, g["text"].astype(np.int32), g["codes"][0, :480]).float().cpu().numpy()[0]
+        got[mode] = (lg, lat)
+    monkeypatch.delenv("ITTS_GEMM_KSPLIT")
+    d_lg = rms_rel(got["auto"][0][0], got["0"][0][0])
+    d_lat = rms_rel(got["auto"][1], got["0"][1])
+    accuracy["smooth_bf16_ksplit_vs_unsplit_prefill_logits_rel_rms"] = d_lg
+    accuracy["smooth_bf16_ksplit_vs_unsplit_latent_T480_rel_rms"] = d_lat
+    assert 0.0 < d_lat, "the split did not engage on the batch-1 latent pass"
+    assert d_lg < BOUND / 2 and d_lat < BOUND_LATENT / 2, (d_lg, d_lat)
+    for mode in got:
+        e = rms_rel(got[mode][1][:, :16], g["latent_sample"])
+        assert e < BOUND_LATENT and e < 2.0 * control["latent"] + 2e-3, (mode, e)
+
+
 @pytest.mark.parametrize("path", ["mfma", "engine"])
 def test_bf16_free_running_six_rows(eng16s, mel, gold, accuracy, path):
     """Six different sentences as ONE decode batch, greedy, free-running, on both six-row paths - "mfma": the launch path

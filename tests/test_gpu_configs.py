@@ -84,9 +84,10 @@ def test_config3_ragged_64_rows_fp32(mel, accuracy):
     assert worst_lat < 1e-3 and worst_wav < 1e-3, (worst_lat, worst_wav)
 
 
-def test_batched_vocoder_at_bench_size_bf16(mel, accuracy):
+def test_batched_vocoder_at_bench_size_bf16(mel, accuracy, monkeypatch):
     """itts_bigvgan with B = 64 x 480 frames (what `bench.py --batch 32` launches: 31 M output samples per call) against
-    batch-1 runs of the same latents."""
+    batch-1 runs of the same latents: bit-identical with ITTS_GEMM_KSPLIT=0 (every kernel accumulates K in the same order at
+    every batch size); with the default K split of the batch-1 conv_pre / stage-0 convolutions, within the bf16 bound."""
     eng = ieng.build_engine(CFG, "bf16", parts=("bigvgan",), max_batch=64)
     spk = eng.ecapa(mel.transpose(1, 2))
     lat = torch.from_numpy(prng.tensor("bigvgan.latent.b64", 5, (64, 480, CFG.bigvgan.gpt_dim), std=1.0, mean=0.0))
@@ -96,17 +97,28 @@ def test_batched_vocoder_at_bench_size_bf16(mel, accuracy):
     for b in (0, 17, 63):
         w1 = eng.bigvgan(lat[b:b + 1], spk)
         worst = max(worst, rms_rel(wav[b].cpu().numpy(), w1[0].cpu().numpy()))
-    accuracy["bf16_bigvgan_b64x480_vs_batch1_rel_rms"] = worst
-    assert worst < 2e-2, worst
+    accuracy["bf16_bigvgan_b64x480_vs_batch1_ksplit_rel_rms"] = worst
+    assert worst < 4e-2, worst  # (PRNG vocoder weights: the bf16 waveform itself is 1.6e-2 from the fp32 reference, test_gpu_longrun.py)
+    monkeypatch.setenv("ITTS_GEMM_KSPLIT", "0")
+    worst0 = 0.0
+    for b in (0, 63):
+        w1 = eng.bigvgan(lat[b:b + 1], spk)
+        worst0 = max(worst0, rms_rel(wav[b].cpu().numpy(), w1[0].cpu().numpy()))
+    accuracy["bf16_bigvgan_b64x480_vs_batch1_rel_rms"] = worst0
+    assert worst0 == 0.0, worst0
 
 
-def test_config5_longform_fp8_weights_batched_and_sequential(mel, accuracy):
-    """BASELINE config 5: a 2000-char text = 20 sentences, GPT projection weights stored as fp8 e4m3 + row scales.
+def test_config5_longform_fp8_weights_batched_and_sequential(mel, accuracy, monkeypatch):
+    """(ITTS_GEMM_KSPLIT=0: the K split of few-tile GEMMs would give the one-sentence prefill a different fp32 summation order than the
+    20-sentence one - tests/test_gpu_bf16_accuracy.py::test_ksplit_changes_only_the_summation_order measures that; the subject here is
+    the fp8 decode kernels.)
+    BASELINE config 5: a 2000-char text = 20 sentences, GPT projection weights stored as fp8 e4m3 + row scales.
     (a) all 20 sentences as ONE decode batch (MFMA path, fp8 bytes read by skinny_mfma_kernel<W8>): codes and logits are
         bit-identical to an engine that reads the bf16 DEQUANTISATION of the same weights - the fp8 bytes really are what
         is streamed, and the conversion is exact;
     (b) the same sentences one at a time ("sequential chunks, fresh KV per chunk": GEMV path, gemv_bf16_kernel<W8>) agree
         with their row of the batch within the bf16 tolerance of the two kernel families (ids until the first near-tie)."""
+    monkeypatch.setenv("ITTS_GEMM_KSPLIT", "0")
     texts = np.stack([synth.text_ids(105, 900 + i, CFG.gpt.number_text_tokens) for i in range(20)]).astype(np.int32)
     n = 24
     res = {}
@@ -142,13 +154,15 @@ def test_config5_longform_fp8_weights_batched_and_sequential(mel, accuracy):
     assert worst < 3e-2, worst
 
 
-def test_rows_5_to_16_layernorm_in_projection_and_half_tiles(mel, accuracy):
-    """The reference's default mode decodes 3 beams per sentence, 2-4 sentences per bucket: 6-12 rows.  At 5-16 rows the
+def test_rows_5_to_16_layernorm_in_projection_and_half_tiles(mel, accuracy, monkeypatch):
+    """(ITTS_GEMM_KSPLIT=0, as above: (c) compares decode kernel families behind the SAME prefill arithmetic.)
+    The reference's default mode decodes 3 beams per sentence, 2-4 sentences per bucket: 6-12 rows.  At 5-16 rows the
     engine folds the LayerNorms into c_attn / c_fc and runs the residual projections as half tiles (decode_mfma.hip
     LNP / HALF), on the fragment-tiled weight copies.
     (a) a row's codes and logits do not depend on how many other rows share the batch (5, 9 or 16 rows: bit-identical);
     (b) fp8 weights (config 5's format) give the bits of their bf16 dequantisation on this path too;
     (c) against the 2-row GEMV path the first-step logits agree within the bf16 tolerance of the two kernel families."""
+    monkeypatch.setenv("ITTS_GEMM_KSPLIT", "0")
     texts = np.stack([synth.text_ids(105, 700 + i, CFG.gpt.number_text_tokens) for i in range(16)]).astype(np.int32)
     n = 20
     eng = ieng.build_engine(CFG, "bf16", parts=("gpt",), max_batch=16)

@@ -121,10 +121,13 @@ def test_full_roundtrip_properties_bf16(eng16, mel):
     assert wav.shape == (1, 1, 64 * 1024) and float(wav.abs().max()) <= 1.0 and torch.isfinite(wav).all()
 
 
-def test_full_batched_decode_matches_small_batch_bf16(eng16, mel, gold):
-    """Batched decode (B = 32 rows: LayerNorm row kernel, MFMA projections with tiled activations, split-K residual
+def test_full_batched_decode_matches_small_batch_bf16(eng16, mel, gold, monkeypatch):
+    """(ITTS_GEMM_KSPLIT=0: the two-sentence prefill would otherwise split K in mlp.c_proj and start the comparison of the DECODE
+    kernel families from prefills that differ in fp32 summation order.)
+    Batched decode (B = 32 rows: LayerNorm row kernel, MFMA projections with tiled activations, split-K residual
     projections, 256-thread cache attention) against the B = 2 GEMV path on the same two sentences: replicated rows
     are bit-identical, logits agree within bf16 tolerance while the greedy ids agree."""
+    monkeypatch.setenv("ITTS_GEMM_KSPLIT", "0")
     g = gold("full_decode_b1")
     cond = eng16.conditioning(mel)
     t2 = np.stack([g["text"][0], synth.text_ids(g["text"].shape[1], 77, CFG.gpt.number_text_tokens)]).astype(np.int32)

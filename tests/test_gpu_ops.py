@@ -72,6 +72,7 @@ def test_snake_vs_oracle(lib, shape, dt):
 
 
 def run_gemm(lib, A, W, Cshape, dt_a, dt_w, dt_c, force_simple=0, **kw):
+    kw_ws = {"ws": kw.pop("ws", None)}
     g = L.GemmArgs()
     for k in ("dil", "in_up", "nphase", "taps"):
         setattr(g, k, 1)
@@ -91,7 +92,12 @@ def run_gemm(lib, A, W, Cshape, dt_a, dt_w, dt_c, force_simple=0, **kw):
         setattr(g, k, v)
     g.dtype_a, g.dtype_w, g.dtype_c, g.force_simple = dt_a, dt_w, dt_c, force_simple
     run_gemm.which = int(lib.itts_gemm_which(C.byref(g)))  # kernel family the dispatcher took (include/itts_hip.h)
-    L.check(lib.itts_gemm(C.byref(g), stream()))
+    ws = kw_ws.get("ws")
+    if ws is not None:  # caller-owned K-split workspace (itts_gemm_ws)
+        run_gemm.ksplit = int(lib.itts_gemm_ksplit(C.byref(g), ws.numel() * ws.element_size()))
+        L.check(lib.itts_gemm_ws(C.byref(g), ws.data_ptr(), ws.numel() * ws.element_size(), stream()))
+    else:
+        L.check(lib.itts_gemm(C.byref(g), stream()))
     torch.cuda.synchronize()
     return Cout
 
@@ -591,6 +597,71 @@ def test_gemm_p8_repeats_are_identical(lib):
     assert run_gemm.which == 3
     for o in outs[1:]:
         assert torch.equal(o, outs[0])
+
+
+KSPLIT_CASES = [
+    # B, T, Cin, Cout, k, dil, mode, forced split (None = the planner's choice)
+    (1, 1242, 5120, 1280, 1, 1, "zeros", None),   # batch-1 latent mlp.c_proj: 25 tiles, 80 K-tiles -> 8 splits of 10
+    (2, 480, 1280, 1536, 7, 1, "zeros", None),    # BigVGAN conv_pre at batch 1: 24 tiles, 140 K-tiles (8 splits of 18, the last of 14)
+    (2, 1920, 768, 768, 11, 5, "reflect", None),  # stage-0 AMP conv: 45 tiles, 132 K-tiles, splits start inside a tap (12 chunks per tap)
+    (2, 1920, 768, 768, 7, 3, "zeros", 5),        # 84 K-tiles in 5 splits of 17: the last split has 16, odd counts (overshoot stages)
+    (1, 1000, 384, 384, 3, 1, "zeros", 3),        # 512 x 128 geometry: 2 x 3 tiles, 18 K-tiles in 3 splits of 6; M not a multiple of 512
+    (1, 142, 5120, 1280, 1, 1, "zeros", None),    # one-sentence prefill mlp.c_proj: ONE row tile, 142 of its 256 rows exist; 8 splits
+    (20, 142, 5120, 1280, 1, 1, "zeros", None),   # 20-sentence prefill: 60 tiles -> 3 splits of 27 / 27 / 26
+]
+
+
+@pytest.mark.parametrize("case", KSPLIT_CASES)
+@pytest.mark.parametrize("out_f32", [False, True])
+def test_gemm_p8_ksplit(lib, case, out_f32):
+    """K split over workgroups (itts_gemm_ws / the engine's few-tile GEMMs): raw sums per split, second launch adds them in split order
+    and runs the epilogue - against torch, against the register-staged kernel on the same arguments, and bit-identical on repeats."""
+    import os
+
+    B, T, Cin, Cout, k, dil, mode, force = case
+    x = rnd(f"ks.x{case}", (B, Cin, T)).to(torch.bfloat16)
+    w = rnd(f"ks.w{case}", (Cout, Cin, k), 1.0 / np.sqrt(Cin * k)).to(torch.bfloat16)
+    bias = rnd(f"ks.b{case}", (B, Cout), 0.1)
+    pad = dil * (k - 1) // 2
+    xp = F.pad(x.float(), (pad, pad), mode="reflect") if mode == "reflect" else F.pad(x.float(), (pad, pad))
+    ref = F.gelu(F.conv1d(xp, w.float(), None, dilation=dil) + bias[:, :, None], approximate="tanh")
+    res = rnd(f"ks.r{case}", (B, Cout, T)).to(torch.float32 if out_f32 else torch.bfloat16)
+    ref = (ref + res.float()) * 0.5
+    A = x.transpose(1, 2).contiguous().to(DEV)
+    W = torch.from_numpy(pack.conv_w(w.float().numpy())).to(torch.bfloat16).to(DEV)
+    R = res.transpose(1, 2).contiguous().to(DEV)
+    ws = torch.empty(64 << 20, dtype=torch.uint8, device=DEV)
+    kw = dict(M=B * T, N=Cout, Cin=Cin, taps=k, lda=Cin, ldc=Cout, T=T, dil=dil, pad_left=pad, pad_mode=1 if mode == "reflect" else 0,
+              bias=bias.to(DEV), bias_bstride=Cout, act=3, R=R, ldr=Cout, alpha=0.5)
+    dt_c = L.F32 if out_f32 else L.BF16
+    if force:
+        os.environ["ITTS_GEMM_KSPLIT"] = str(force)
+    try:
+        outs = [run_gemm(lib, A, W, (B, T, Cout), L.BF16, L.BF16, dt_c, 0, ws=ws, **kw) for _ in range(3)]
+        nsplit = run_gemm.ksplit
+    finally:
+        os.environ.pop("ITTS_GEMM_KSPLIT", None)
+    assert nsplit == (force or nsplit) and nsplit >= 2, nsplit
+    plain = run_gemm(lib, A, W, (B, T, Cout), L.BF16, L.BF16, dt_c, 0, **kw)  # no workspace: the unsplit dispatch
+    assert run_gemm.which in (1, 2, 3)
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    assert relerr(outs[0].float().transpose(1, 2), ref) < (3e-3 if out_f32 else 2e-2)
+    assert relerr(outs[0].float(), plain.float()) < (1e-4 if out_f32 else 1e-2)
+    d = (outs[0].float() - plain.float()).abs().max().item()
+    assert d < (2e-3 if out_f32 else 6e-2), d
+
+
+def test_gemm_ws_leaves_other_shapes_alone(lib):
+    """itts_gemm_ws on a shape with plenty of tiles (or too little K) is itts_gemm: same kernel, same bits."""
+    B, T, Cin, Cout, k = 2, 16384, 768, 768, 3
+    x = rnd("p8r.x", (B, T, Cin)).to(torch.bfloat16).to(DEV)
+    W = torch.from_numpy(pack.conv_w(rnd("p8r.w", (Cout, Cin, k), 1.0 / np.sqrt(Cin * k)).float().numpy())).to(torch.bfloat16).to(DEV)
+    ws = torch.empty(64 << 20, dtype=torch.uint8, device=DEV)
+    kw = dict(M=B * T, N=Cout, Cin=Cin, taps=k, lda=Cin, ldc=Cout, T=T, dil=1, pad_left=1)
+    a = run_gemm(lib, x, W, (B, T, Cout), L.BF16, L.BF16, L.BF16, 0, ws=ws, **kw)
+    assert run_gemm.ksplit == 1
+    b = run_gemm(lib, x, W, (B, T, Cout), L.BF16, L.BF16, L.BF16, 0, **kw)
+    assert torch.equal(a, b)
 
 
 @pytest.mark.parametrize("dims", [(2, 6144, 1536, 768), (2, 12288, 768, 384)])

@@ -14,7 +14,13 @@ import torch  # noqa: E402
 from itts_hip import lib as L  # noqa: E402
 
 
-def run(lib, M, T, N, Cin, taps, dil, nphase=1, reps=10, old=False, p8=True):
+_WS = None
+
+
+def run(lib, M, T, N, Cin, taps, dil, nphase=1, reps=10, old=False, p8=True, ksplit=None):
+    """ksplit: None = itts_gemm (no workspace, never splits K); "auto" / int = itts_gemm_ws with a 64 MiB workspace (int forces
+    that split count on eligible shapes through ITTS_GEMM_KSPLIT)."""
+    global _WS
     dev = "cuda:0"
     A = torch.randn(M, Cin, device=dev).to(torch.bfloat16)
     W = (torch.randn(nphase, N, taps * Cin, device=dev) / (taps * Cin) ** 0.5).to(torch.bfloat16)
@@ -32,14 +38,28 @@ def run(lib, M, T, N, Cin, taps, dil, nphase=1, reps=10, old=False, p8=True):
     os.environ["ITTS_GEMM_P8"] = "1" if p8 else "0"
     which = int(lib.itts_gemm_which(C.byref(g)))
     s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    if ksplit is None:
+        call = lambda: lib.itts_gemm(C.byref(g), s)  # noqa: E731
+    else:
+        if _WS is None:
+            _WS = torch.empty(64 << 20, dtype=torch.uint8, device=dev)
+        if ksplit == "auto":
+            os.environ.pop("ITTS_GEMM_KSPLIT", None)
+        else:
+            os.environ["ITTS_GEMM_KSPLIT"] = str(ksplit)
+        ns = int(lib.itts_gemm_ksplit(C.byref(g), _WS.numel()))
+        if ns > 1:
+            which = 30 + ns
+        call = lambda: lib.itts_gemm_ws(C.byref(g), _WS.data_ptr(), _WS.numel(), s)  # noqa: E731
     for _ in range(2):
-        L.check(lib.itts_gemm(C.byref(g), s))
+        L.check(call())
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(reps):
-        lib.itts_gemm(C.byref(g), s)
+        call()
     e1.record()
     torch.cuda.synchronize()
+    os.environ.pop("ITTS_GEMM_KSPLIT", None)
     us = e0.elapsed_time(e1) * 1e3 / reps
     return us, 2.0 * M * N * nphase * taps * Cin / us / 1e6, which
 
@@ -47,6 +67,7 @@ def run(lib, M, T, N, Cin, taps, dil, nphase=1, reps=10, old=False, p8=True):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--ksplit", action="store_true", help="K-split sweep (itts_gemm_ws): no split / auto / 2 / 4 / 8 per shape")
     a = ap.parse_args()
     lib = L.load()
     rows = 2 * a.batch  # sentences
@@ -64,6 +85,17 @@ def main():
     for nm, N, K in (("latent c_attn", 3840, 1280), ("latent c_proj", 1280, 1280), ("latent c_fc", 5120, 1280), ("latent proj2", 1280, 5120)):
         shapes.append((nm, rows * n, rows * n, N, K, 1, 1, 1))
     names = {0: "valu", 1: "mfma", 2: "glds", 3: "p8", 4: "convlds"}
+    names.update({30 + k: "p8/%d" % k for k in range(2, 9)})
+    if a.ksplit:
+        extra = [("prefill proj2 (2 x 142 rows)", 284, 284, 1280, 5120, 1, 1, 1), ("prefill c_fc", 284, 284, 5120, 1280, 1, 1, 1)]
+        print(f"{'shape':30s} {'M':>7s}  " + "  ".join(f"{h:>14s}" for h in ("no split", "auto", "S=2", "S=4", "S=8")))
+        for nm, M, T, N, Cin, taps, dil, nph in shapes + extra:
+            cols = []
+            for ks in (None, "auto", 2, 4, 8):
+                us, tf, wh = run(lib, M, T, N, Cin, taps, dil, nph, ksplit=ks)
+                cols.append(f"{names[wh]:>5s} {us:7.1f}us")
+            print(f"{nm:30s} {M:7d}  " + "  ".join(cols), flush=True)
+        return
     print(f"{'shape':28s} {'M':>9s}  {'default':>8s} {'us':>9s} {'TF/s':>7s}   {'no-p8':>7s} {'us':>9s} {'TF/s':>7s}   {'old us':>9s} {'TF/s':>7s}  default vs no-p8")
     for nm, M, T, N, Cin, taps, dil, nph in shapes:
         new = run(lib, M, T, N, Cin, taps, dil, nph)
