@@ -2,6 +2,7 @@
 // caller's arena and are bound by name (itts_engine_bind_tensor).
 #pragma once
 #include <map>
+#include <utility>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -199,6 +200,21 @@ struct Engine {
     return dry ? (void*)(uintptr_t)(0x1000 + a) : (void*)(ws + a);
   }
   int ws_reserve(size_t bytes, hipStream_t s);
+  // A second scratch arena for the speaker encoder: Engine::ecapa swaps it in for the duration of the call, so that the caller may
+  // run it on a side stream beside the conditioning encoder / the prefill (both are chains of small kernels that leave most of the
+  // chip idle; itts_hip/engine.py ecapa(overlap=True)).  K-split GEMMs are off inside the swap (one split workspace per engine).
+  char* ws_b = nullptr;
+  size_t ws_b_cap = 0;
+  bool ksplit_off = false;
+  struct ArenaSwap {
+    Engine& e;
+    explicit ArenaSwap(Engine& en) : e(en) { flip(); e.ksplit_off = true; }
+    ~ArenaSwap() { flip(); e.ksplit_off = false; }
+    void flip() {
+      std::swap(e.ws, e.ws_b);
+      std::swap(e.ws_cap, e.ws_b_cap);
+    }
+  };
   // raw partial sums of K-split GEMMs (Engine::conv): [split][M][N] fp32, allocated at the first split launch
   static constexpr size_t KSPLIT_WS_BYTES = size_t(64) << 20;
   float* ksplit_ws = nullptr;

@@ -8,6 +8,7 @@ namespace itts {
 
 Engine::~Engine() {
   if (ws) (void)hipFree(ws);
+  if (ws_b) (void)hipFree(ws_b);
   if (gpt_tiles) (void)hipFree(gpt_tiles);
   DecodeState& d = ds;
   void* ptrs[] = {d.kc, d.vc, d.h, d.qkv, d.ctx, d.act, d.hn, d.logits, d.len, d.prefix_dev,
@@ -89,7 +90,7 @@ int Engine::conv(GemmArgs& g, int ta, int tw, int tc, hipStream_t s) {
   if (dry) return OK;
   if (force_simple) return gemm_simple(g, ta, tw, tc, s);
   // few-tile deep-K shapes split K over workgroups (this engine's own fp32 workspace: engines on other streams have theirs)
-  const int S = gemm_ksplit_plan(g, ta, tw, tc, KSPLIT_WS_BYTES);
+  const int S = ksplit_off ? 1 : gemm_ksplit_plan(g, ta, tw, tc, KSPLIT_WS_BYTES);
   if (S > 1) {
     if (!ksplit_ws) {  // first use (prefill / latent / vocoder: never inside a graph capture)
       if (hipMalloc((void**)&ksplit_ws, KSPLIT_WS_BYTES) != hipSuccess) {

@@ -196,6 +196,7 @@ int Engine::ecapa(const void* mel, int B, int F, float* spk_out, hipStream_t s) 
     ITTS_TRY(lin(spk_out, F32, pooled, F32, 2 * C4, ec.fc, B, c.bv_spk_dim, s));
     return OK;
   };
+  ArenaSwap arena(*this);  // its own scratch: may run beside this engine's work on another stream
   return two_pass(body, s);
 }
 

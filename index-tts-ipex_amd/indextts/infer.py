@@ -200,8 +200,9 @@ class IndexTTS:
             raise RuntimeError("IndexTTS: the text produced no sentences (empty input)")
         self._set_gr_progress(0.1, "text processing...")
         with self.engine.lock:
+            # the speaker embedding (needed by the vocoder only) on the engine's side stream, beside the conditioning encoder and the prefill
+            spk = self.engine.ecapa(prompt_mel.transpose(1, 2), overlap=True)
             cond = self.gpt.get_conditioning(prompt_mel)
-            spk = self.engine.ecapa(prompt_mel.transpose(1, 2))
             t_gen = t_fwd = t_voc = 0.0
             t0 = time.perf_counter()
             code_rows = [None] * len(sents)
@@ -251,8 +252,8 @@ class IndexTTS:
         with self.engine.lock:
             for us in groups.values():
                 mel = self._prompt(prompts[us[0]], None)
+                spk = self.engine.ecapa(mel.transpose(1, 2), overlap=True)
                 cond = self.gpt.get_conditioning(mel)
-                spk = self.engine.ecapa(mel.transpose(1, 2))
                 flat = [(u, k, s) for u in us for k, s in enumerate(utt_sents[u])]
                 if not flat:
                     continue

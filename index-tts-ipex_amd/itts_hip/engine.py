@@ -103,6 +103,8 @@ class Engine:
         self.device = torch.device(device)
         torch.cuda.set_device(self.device)
         self.stream = torch.cuda.Stream(device=self.device)
+        self.side = torch.cuda.Stream(device=self.device)  # ecapa(overlap=True): the speaker encoder beside conditioning / prefill
+        self._side_busy = False
         self.ccfg = make_config(cfg, self.dt, max_batch)
         h = C.c_void_p()
         self._ck(self.lib.itts_engine_create(C.byref(self.ccfg), C.byref(h)), "engine_create")
@@ -162,7 +164,22 @@ class Engine:
         self.stream.wait_stream(torch.cuda.current_stream(self.device))
 
     def _exit(self):
+        # (NOT the side stream: the caller's stream is what the next engine call waits for in _enter(), and an overlapped ecapa()
+        #  must not hold that call up - its result is joined where it is consumed: _join_side())
         torch.cuda.current_stream(self.device).wait_stream(self.stream)
+
+    def join_side(self):
+        """After ecapa(overlap=True): make the engine's stream AND the caller's current stream wait for the speaker embedding."""
+        if self._side_busy:
+            torch.cuda.current_stream(self.device).wait_stream(self.side)
+        self._join_side()
+
+    def _join_side(self):
+        """The engine's own stream waits for an overlapped ecapa(): in front of the decode steps (the persistent decode engine wants
+        every CU of the device) and of the vocoder (which reads the embedding)."""
+        if self._side_busy:
+            self.stream.wait_stream(self.side)
+            self._side_busy = False
 
     def to_act(self, x: torch.Tensor) -> torch.Tensor:
         return x.to(device=self.device, dtype=self.tdt).contiguous()
@@ -184,11 +201,24 @@ class Engine:
         mel.record_stream(self.stream)
         return out
 
-    def ecapa(self, mel_bfc: torch.Tensor) -> torch.Tensor:
-        """mel_ref [B, F, n_mels] -> spk fp32 [B, E]."""
+    def ecapa(self, mel_bfc: torch.Tensor, overlap: bool = False) -> torch.Tensor:
+        """mel_ref [B, F, n_mels] -> spk fp32 [B, E].
+        overlap=True: enqueued on the engine's SIDE stream (its own scratch arena in the library), so that the engine calls that
+        FOLLOW - conditioning, prefill: chains of small kernels, as this one - run beside it (conditioning + speaker encoder 3.65 ->
+        2.40 ms at IndexTTS-1.5 sizes).  CONTRACT: the returned tensor is for THIS engine's vocoder calls (bigvgan / bigvgan_grouped
+        join the side stream themselves, and so does prefill() in front of the decode steps); any other consumer calls
+        join_side() first.  IndexTTS.infer / infer_batch and bench.py use it exactly so."""
         mel = self.to_act(mel_bfc)
         B, F, _ = mel.shape
         out = torch.empty(B, self.ccfg.bv_spk_dim, dtype=torch.float32, device=self.device)
+        if overlap:
+            self._join_side()  # one overlapped call at a time (one side arena)
+            self.side.wait_stream(torch.cuda.current_stream(self.device))
+            self._ck(self.lib.itts_ecapa(self.h, mel.data_ptr(), B, F, out.data_ptr(), C.c_void_p(self.side.cuda_stream)), "ecapa")
+            self._side_busy = True
+            mel.record_stream(self.side)
+            out.record_stream(self.side)
+            return out
         self._enter()
         self._ck(self.lib.itts_ecapa(self.h, mel.data_ptr(), B, F, out.data_ptr(), self._s()), "ecapa")
         self._exit()
@@ -207,6 +237,7 @@ class Engine:
         self._enter()
         self._ck(self.lib.itts_gpt_prefill(self.h, cond.data_ptr(), ids.ctypes.data_as(C.c_void_p), B, Lt, max_gen,
                                           float(repetition_penalty), int(suppress_stop), self._s()), "gpt_prefill")
+        self._join_side()  # an overlapped ecapa() ends before the first decode step
         self._gen = (B, max_gen)
 
     def set_sampling(self, do_sample: bool, top_k: int = 30, top_p: float = 0.8, temperature: float = 1.0,
@@ -484,6 +515,7 @@ class Engine:
         spk = spk.to(device=self.device, dtype=torch.float32).contiguous().view(B, -1)
         out = torch.empty(B, 1, T * self.up_total, dtype=torch.float32, device=self.device)
         self._enter()
+        self._join_side()
         self._ck(self.lib.itts_bigvgan(self.h, lat.data_ptr(), spk.data_ptr(), B, T, out.data_ptr(), self._s()), "bigvgan")
         self._exit()
         lat.record_stream(self.stream)

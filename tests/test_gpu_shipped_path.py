@@ -373,3 +373,32 @@ def test_beam_sample_wide_top_k0_equals_the_oracle_step_by_step(eng32s, mel):
     assert min(widths) > 128, f"the case is meant to exceed the device sampler's 128 candidates per beam (kept {min(widths)} .. {max(widths)})"
     n = min(got.shape[1], want.shape[1])
     assert got.shape[0] == items and np.array_equal(got[:, :n], want[:, :n]), (got, want)
+
+
+def test_speaker_encoder_on_the_side_stream_is_the_same_embedding(mel):
+    """Engine.ecapa(overlap=True) (IndexTTS.infer: the speaker encoder on the engine's side stream, with its own scratch arena, beside
+    the conditioning encoder and the prefill): the embedding, the conditioning latents computed beside it, the prefill logits and the
+    waveform of a vocoder call that consumes the overlapped embedding are bit-identical to the serial order - over several rounds,
+    so that a race between the two arenas would have its chances."""
+    cfg = icfg.indextts_1_5()
+    eng = ieng.build_engine(cfg, "bf16", parts=("gpt", "bigvgan"))
+    texts = np.stack([synth.text_ids(40, 5 + i, cfg.gpt.number_text_tokens) for i in range(2)]).astype(np.int32)
+    lat = torch.randn(1, 24, cfg.bigvgan.gpt_dim, generator=torch.Generator().manual_seed(3))
+    spk0 = eng.ecapa(mel.transpose(1, 2))
+    cond0 = eng.conditioning(mel)
+    eng.prefill(cond0, texts, 4, 10.0, True)
+    lg0 = eng.fetch(logits=True)[1].copy()
+    eng._exit()
+    wav0 = eng.bigvgan(lat, spk0)
+    torch.cuda.synchronize()
+    for _ in range(4):
+        spk = eng.ecapa(mel.transpose(1, 2), overlap=True)
+        cond = eng.conditioning(mel)
+        eng.prefill(cond, texts, 4, 10.0, True)
+        lg = eng.fetch(logits=True)[1].copy()
+        eng._exit()
+        wav = eng.bigvgan(lat, spk)
+        eng.join_side()
+        torch.cuda.synchronize()
+        assert torch.equal(spk, spk0) and torch.equal(cond, cond0)
+        assert np.array_equal(lg, lg0) and torch.equal(wav, wav0)
