@@ -1,3 +1,5 @@
+"""Conditioning encoder, speaker encoder, and the pair with the speaker encoder on the engine's side stream (Engine.ecapa(overlap=True)):
+ms per call at IndexTTS-1.5 sizes, prompt of 511 frames.   python tools/t_ecapa.py"""
 import sys, time, torch, numpy as np
 sys.path.insert(0, "/root/repo/index-tts-ipex_amd")
 from itts_hip import config as icfg, engine as ieng, synth
