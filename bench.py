@@ -446,6 +446,18 @@ def main():
                 torch.cuda.empty_cache()
             except Exception as e:  # noqa: BLE001
                 also["config5_longform_fp8"] = {"error": repr(e)[:200]}
+            try:  # the reference's own GPU precision (is_fp16=True = IEEE half: libitts_hip_f16.so), same utterance, same kernels' f16 build
+                eng16 = build_engine_dp(cfg, "f16", device)
+                a16 = copy.copy(a)
+                a16.dtype = "f16"
+                m16 = measure(eng16, cfg, a16, a.batch, 3, 1, rank, world)
+                also["ieee_half_f16"] = {"value": m16["value"], "unit": "audio-s/s", "steps": 3, "warmup": 1, "ms_per_step": m16["ms_per_step"],
+                                         "vs_headline": round(m16["value"] / max(m["value"], 1e-9), 4), "dtype": "f16",
+                                         "decode_ms_per_token_step": m16["roofline"]["avg_launch_ms"], "decode_mode": eng16.decode_mode()}
+                del eng16
+                torch.cuda.empty_cache()
+            except Exception as e:  # noqa: BLE001
+                also["ieee_half_f16"] = {"error": repr(e)[:200]}
         out["also"] = also
     if rank == 0:
         if not a.no_cpu_baseline:
