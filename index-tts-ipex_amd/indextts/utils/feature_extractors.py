@@ -3,8 +3,9 @@
 100 mels, center=True, power=1) followed by safe_log(clip 1e-7)).  torchaudio is not a dependency here: the STFT is
 torch.stft and the filterbank is the HTK-scale, un-normalised triangular bank torchaudio builds by default.
 `resample` restates torchaudio.transforms.Resample's published algorithm (Hann-windowed sinc polyphase bank).
-Runs once per prompt on the host (torchaudio is absent offline, so parity is pinned analytically in
-tests/test_host_logic.py - filterbank / STFT identities, resampler tone and DC tests - not against torchaudio outputs)."""
+Runs once per prompt on the host.  PARITY UNPINNED: torchaudio is absent offline and the reference holds no
+mel values, so this file is checked analytically only (tests/test_host_logic.py, tests/test_frontend_cpu.py: filterbank / STFT
+identities, resampler tone and DC tests) - not against torchaudio outputs."""
 from __future__ import annotations
 
 import math
